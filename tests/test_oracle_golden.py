@@ -1,0 +1,65 @@
+"""CPU: the oracle (oracle/cunet_ref.py) reproduces the reference's golden vectors bit-for-bit.
+
+The vectors were produced by running the reference itself (tools/gen_golden.py); this test pins
+the oracle without needing /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cunet_ref as O
+from tests._golden import TINY, Golden
+
+
+@pytest.mark.parametrize('tag', TINY)
+def test_oracle_train_step_matches_reference(tag):
+    g = Golden(tag)
+    spec = O.Spec(**g.cfg)
+    st = g.group('state0')
+    assert list(st.keys()) == [e[0] for e in O.state_entries(spec)]
+    x, target = g.t('x'), g.t('target')
+    loss, outs, grads = O.train_step(spec, st, x, target)
+    assert torch.equal(loss, g.t('loss'))
+    for a, b in zip(outs, g.list('out')):
+        assert torch.equal(a, b)
+    gg = g.group('grad')
+    none = set(g.z['grad_none'].tolist())
+    for k, v in grads.items():
+        if v is None:
+            assert k in none
+        else:
+            assert torch.equal(v, gg[k]), k
+    for k, v in g.group('state1').items():
+        assert torch.equal(st[k], v), k
+    # eval forward on the post-step state
+    ev = O.forward(spec, st, x, training=False)
+    for a, b in zip(ev, g.list('eval')):
+        assert torch.equal(a, b)
+    # train-mode forward without backward: single running-stat update
+    with torch.no_grad():
+        O.forward(spec, st, x, training=True)
+    for k, v in g.group('state2').items():
+        assert torch.equal(st[k], v), k
+
+
+def test_oracle_full_width_matches_reference():
+    g = Golden('G5_full_L2K68')
+    spec = O.Spec(**g.cfg)
+    st = O.init_state(spec, seed=int(g.z['init_seed']))
+    x, target = O.synthetic_batch(1, spec.class_num, 256, seed=int(g.z['batch_seed']))
+    loss, outs, grads = O.train_step(spec, st, x, target, apply_update=False)
+    np.testing.assert_allclose(float(loss), float(g.z['loss']), rtol=1e-6)
+    for i, o in enumerate(outs):
+        assert torch.equal(o[:, ::4, ::4, ::4], g.t(f'out_sub/{i}'))
+    names = g.z['grad_norm_names'].tolist()
+    for k, n in zip(names, g.z['grad_norms']):
+        np.testing.assert_allclose(float(grads[k].double().norm()), n, rtol=1e-5)
+
+
+def test_spec_validation():
+    with pytest.raises(AssertionError):
+        O.Spec(4, 32, 128, 16, 2, 1, 3)
+    with pytest.raises(ValueError):
+        O.Spec(4, 32, 128, 16, 2, 2, 2)
+    assert O.Spec(4, 32, 128, 16, 4, 1, 2).loss_anchors == [2, 4]
+    n = sum(int(np.prod(s)) for _, s, k in O.state_entries(O.Spec(4, 32, 128, 68, 2, 1, 2)) if k == 'param')
+    assert n == 1936512   # SURVEY.md section 6 probe

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the CU-Net hot path by RUNNING THE REFERENCE (this container only).
+
+The reference (`/root/reference/models/cu_net.py`) is Python 2; it is imported here through an
+in-memory source shim (two textual patches, nothing is written to /root/reference and no
+reference text is stored in this repo):
+    print 'x'                ->  print('x')          (models/cu_net.py:286)
+    adapter_out_num / 2      ->  adapter_out_num // 2 (models/cu_net.py:94, py3 true division)
+The fixtures written under tests/golden/ are DATA ONLY (inputs, parameters, expected outputs).
+
+While generating, the script also checks `oracle/cunet_ref.py` against the reference
+(outputs, loss, every gradient, running statistics after one train step, RMSprop update) and
+refuses to write fixtures if the oracle disagrees.
+
+Usage:  python -B tools/gen_golden.py      (needs /root/reference; not runnable on the GPU box)
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get('CUNET_REFERENCE', '/root/reference')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+from oracle import cunet_ref as O  # noqa: E402
+
+
+def load_reference_models():
+    src = open(os.path.join(REF, 'models', 'cu_net.py')).read()
+    src = src.replace("print 'order is larger than the layer number.'",
+                      "print('order is larger than the layer number.')")
+    src = src.replace('adapter_out_num = adapter_out_num / 2', 'adapter_out_num = adapter_out_num // 2')
+    mod = types.ModuleType('ref_cu_net')
+    exec(compile(src, '<reference models/cu_net.py via shim>', 'exec'), mod.__dict__)
+    return mod
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def check(name, a, b, exact=True):
+    a, b = to_np(a), to_np(b)
+    if exact:
+        ok = np.array_equal(a, b)
+    else:
+        ok = np.allclose(a, b, rtol=1e-6, atol=1e-7)
+    if not ok:
+        raise SystemExit(f'ORACLE MISMATCH at {name}: max abs diff {np.abs(a - b).max()}')
+
+
+def one_config(ref, tag, cfg, n, hw, seed):
+    torch.manual_seed(seed)
+    net = quiet(ref.create_cu_net, **cfg)
+    spec = O.Spec(**cfg)
+    # --- state layout must match key-for-key, shape-for-shape, in order
+    sd = net.state_dict()
+    ents = O.state_entries(spec)
+    assert [k for k in sd.keys()] == [e[0] for e in ents], 'state_dict key order differs'
+    for (k, v), (_, shp, _) in zip(sd.items(), ents):
+        assert tuple(v.shape) == tuple(shp), (k, v.shape, shp)
+    # make BN betas / running stats non-trivial so the fixture pins them
+    g = torch.Generator().manual_seed(seed + 100)
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.endswith('.bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith('running_mean'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith('running_var'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.rand(n, 3, hw, hw, generator=g)
+    target = torch.rand(n, cfg['class_num'], hw // 4, hw // 4, generator=g)
+
+    fx = {'cfg': np.array([cfg[k] for k in ('neck_size', 'growth_rate', 'init_chan_num', 'class_num',
+                                              'layer_num', 'order', 'loss_num')], dtype=np.int64),
+          'x': to_np(x), 'target': to_np(target)}
+    for k, v in state0.items():
+        fx['state0/' + k] = to_np(v)
+
+    # --- reference: one train step (cu-net.py:171-183) with RMSprop (cu-net.py:60-61)
+    net.train()
+    opt = torch.optim.RMSprop(net.parameters(), lr=2.5e-4, alpha=0.99, eps=1e-8, momentum=0, weight_decay=0)
+    out = net(x)
+    loss = 0
+    for o in out:
+        t = (o - target) ** 2
+        loss = loss + t.sum() / t.numel()
+    opt.zero_grad()
+    loss.backward()
+    ref_grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+    opt.step()
+    state1 = {k: v.clone() for k, v in net.state_dict().items()}
+
+    # --- oracle on the same inputs
+    ost = {k: v.clone() for k, v in state0.items()}
+    oloss, oouts, ograds = O.train_step(spec, ost, x, target)
+    check(tag + '/loss', loss, oloss)
+    for i, (a, b) in enumerate(zip(out, oouts)):
+        check(f'{tag}/out{i}', a, b)
+    for k, gr in ref_grads.items():
+        if gr is None:
+            assert ograds[k] is None, k
+        else:
+            check(f'{tag}/grad/{k}', gr, ograds[k])
+    for k, v in state1.items():
+        check(f'{tag}/state1/{k}', v, ost[k])
+
+    fx['loss'] = to_np(loss)
+    for i, o in enumerate(out):
+        fx[f'out/{i}'] = to_np(o)
+    for k, gr in ref_grads.items():
+        if gr is not None:
+            fx['grad/' + k] = to_np(gr)
+    fx['grad_none'] = np.array([k for k, gr in ref_grads.items() if gr is None], dtype='U')
+    for k, v in state1.items():
+        fx['state1/' + k] = to_np(v)
+
+    # --- eval-mode forward on the post-step state (pins running-stat usage; G8)
+    net.eval()
+    with torch.no_grad():
+        eout = net(x)
+        oe = O.forward(spec, ost, x, training=False)
+    for i, (a, b) in enumerate(zip(eout, oe)):
+        check(f'{tag}/eval{i}', a, b)
+        fx[f'eval/{i}'] = to_np(a)
+
+    # --- train-mode forward WITHOUT backward: single running-stat update everywhere
+    net.train()
+    with torch.no_grad():
+        net(x)
+        O.forward(spec, ost, x, training=True)
+    for k, v in net.state_dict().items():
+        if 'running' in k or 'tracked' in k:
+            check(f'{tag}/state2/{k}', v, ost[k])
+            fx['state2/' + k] = to_np(v)
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **fx)
+    nparam = sum(p.numel() for p in net.parameters())
+    print(f'{tag}: {cfg} N={n} hw={hw} params={nparam} loss={float(loss):.6f}  oracle == reference')
+
+
+def full_width(ref):
+    """G5: full-width CU-Net-2 (K=68), N=1, 256x256: reference outputs on the oracle's own
+    deterministic init (seed) and synthetic batch; stored sub-sampled + checksums."""
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=2)
+    x, target = O.synthetic_batch(1, 68, 256, seed=0)
+    net = quiet(ref.create_cu_net, **cfg)
+    net.load_state_dict(st)
+    net.train()
+    out = net(x)
+    loss = sum(((o - target) ** 2).mean() for o in out)
+    loss.backward()
+    ost = {k: v.clone() for k, v in st.items()}
+    oloss, oouts, ograds = O.train_step(spec, ost, x, target, apply_update=False)
+    check('G5/loss', loss, oloss, exact=False)
+    fx = {'cfg': np.array(list(cfg.values()), dtype=np.int64), 'init_seed': np.array(2), 'batch_seed': np.array(0),
+          'loss': to_np(loss)}
+    for i, (a, b) in enumerate(zip(out, oouts)):
+        check(f'G5/out{i}', a, b)
+        fx[f'out_sub/{i}'] = to_np(a)[:, ::4, ::4, ::4].copy()
+        fx[f'out_sum/{i}'] = np.array([to_np(a).astype(np.float64).sum(), np.abs(to_np(a).astype(np.float64)).sum()])
+    gsum = {}
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            check('G5/grad/' + k, p.grad, ograds[k])
+            gsum[k] = float(p.grad.double().norm())
+    fx['grad_norm_names'] = np.array(list(gsum.keys()), dtype='U')
+    fx['grad_norms'] = np.array(list(gsum.values()))
+    np.savez_compressed(os.path.join(OUT, 'G5_full_L2K68.npz'), **fx)
+    print(f'G5: full width L2/K68 N=1 loss={float(loss):.6f}  oracle == reference')
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = load_reference_models()
+    tiny = dict(neck_size=2, growth_rate=4, init_chan_num=8)
+    one_config(ref, 'G1_L2_o1', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=2, hw=64, seed=11)
+    one_config(ref, 'G2_L3_o2', dict(tiny, class_num=5, layer_num=3, order=2, loss_num=3), n=2, hw=64, seed=12)
+    one_config(ref, 'G3_L4_o1_ln2', dict(tiny, class_num=3, layer_num=4, order=1, loss_num=2), n=2, hw=64, seed=13)
+    one_config(ref, 'G4_L2_o0', dict(tiny, class_num=4, layer_num=2, order=0, loss_num=1), n=3, hw=64, seed=14)
+    # wider channels (multiples of 32 like the real net), one image, rectangular-free 128x128 input
+    one_config(ref, 'G9_L2_o1_c32', dict(neck_size=2, growth_rate=16, init_chan_num=32, class_num=6,
+                                         layer_num=2, order=1, loss_num=2), n=1, hw=128, seed=15)
+    full_width(ref)
+
+
+if __name__ == '__main__':
+    main()
