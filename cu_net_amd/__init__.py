@@ -1,0 +1,12 @@
+"""cu_net_amd -- MI355X-native (gfx950) Coupled U-Net hot path.
+
+(The directory is named `cu_net_amd` rather than `cu-net_amd` because a hyphen is not importable.)
+
+Public surface mirrors the reference (zhiqiangdon/CU-Net):
+    create_cu_net(neck_size, growth_rate, init_chan_num, class_num, layer_num, order, loss_num)
+plus the fused train step (`FusedTrainer`), data parallelism over RCCL (`cu_net_amd.parallel`),
+the landmark decode (`get_preds`) and the weight quantisers (`cu_net_amd.quant`).
+"""
+from ._lib import CUNetError, LIB_PATH  # noqa: F401
+from .module import CUNet, create_cu_net  # noqa: F401
+from .trainer import FusedTrainer, get_preds  # noqa: F401

@@ -1,0 +1,165 @@
+"""ctypes binding of libcunet_hip.so (include/cunet.h).
+
+The library is built in-tree by `cu_net_amd/csrc/build.sh` (or `__graft_entry__.build()`).
+There is NO fallback: if the shared object is missing or a call fails, a CUNetError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcunet_hip.so')
+
+
+class CUNetError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('neck_size', 'growth_rate', 'init_chan_num', 'class_num', 'layer_num',
+                                         'order', 'loss_num', 'batch', 'height', 'width')]
+
+
+class StateDesc(C.Structure):
+    _fields_ = [('name', C.c_char * 160), ('kind', C.c_int32), ('ndim', C.c_int32), ('shape', C.c_int64 * 4),
+                ('offset', C.c_int64), ('numel', C.c_int64)]
+
+
+BUCKET_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once). Raises CUNetError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CUNetError(f'{LIB_PATH} not found: build it with cu_net_amd/csrc/build.sh '
+                         '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    sig = {
+        'cunet_last_error': (C.c_char_p, []),
+        'cunet_version': (C.c_char_p, []),
+        'cunet_plan_create': (i32, [C.POINTER(Cfg), C.POINTER(vp)]),
+        'cunet_plan_destroy': (None, [vp]),
+        'cunet_state_count': (i32, [vp]),
+        'cunet_state_entry': (i32, [vp, i32, C.POINTER(StateDesc)]),
+        'cunet_param_numel': (i64, [vp]),
+        'cunet_buffer_numel': (i64, [vp]),
+        'cunet_counter_numel': (i64, [vp]),
+        'cunet_workspace_bytes': (i64, [vp, i32]),
+        'cunet_num_heads': (i32, [vp]),
+        'cunet_loss_anchors': (i32, [vp, C.POINTER(C.c_int32), i32]),
+        'cunet_plan_describe': (C.c_char_p, [vp]),
+        'cunet_bind': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+        'cunet_forward': (i32, [vp, vp, C.POINTER(vp), i32, vp]),
+        'cunet_loss_mse': (i32, [vp, vp, vp, vp]),
+        'cunet_backward': (i32, [vp, C.POINTER(vp), vp]),
+        'cunet_num_buckets': (i32, [vp]),
+        'cunet_bucket_range': (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+        'cunet_backward_ex': (i32, [vp, C.POINTER(vp), vp, BUCKET_CB, vp]),
+        'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
+        'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+        'cunet_debug_tensor_offset': (i64, [vp, C.c_char_p, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)      # AttributeError here == the ABI in include/cunet.h is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_plan_destroy', 'cunet_state_count',
+            'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
+            'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind',
+            'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_num_buckets',
+            'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds',
+            'cunet_debug_tensor_offset']
+
+
+def check(rc: int, what: str = ''):
+    if rc < 0:
+        msg = lib().cunet_last_error().decode()
+        raise CUNetError(f'{what}: {msg} (status {rc})')
+    return rc
+
+
+class PlanHandle:
+    """Owns one cunet_plan_t (host object; device memory stays caller-owned)."""
+
+    def __init__(self, neck_size, growth_rate, init_chan_num, class_num, layer_num, order, loss_num,
+                 batch, height, width):
+        L = lib()
+        self.cfg = Cfg(neck_size, growth_rate, init_chan_num, class_num, layer_num, order, loss_num,
+                       batch, height, width)
+        h = C.c_void_p()
+        check(L.cunet_plan_create(C.byref(self.cfg), C.byref(h)), 'cunet_plan_create')
+        self.h = h
+        self._desc = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                lib().cunet_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- layout
+    def state_entries(self):
+        L = lib()
+        out = []
+        d = StateDesc()
+        for i in range(L.cunet_state_count(self.h)):
+            check(L.cunet_state_entry(self.h, i, C.byref(d)), 'cunet_state_entry')
+            out.append((d.name.decode(), int(d.kind), tuple(int(d.shape[k]) for k in range(d.ndim)),
+                        int(d.offset), int(d.numel)))
+        return out
+
+    @property
+    def param_numel(self):
+        return int(lib().cunet_param_numel(self.h))
+
+    @property
+    def buffer_numel(self):
+        return int(lib().cunet_buffer_numel(self.h))
+
+    @property
+    def counter_numel(self):
+        return int(lib().cunet_counter_numel(self.h))
+
+    def workspace_bytes(self, training: bool):
+        return int(lib().cunet_workspace_bytes(self.h, 1 if training else 0))
+
+    @property
+    def num_heads(self):
+        return int(lib().cunet_num_heads(self.h))
+
+    def anchors(self):
+        buf = (C.c_int32 * 64)()
+        n = check(lib().cunet_loss_anchors(self.h, buf, 64), 'cunet_loss_anchors')
+        return [int(buf[i]) for i in range(n)]
+
+    def buckets(self):
+        """[(begin, count)] float ranges of the parameter/gradient arena; last one is the stem."""
+        L = lib()
+        out = []
+        b, c = C.c_int64(), C.c_int64()
+        for i in range(L.cunet_num_buckets(self.h)):
+            check(L.cunet_bucket_range(self.h, i, C.byref(b), C.byref(c)), 'cunet_bucket_range')
+            out.append((int(b.value), int(c.value)))
+        return out
+
+    def describe(self):
+        if self._desc is None:
+            self._desc = json.loads(lib().cunet_plan_describe(self.h).decode())
+        return self._desc
+
+    def tensor_offset(self, name: str, which: int = 0) -> int:
+        return int(lib().cunet_debug_tensor_offset(self.h, name.encode(), which))

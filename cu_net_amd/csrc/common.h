@@ -1,0 +1,135 @@
+// Shared device/host structures of the CU-Net HIP path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cunet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MAXSEG = 8;        // segments of one virtual concat (2 inputs + order carried + 1 new)
+constexpr int WAVE = 64;
+constexpr float BN_EPS = 1e-5f;  // nn.BatchNorm2d default (models/cu_net.py:22,41,45,195,301)
+
+// One source tensor of a virtual channel concat (models/cu_net.py:13 torch.cat is never
+// materialised: consumers read the segments in place).
+struct Seg {
+    const float* x;        // activation [rows][ld]
+    float* gx;             // gradient   [rows][ld]
+    const double* stats;   // [2][C]: sum, sum of squares over the tensor's rows
+    double count;          // rows of the source tensor (BN sample count per channel)
+    int C;                 // channels taken from this tensor (all of it)
+    int ld;                // row pitch in floats
+    int ups;               // 1: tensor is at half resolution, read through nearest-upsample (cu_net.py:250,265)
+    int gfirst;            // backward: 1 = first writer of gx (store), 0 = accumulate
+    int choff;             // channel offset inside the concat
+    int pad_;
+};
+
+// Loader / epilogue selectors of conv_kernel
+enum ConvLoad { LD_SEG = 0, LD_3X3 = 1, LD_PLAIN = 2, LD_PLAIN3 = 3, LD_STEM = 4 };
+enum ConvEpi { EP_FWD = 0, EP_BWD = 1 };
+
+struct ConvArgs {
+    // ---- concat description: A operand for LD_SEG/LD_3X3 (forward), X of the BN being
+    //      differentiated for EP_BWD
+    int nseg;
+    int Ccat;              // total channels of the concat
+    Seg seg[MAXSEG];
+    const float* gamma;    // BN over the concat
+    const float* beta;
+    const float* rmean;
+    const float* rvar;
+    int training;
+    // ---- plain A operand (LD_PLAIN / LD_PLAIN3: backward-data)
+    const float* a;
+    int lda;
+    // ---- contraction
+    int K;                 // channels contracted per tap
+    int taps;              // 1 or 9
+    const float* wB;       // repacked weights [taps][Kpad/4][Npad][4]
+    int Kpad, Npad;
+    // ---- output
+    float* y;
+    int ldy;
+    int Nout;              // valid output channels
+    double* ystats;        // EP_FWD: [2][Nout] or null; EP_BWD: [2][Nout] sum dz, sum dz*xhat
+    // ---- geometry of the output rows
+    int M, H, W;
+    // ---- stem (LD_STEM): NCHW image
+    const float* img;
+    int IH, IW;
+};
+
+struct WgradArgs {
+    const float* dy;       // [M][lddy]
+    int lddy;
+    int Cout;
+    int nseg;
+    int Ccat;
+    Seg seg[MAXSEG];
+    const float* gamma;
+    const float* beta;
+    int taps;
+    int M, H, W;
+    float* dw;             // [Cout][Ccat][taps] (torch layout), atomically accumulated
+    int rows_per_block;
+    int ctw;               // c-tiles per job (1x1); 3x3 jobs take one c-tile x 9 taps
+    const float* img;      // stem
+    int IH, IW;
+};
+
+struct BnApplyArgs {       // dX (+)= scale * (dz - mean(dz) - xhat * mean(dz*xhat)) per segment
+    int nseg;
+    int Ccat;
+    Seg seg[MAXSEG];
+    const float* gamma;
+    const float* beta;
+    const float* dz;       // [M][lddz]
+    int lddz;
+    const double* red;     // [2][Ccat]
+    float* dgamma;         // param-grad destinations (written, fp32)
+    float* dbeta;
+    int M, H, W;           // geometry of the concat (full resolution)
+};
+
+// device-side tables (uploaded once at bind)
+struct RepackEntry {       // weight -> GEMM operand layouts
+    int64_t src;           // float offset in the parameter arena, [Cout][Cin][taps]
+    int64_t dstF;          // float offset in workspace: forward B  [taps][KpadF/4][NpadF][4], K=Cin, N=Cout
+    int64_t dstB;          // float offset in workspace: backward B [taps][KpadB/4][NpadB][4], K=Cout, N=Cin (taps flipped); -1 if unused
+    int Cout, Cin, taps;
+    int KpadF, NpadF, KpadB, NpadB;
+    int pad_;
+};
+
+struct RunStatEntry {      // running_mean / running_var update of one BN segment
+    int64_t stats;         // double offset into stats arena: sum[C], sumsq[C]
+    int64_t rmean;         // float offset in buffer arena
+    int64_t rvar;
+    int64_t counter;       // int64 offset in counter arena, or -1 (only the first segment of a BN carries it)
+    double count;
+    int C;
+    int times;             // 1, or 2 for BNs the reference re-runs under torch.utils.checkpoint (2nd update from backward)
+};
+
+struct PoolArgs {
+    const float* x;        // [N*H*W][C]   (H, W = input spatial dims)
+    float* y;              // [N*H/2*W/2][C]
+    double* ystats;        // [2][C]
+    const double* xstats;  // MODE 1: stats of x
+    const float* gamma; const float* beta; const float* rmean; const float* rvar;
+    double count;
+    int training;
+    int N, H, W, C;
+    // backward
+    const float* gy;       // [lo][C]
+    float* gx;             // [hi][C]
+    double* red;           // stem backward reductions [2][C]
+};
+
+__host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace cunet

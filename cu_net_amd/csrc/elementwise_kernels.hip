@@ -1,0 +1,642 @@
+// HBM-bound kernels of the CU-Net hot path: BatchNorm backward apply, max-pool / nearest-upsample
+// index maps, the stem's BN-ReLU-pool, layout transposes at the NCHW boundary, pixelwise MSE,
+// running-statistics update, weight repacking, fused RMSprop and the arg-max landmark decode.
+// All are vectorised (16 B per lane) streaming kernels; per-channel reductions are carried in
+// fp64 and committed with one atomic per channel per block.
+#include "common.h"
+
+namespace cunet {
+
+__device__ __forceinline__ void atomic_add_f64e(double* p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward, second half (first half = EP_BWD epilogue of conv_kernel):
+//   dX = scale * (dz - mean(dz) - xhat * mean(dz * xhat))        per segment of the concat,
+// folded to dX = A*dz + E - D*x with per-channel A, E, D.  For a nearest-upsampled segment
+// (models/cu_net.py:250,265) the four children of a source pixel share x, so the source
+// gradient is A*sum(dz) + 4E - 4D*x  (this IS the backward of the index map y>>1, x>>1).
+// Also emits dgamma = sum(dz*xhat), dbeta = sum(dz) into the parameter-gradient arena.
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const BnApplyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cA = reinterpret_cast<float*>(smem);
+    float* cE = cA + p.Ccat;
+    float* cD = cE + p.Ccat;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.y;
+    const Seg sg = p.seg[s];
+    const double invM = 1.0 / (double)p.M;
+    for (int lc = tid; lc < sg.C; lc += 256) {
+        const int c = sg.choff + lc;
+        const double sum = sg.stats[lc], sq = sg.stats[sg.C + lc];
+        const double mean = sum / sg.count;
+        double var = sq / sg.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[c] * istd;
+        const double c1 = p.red[c] * invM;
+        const double c2 = p.red[p.Ccat + c] * invM;
+        const double D = scale * c2 * istd;
+        cA[c] = (float)scale;
+        cD[c] = (float)D;
+        cE[c] = (float)(D * mean - scale * c1);
+        if (blockIdx.x == 0) {
+            p.dgamma[c] = (float)p.red[p.Ccat + c];
+            p.dbeta[c] = (float)p.red[c];
+        }
+    }
+    __syncthreads();
+
+    const int g4 = sg.C >> 2;
+    const int HW = p.H * p.W;
+    const long rows = sg.ups ? (long)(p.M >> 2) : (long)p.M;
+    const long total = rows * g4;
+    for (long idx = (long)blockIdx.x * 256 + tid; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / g4;
+        const int g = (int)(idx - row * g4);
+        const int c = sg.choff + 4 * g;
+        const float4 A = *reinterpret_cast<const float4*>(cA + c);
+        const float4 E = *reinterpret_cast<const float4*>(cE + c);
+        const float4 D = *reinterpret_cast<const float4*>(cD + c);
+        const float4 x = *reinterpret_cast<const float4*>(sg.x + (size_t)row * sg.ld + 4 * g);
+        float4 r;
+        if (!sg.ups) {
+            const float4 dz = *reinterpret_cast<const float4*>(p.dz + (size_t)row * p.lddz + c);
+            r.x = fmaf(A.x, dz.x, E.x) - D.x * x.x;
+            r.y = fmaf(A.y, dz.y, E.y) - D.y * x.y;
+            r.z = fmaf(A.z, dz.z, E.z) - D.z * x.z;
+            r.w = fmaf(A.w, dz.w, E.w) - D.w * x.w;
+        } else {
+            const int HWs = HW >> 2, Ws = p.W >> 1;
+            const int ni = (int)(row / HWs);
+            const int rm = (int)(row - (long)ni * HWs);
+            const int ys = rm / Ws, xs = rm - ys * Ws;
+            const size_t m00 = (size_t)ni * HW + (size_t)(2 * ys) * p.W + 2 * xs;
+            const float4 d0 = *reinterpret_cast<const float4*>(p.dz + m00 * p.lddz + c);
+            const float4 d1 = *reinterpret_cast<const float4*>(p.dz + (m00 + 1) * p.lddz + c);
+            const float4 d2 = *reinterpret_cast<const float4*>(p.dz + (m00 + p.W) * p.lddz + c);
+            const float4 d3 = *reinterpret_cast<const float4*>(p.dz + (m00 + p.W + 1) * p.lddz + c);
+            r.x = fmaf(A.x, (d0.x + d1.x) + (d2.x + d3.x), 4.f * E.x) - 4.f * D.x * x.x;
+            r.y = fmaf(A.y, (d0.y + d1.y) + (d2.y + d3.y), 4.f * E.y) - 4.f * D.y * x.y;
+            r.z = fmaf(A.z, (d0.z + d1.z) + (d2.z + d3.z), 4.f * E.z) - 4.f * D.z * x.z;
+            r.w = fmaf(A.w, (d0.w + d1.w) + (d2.w + d3.w), 4.f * E.w) - 4.f * D.w * x.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(sg.gx + (size_t)row * sg.ld + 4 * g);
+        if (!sg.gfirst) {
+            const float4 o = *dst;
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        *dst = r;
+    }
+}
+
+hipError_t launch_bn_apply(const BnApplyArgs& a, int num_cus, hipStream_t s) {
+    long maxtotal = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        const long t = (long)(a.seg[i].ups ? a.M / 4 : a.M) * (a.seg[i].C / 4);
+        if (t > maxtotal) maxtotal = t;
+    }
+    long gx = (maxtotal + 255) / 256;
+    if (gx > 8L * num_cus) gx = 8L * num_cus;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)gx, a.nseg), dim3(256), (size_t)a.Ccat * 12, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x2/2 max-pool over NHWC (+ fp64 batch statistics of the pooled tensor).  MODE 0: plain
+// (models/cu_net.py:249,260); MODE 1: the stem's BN -> ReLU -> pool (models/cu_net.py:301-303).
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int g4 = p.C >> 2;
+    const int rpi = 256 / g4;                      // rows per block iteration
+    const int g = tid % g4;
+    const int ry = tid / g4;
+    const bool active = ry < rpi;
+    float* sc = reinterpret_cast<float*>(smem);
+    float* sh = sc + p.C;
+    double* red = reinterpret_cast<double*>(smem + (size_t)(MODE == 1 ? 2 * p.C * 4 : 0));   // [rpi][C][2]
+    if (MODE == 1) {
+        for (int c = tid; c < p.C; c += 256) {
+            double mean, istd;
+            if (p.training) {
+                mean = p.xstats[c] / p.count;
+                double var = p.xstats[p.C + c] / p.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                istd = 1.0 / sqrt(var + (double)BN_EPS);
+            } else {
+                mean = (double)p.rmean[c];
+                istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+            }
+            const double scale = (double)p.gamma[c] * istd;
+            sc[c] = (float)scale;
+            sh[c] = (float)((double)p.beta[c] - mean * scale);
+        }
+        __syncthreads();
+    }
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const long rows = (long)p.N * Ho * Wo;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (active) {
+        float4 S = make_float4(1.f, 1.f, 1.f, 1.f), Hh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) {
+            S = *reinterpret_cast<const float4*>(sc + 4 * g);
+            Hh = *reinterpret_cast<const float4*>(sh + 4 * g);
+        }
+        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
+            const int ni = (int)(row / (Ho * Wo));
+            const int rm = (int)(row - (long)ni * Ho * Wo);
+            const int yo = rm / Wo, xo = rm - yo * Wo;
+            const size_t m00 = ((size_t)ni * p.H + 2 * yo) * p.W + 2 * xo;
+            float4 v[4];
+            v[0] = *reinterpret_cast<const float4*>(p.x + m00 * p.C + 4 * g);
+            v[1] = *reinterpret_cast<const float4*>(p.x + (m00 + 1) * p.C + 4 * g);
+            v[2] = *reinterpret_cast<const float4*>(p.x + (m00 + p.W) * p.C + 4 * g);
+            v[3] = *reinterpret_cast<const float4*>(p.x + (m00 + p.W + 1) * p.C + 4 * g);
+            if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k].x = fmaxf(fmaf(v[k].x, S.x, Hh.x), 0.f);
+                    v[k].y = fmaxf(fmaf(v[k].y, S.y, Hh.y), 0.f);
+                    v[k].z = fmaxf(fmaf(v[k].z, S.z, Hh.z), 0.f);
+                    v[k].w = fmaxf(fmaf(v[k].w, S.w, Hh.w), 0.f);
+                }
+            }
+            float4 m;
+            m.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
+            m.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
+            m.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
+            m.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
+            *reinterpret_cast<float4*>(p.y + (size_t)row * p.C + 4 * g) = m;
+            s1[0] += m.x; s2[0] += (double)m.x * m.x;
+            s1[1] += m.y; s2[1] += (double)m.y * m.y;
+            s1[2] += m.z; s2[2] += (double)m.z * m.z;
+            s1[3] += m.w; s2[3] += (double)m.w * m.w;
+        }
+    }
+    if (p.ystats == nullptr) return;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[((size_t)ry * p.C + 4 * g + e) * 2 + 0] = s1[e];
+            red[((size_t)ry * p.C + 4 * g + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < rpi; ++r) {
+            a += red[((size_t)r * p.C + c) * 2 + 0];
+            b += red[((size_t)r * p.C + c) * 2 + 1];
+        }
+        atomic_add_f64e(p.ystats + c, a);
+        atomic_add_f64e(p.ystats + p.C + c, b);
+    }
+}
+
+static size_t pool_smem(int C, int mode) {
+    const int g4 = C / 4;
+    const int rpi = 256 / g4;
+    return (size_t)(mode == 1 ? 2 * C * 4 : 0) + (size_t)rpi * C * 2 * 8;
+}
+
+hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t s) {
+    const int rpi = 256 / (a.C / 4);
+    const long rows = (long)a.N * (a.H / 2) * (a.W / 2);
+    long gx = (rows + rpi - 1) / rpi;
+    if (gx > 4L * num_cus) gx = 4L * num_cus;
+    if (gx < 1) gx = 1;
+    if (mode == 0)
+        hipLaunchKernelGGL(pool_fwd_kernel<0>, dim3((unsigned)gx), dim3(256), pool_smem(a.C, 0), s, a);
+    else
+        hipLaunchKernelGGL(pool_fwd_kernel<1>, dim3((unsigned)gx), dim3(256), pool_smem(a.C, 1), s, a);
+    return hipGetLastError();
+}
+
+// max-pool backward: the gradient goes to the FIRST maximum in window order (0,0),(0,1),(1,0),(1,1)
+// (torch CPU max_pool2d tie-break), every other input position gets 0.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolArgs p) {
+    const int g4 = p.C >> 2;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const long total = (long)p.N * Ho * Wo * g4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / g4;
+        const int g = (int)(idx - row * g4);
+        const int ni = (int)(row / (Ho * Wo));
+        const int rm = (int)(row - (long)ni * Ho * Wo);
+        const int yo = rm / Wo, xo = rm - yo * Wo;
+        const size_t m00 = ((size_t)ni * p.H + 2 * yo) * p.W + 2 * xo;
+        const size_t off[4] = {m00, m00 + 1, m00 + p.W, m00 + p.W + 1};
+        float v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(p.x + off[k] * p.C + 4 * g);
+            v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+        }
+        const float4 gq = *reinterpret_cast<const float4*>(p.gy + (size_t)row * p.C + 4 * g);
+        const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+        float o[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int am = 0;
+            float best = v[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][e] > best) { best = v[k][e]; am = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][e] = (k == am) ? gv[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float4*>(p.gx + off[k] * p.C + 4 * g) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    }
+}
+
+hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s) {
+    const long total = (long)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
+    long gx = (total + 255) / 256;
+    if (gx > 8L * num_cus) gx = 8L * num_cus;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// Stem backward (pool -> ReLU -> BN), two streaming passes because BN backward needs full-batch
+// reductions.  PASS 0: reductions sum(dz), sum(dz*xhat) -> p.red.  PASS 1: dC = A*dz + E - D*x.
+// dz is non-zero only at the window's first arg-max, and only where the BN output was > 0.
+template <int PASS>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const PoolArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int g4 = p.C >> 2;
+    const int rpi = 256 / g4;
+    const int g = tid % g4;
+    const int ry = tid / g4;
+    const bool active = ry < rpi;
+    float* sc = reinterpret_cast<float*>(smem);
+    float* sh = sc + p.C;
+    float* mu = sh + p.C;
+    float* is = mu + p.C;
+    float* cE = is + p.C;      // PASS 1
+    float* cD = cE + p.C;
+    double* red = reinterpret_cast<double*>(cD + p.C);   // PASS 0: [rpi][C][2]
+    const double invM = 1.0 / p.count;
+    for (int c = tid; c < p.C; c += 256) {
+        const double mean = p.xstats[c] / p.count;
+        double var = p.xstats[p.C + c] / p.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+        mu[c] = (float)mean;
+        is[c] = (float)istd;
+        if (PASS == 1) {
+            const double c1 = p.red[c] * invM, c2 = p.red[p.C + c] * invM;
+            const double D = scale * c2 * istd;
+            cD[c] = (float)D;
+            cE[c] = (float)(D * mean - scale * c1);
+        }
+    }
+    __syncthreads();
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const long rows = (long)p.N * Ho * Wo;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (active) {
+        float S[4], Hh[4], MU[4], IS[4], E[4], D[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            S[e] = sc[4 * g + e]; Hh[e] = sh[4 * g + e]; MU[e] = mu[4 * g + e]; IS[e] = is[4 * g + e];
+            E[e] = PASS == 1 ? cE[4 * g + e] : 0.f;
+            D[e] = PASS == 1 ? cD[4 * g + e] : 0.f;
+        }
+        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
+            const int ni = (int)(row / (Ho * Wo));
+            const int rm = (int)(row - (long)ni * Ho * Wo);
+            const int yo = rm / Wo, xo = rm - yo * Wo;
+            const size_t m00 = ((size_t)ni * p.H + 2 * yo) * p.W + 2 * xo;
+            const size_t off[4] = {m00, m00 + 1, m00 + p.W, m00 + p.W + 1};
+            float v[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(p.x + off[k] * p.C + 4 * g);
+                v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+            }
+            const float4 gq = *reinterpret_cast<const float4*>(p.gy + (size_t)row * p.C + 4 * g);
+            const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+            float o[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int am = 0;
+                float best = fmaxf(fmaf(v[0][e], S[e], Hh[e]), 0.f);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float a = fmaxf(fmaf(v[k][e], S[e], Hh[e]), 0.f);
+                    if (a > best) { best = a; am = k; }
+                }
+                const float dz = best > 0.f ? gv[e] : 0.f;
+                if (PASS == 0) {
+                    float xa = v[0][e];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) xa = (k == am) ? v[k][e] : xa;
+                    s1[e] += dz;
+                    s2[e] += (double)(dz * ((xa - MU[e]) * IS[e]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k][e] = fmaf(S[e], (k == am) ? dz : 0.f, E[e]) - D[e] * v[k][e];
+                }
+            }
+            if (PASS == 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float4*>(p.gx + off[k] * p.C + 4 * g) =
+                        make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+            }
+        }
+    }
+    if (PASS == 0) {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[((size_t)ry * p.C + 4 * g + e) * 2 + 0] = s1[e];
+                red[((size_t)ry * p.C + 4 * g + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < p.C; c += 256) {
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < rpi; ++r) {
+                a += red[((size_t)r * p.C + c) * 2 + 0];
+                b += red[((size_t)r * p.C + c) * 2 + 1];
+            }
+            atomic_add_f64e(p.red + c, a);
+            atomic_add_f64e(p.red + p.C + c, b);
+        }
+    }
+}
+
+// writes dgamma/dbeta of the stem BN from its reductions (tiny)
+__global__ void stem_bn_param_grad_kernel(const double* red, float* dgamma, float* dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        dbeta[c] = (float)red[c];
+        dgamma[c] = (float)red[C + c];
+    }
+}
+
+hipError_t launch_stem_bwd(const PoolArgs& a, int pass, float* dgamma, float* dbeta, int num_cus, hipStream_t s) {
+    const int rpi = 256 / (a.C / 4);
+    const long rows = (long)a.N * (a.H / 2) * (a.W / 2);
+    long gx = (rows + rpi - 1) / rpi;
+    if (gx > 4L * num_cus) gx = 4L * num_cus;
+    if (gx < 1) gx = 1;
+    const size_t smem = (size_t)6 * a.C * 4 + (size_t)rpi * a.C * 2 * 8;
+    if (pass == 0) {
+        hipLaunchKernelGGL(stem_bwd_kernel<0>, dim3((unsigned)gx), dim3(256), smem, s, a);
+    } else {
+        hipLaunchKernelGGL(stem_bwd_kernel<1>, dim3((unsigned)gx), dim3(256), smem, s, a);
+        hipLaunchKernelGGL(stem_bn_param_grad_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s,
+                           (const double*)a.red, dgamma, dbeta, a.C);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW <-> NHWC at the public boundary (heat maps / their gradients / targets), 32x32 LDS tiles.
+// nchw [N][C][HW]   nhwc [N*HW][ld]  (channels C..ld-1 are written as zeros)
+template <int TO_NHWC>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        int C, int HW, int ld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    if (TO_NHWC) {
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, pp = p0 + tx;
+            tile[j][tx] = (c < C && pp < HW) ? src[((size_t)n * C + c) * HW + pp] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int pp = p0 + j, c = c0 + tx;
+            if (pp < HW && c < ld) dst[((size_t)n * HW + pp) * ld + c] = tile[tx][j];
+        }
+    } else {
+        for (int j = ty; j < 32; j += 8) {
+            const int pp = p0 + j, c = c0 + tx;
+            tile[j][tx] = (pp < HW && c < C) ? src[((size_t)n * HW + pp) * ld + c] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, pp = p0 + tx;
+            if (c < C && pp < HW) dst[((size_t)n * C + c) * HW + pp] = tile[tx][j];
+        }
+    }
+}
+
+hipError_t launch_transpose(const float* src, float* dst, int N, int C, int HW, int ld, int to_nhwc, hipStream_t s) {
+    const dim3 grid((HW + 31) / 32, (ld + 31) / 32, N);
+    if (to_nhwc)
+        hipLaunchKernelGGL(transpose_kernel<1>, grid, dim3(256), 0, s, src, dst, C, HW, ld);
+    else
+        hipLaunchKernelGGL(transpose_kernel<0>, grid, dim3(256), 0, s, src, dst, C, HW, ld);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pixelwise MSE of one head (cu-net.py:175-178): loss += sum((o-t)^2)/numel, dO = 2(o-t)/numel.
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                  float* __restrict__ dout, double* loss_acc,
+                                                  long rows, int C, int ld) {
+    __shared__ double wsum[4];
+    const long total = rows * ld;
+    const double inv = 1.0 / ((double)rows * C);
+    const float ginv = (float)(2.0 * inv);
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % ld);
+        float d = 0.f;
+        if (c < C) d = out[i] - tgt[i];
+        dout[i] = d * ginv;
+        acc += (double)d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int lo = __double2loint(acc), hi = __double2hiint(acc);
+        lo = __shfl_xor(lo, o, 64); hi = __shfl_xor(hi, o, 64);
+        acc += __hiloint2double(hi, lo);
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f64e(loss_acc, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv);
+}
+
+__global__ void loss_finalize_kernel(const double* acc, float* loss) { *loss = (float)(*acc); }
+
+hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld,
+                      int num_cus, hipStream_t s) {
+    long gx = (rows * ld + 255) / 256;
+    if (gx > 4L * num_cus) gx = 4L * num_cus;
+    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_finalize(const double* acc, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, s, acc, loss);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// running_mean / running_var / num_batches_tracked update for every BN of the net in ONE launch
+// (nn.BatchNorm2d train-mode semantics: momentum 0.1, unbiased variance for the running estimate).
+// mode 0: every entry once (forward); mode 1: only entries of BNs the reference re-runs under
+// torch.utils.checkpoint (models/cu_net.py:30-31,58-59), applied from backward.
+__global__ __launch_bounds__(256) void running_update_kernel(const RunStatEntry* tab, const double* stats_base,
+                                                             float* buffers, int64_t* counters, int mode) {
+    const RunStatEntry e = tab[blockIdx.x];
+    if (mode == 1 && e.times < 2) return;
+    const double mom = 0.1;
+    for (int c = threadIdx.x; c < e.C; c += 256) {
+        const double mean = stats_base[e.stats + c] / e.count;
+        double var = stats_base[e.stats + e.C + c] / e.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double unb = e.count > 1.0 ? var * e.count / (e.count - 1.0) : var;
+        float* rm = buffers + e.rmean + c;
+        float* rv = buffers + e.rvar + c;
+        *rm = (float)((1.0 - mom) * (double)*rm + mom * mean);
+        *rv = (float)((1.0 - mom) * (double)*rv + mom * unb);
+    }
+    if (threadIdx.x == 0 && e.counter >= 0) counters[e.counter] += 1;
+}
+
+hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* stats_base, float* buffers,
+                                 int64_t* counters, int mode, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(running_update_kernel, dim3(n), dim3(256), 0, s, tab, stats_base, buffers, counters, mode);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight repack: torch [Cout][Cin][taps] -> MFMA B-operand layouts [tap][K/4][Npad][4]
+//   forward : K = Cin,  N = Cout
+//   backward: K = Cout, N = Cin, taps flipped (transposed convolution for the data gradient)
+__global__ __launch_bounds__(256) void repack_kernel(const RepackEntry* tab, const float* params, float* ws) {
+    const RepackEntry e = tab[blockIdx.y];
+    const float* w = params + e.src;
+    {
+        const long total = (long)e.taps * e.KpadF * e.NpadF;
+        float* dst = ws + e.dstF;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int ee = (int)(i & 3);
+            long r = i >> 2;
+            const int n = (int)(r % e.NpadF); r /= e.NpadF;
+            const int kq = (int)(r % (e.KpadF >> 2));
+            const int t = (int)(r / (e.KpadF >> 2));
+            const int k = 4 * kq + ee;
+            dst[i] = (k < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k) * e.taps + t] : 0.f;
+        }
+    }
+    if (e.dstB >= 0) {
+        const long total = (long)e.taps * e.KpadB * e.NpadB;
+        float* dst = ws + e.dstB;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int ee = (int)(i & 3);
+            long r = i >> 2;
+            const int n = (int)(r % e.NpadB); r /= e.NpadB;
+            const int kq = (int)(r % (e.KpadB >> 2));
+            const int t = (int)(r / (e.KpadB >> 2));
+            const int k = 4 * kq + ee;          // output channel of the forward conv
+            dst[i] = (k < e.Cout && n < e.Cin) ? w[((size_t)k * e.Cin + n) * e.taps + (e.taps - 1 - t)] : 0.f;
+        }
+    }
+}
+
+hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, float* ws, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(repack_kernel, dim3(16, n), dim3(256), 0, s, tab, params, ws);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused RMSprop over the flat arena (torch.optim.RMSprop, momentum 0, centered False; cu-net.py:60-61):
+//   v = alpha*v + (1-alpha)*g*g ;  p -= lr * g / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ v, long n, float lr, float alpha,
+                                                      float eps, float gscale) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
+        vv.x = alpha * vv.x + (1.f - alpha) * gg.x * gg.x;
+        vv.y = alpha * vv.y + (1.f - alpha) * gg.y * gg.y;
+        vv.z = alpha * vv.z + (1.f - alpha) * gg.z * gg.z;
+        vv.w = alpha * vv.w + (1.f - alpha) * gg.w * gg.w;
+        pp.x -= lr * gg.x / (sqrtf(vv.x) + eps);
+        pp.y -= lr * gg.y / (sqrtf(vv.y) + eps);
+        pp.z -= lr * gg.z / (sqrtf(vv.z) + eps);
+        pp.w -= lr * gg.w / (sqrtf(vv.w) + eps);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gg = g[i] * gscale;
+        const float vv = alpha * v[i] + (1.f - alpha) * gg * gg;
+        v[i] = vv;
+        p[i] -= lr * gg / (sqrtf(vv) + eps);
+    }
+}
+
+hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
+                          float gscale, hipStream_t s) {
+    long gx = (n / 4 + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)gx), dim3(256), 0, s, p, g, v, n, lr, alpha, eps, gscale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Landmark decode (pylib/Evaluation.py:6-23 get_preds): flat arg-max per (n,k) map with the
+// LOWEST index winning ties (torch.max on CPU), x = idx % W + 1, y = floor(idx / H) + 1
+// (the reference divides by size(2)), zeroed where max <= 0.  One wave per map; bit-exact.
+__global__ __launch_bounds__(256) void get_preds_kernel(const float* __restrict__ heat, float* __restrict__ preds,
+                                                        int maps, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (map >= maps) return;
+    const int HW = H * W;
+    const float* h = heat + (size_t)map * HW;
+    float best = -INFINITY;
+    int bi = HW;                       // sentinel: larger than any index
+    for (int i = lane; i < HW; i += 64) {
+        const float v = h[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        if (bi >= HW) bi = 0;
+        float x = (float)(bi % W + 1);
+        float y = floorf((float)bi / (float)H) + 1.f;
+        if (!(best > 0.f)) { x = 0.f; y = 0.f; }
+        preds[(size_t)map * 2 + 0] = x;
+        preds[(size_t)map * 2 + 1] = y;
+    }
+}
+
+hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, int W, hipStream_t s) {
+    hipLaunchKernelGGL(get_preds_kernel, dim3((maps + 3) / 4), dim3(256), 0, s, heat, preds, maps, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace cunet

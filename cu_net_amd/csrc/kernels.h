@@ -1,0 +1,26 @@
+// Host-side launchers of the HIP kernels (definitions in *_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace cunet {
+
+enum WgLoadSel { WGL_SEG = 0, WGL_3X3 = 1, WGL_STEM = 2 };
+
+hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStream_t s);
+hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
+hipError_t launch_bn_apply(const BnApplyArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t s);
+hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_stem_bwd(const PoolArgs& a, int pass, float* dgamma, float* dbeta, int num_cus, hipStream_t s);
+hipError_t launch_transpose(const float* src, float* dst, int N, int C, int HW, int ld, int to_nhwc, hipStream_t s);
+hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld,
+                      int num_cus, hipStream_t s);
+hipError_t launch_loss_finalize(const double* acc, float* loss, hipStream_t s);
+hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* stats_base, float* buffers,
+                                 int64_t* counters, int mode, hipStream_t s);
+hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, float* ws, hipStream_t s);
+hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
+                          float gscale, hipStream_t s);
+hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, int W, hipStream_t s);
+
+}  // namespace cunet

@@ -1,0 +1,119 @@
+// Host-side execution plan of the Coupled U-Net: state layout (reference state_dict order),
+// tensor table, node list and workspace layout.  Pure C++ (no device calls) so it can be
+// built, described and checked on a machine without a GPU.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cunet.h"
+
+namespace cunet {
+
+struct StateEntry {
+    std::string name;
+    int kind;                 // 0 param, 1 buffer, 2 counter
+    std::vector<int64_t> shape;
+    int64_t offset;           // element offset inside its arena
+    int64_t numel;
+    int bucket = 0;           // gradient bucket (U-Net index; layer_num = stem)
+};
+
+struct TensorInfo {
+    std::string name;
+    int N, H, W, C, ld;
+    int64_t rows() const { return (int64_t)N * H * W; }
+    int64_t act = -1;         // float offset in workspace
+    int64_t grad = -1;        // float offset in workspace (training)
+    int64_t stats = -1;       // double offset in the zeroed region ([2][C]) or -1
+};
+
+struct BnInfo {
+    std::string name;         // module path, e.g. hg.down_blocks.0.layers.0.norm1
+    int C;
+    int64_t gamma, beta;      // param arena
+    int64_t rmean, rvar;      // buffer arena
+    int64_t counter;          // counter arena
+    bool ckpt;                // re-run by torch.utils.checkpoint in the reference's backward
+};
+
+struct ConvInfo {
+    std::string name;         // module path of the conv
+    int Cout, Cin, taps;
+    int64_t w;                // param arena
+    int64_t wF = -1, wB = -1; // workspace float offsets of the repacked operands
+    int KpadF, NpadF, KpadB, NpadB;
+};
+
+struct SegRef {
+    int tensor;
+    int ups;
+    int gfirst = 0;           // filled by the backward-order simulation
+};
+
+enum NodeType { N_STEM_CONV = 0, N_STEM_BNPOOL = 1, N_CONV = 2, N_POOL = 3 };
+
+struct Node {
+    NodeType type;
+    std::string name;
+    int bn = -1;              // index into bns
+    int conv = -1;            // index into convs
+    std::vector<SegRef> segs; // inputs (N_CONV); segs[0] is the single input for pool / stem bn-pool
+    int out = -1;             // output tensor
+    int taps = 1;
+    int head = -1;            // >= 0: this conv is heat-map head number `head` (output index)
+    int Ccat = 0;             // channels of the concat
+    int64_t red = -1;         // double offset in the zeroed region: [2][Ccat] backward reductions
+    int bucket = 0;           // gradient bucket this node's parameters live in
+};
+
+struct Plan {
+    cunet_cfg cfg;
+    std::vector<int> anchors;
+    std::vector<StateEntry> state;
+    std::map<std::string, int> state_index;
+    int64_t n_params = 0, n_buffers = 0, n_counters = 0;
+    std::vector<int64_t> bucket_begin, bucket_count;   // float ranges of the parameter arena
+
+    std::vector<TensorInfo> tensors;
+    std::vector<BnInfo> bns;
+    std::vector<ConvInfo> convs;
+    std::vector<Node> nodes;
+    std::vector<int> head_tensors;   // per output index: tensor id of the NHWC heat map
+
+    // workspace layout (bytes)
+    int64_t off_repack_tab = 0, off_runstat_tab = 0;
+    int64_t off_zero = 0, zero_bytes = 0;     // fp64 region cleared at the start of every forward
+    int64_t n_zero_doubles = 0;
+    int64_t loss_acc = -1;                    // double offset inside the zero region
+    int64_t off_floats = 0;                   // base of the float region (byte offset)
+    int64_t n_floats_infer = 0, n_floats_train = 0;
+    int64_t dz_off = -1, target_off = -1;     // float offsets (training)
+    int64_t ws_bytes_infer = 0, ws_bytes_train = 0;
+    int n_runstat = 0;
+
+    std::string json;
+    std::string error;
+
+    bool build(const cunet_cfg& c);
+    int tensor_by_name(const std::string& n) const;
+
+   private:
+    int64_t param(const std::string& n) const;
+    int add_tensor(const std::string& name, int N, int H, int W, int C, bool stats);
+    int add_bn(const std::string& path, bool ckpt);
+    int add_conv(const std::string& path, int taps, bool need_bwd);
+    int conv_node(const std::string& name, const std::string& bn_path, const std::string& conv_path,
+                  const std::vector<SegRef>& segs, int taps, bool ckpt, int H, int W, int head, bool out_stats);
+    void build_state();
+    void block_entries(const std::string& prefix, int in_num, bool requires_skip, bool is_up);
+    void bn_entries(const std::string& prefix, int c, int bucket);
+    void add_state(const std::string& name, int kind, std::vector<int64_t> shape, int bucket);
+    void assign_param_offsets();
+    void layout_workspace();
+    void describe();
+};
+
+}  // namespace cunet

@@ -1,0 +1,415 @@
+// C-ABI entry points (include/cunet.h) and the executor that walks a Plan and enqueues the HIP
+// kernels on the caller's stream.  Owns no device memory.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cunet.h"
+#include "kernels.h"
+#include "plan.h"
+
+using namespace cunet;
+
+struct cunet_plan {
+    Plan plan;
+    // bound, caller-owned device memory
+    float* params = nullptr;
+    float* grads = nullptr;
+    float* buffers = nullptr;
+    int64_t* counters = nullptr;
+    char* ws = nullptr;
+    int64_t ws_bytes = 0;
+    int bound_training = 0;
+    int num_cus = 256;
+    // host copies of the device tables (kept alive for async uploads)
+    std::vector<RepackEntry> repack;
+    std::vector<RunStatEntry> runstat;
+    // call-order state
+    int fwd_training_done = 0;
+    int loss_done = 0;
+    const float* last_x = nullptr;   // image of the last training forward (needed by the stem weight gradient)
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CUNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+extern "C" {
+
+const char* cunet_last_error(void) { return g_err.c_str(); }
+const char* cunet_version(void) { return "cunet-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int cunet_plan_create(const cunet_cfg* cfg, cunet_plan_t** out) {
+    if (!cfg || !out) return fail(CUNET_ERR_INVALID, "null argument");
+    cunet_plan* p = new (std::nothrow) cunet_plan();
+    if (!p) return fail(CUNET_ERR_NOMEM, "out of host memory");
+    if (!p->plan.build(*cfg)) {
+        const std::string e = p->plan.error;
+        delete p;
+        return fail(CUNET_ERR_INVALID, e);
+    }
+    *out = p;
+    return CUNET_OK;
+}
+
+void cunet_plan_destroy(cunet_plan_t* plan) { delete plan; }
+
+int cunet_state_count(const cunet_plan_t* plan) { return plan ? (int)plan->plan.state.size() : 0; }
+
+int cunet_state_entry(const cunet_plan_t* plan, int index, cunet_state_desc* out) {
+    if (!plan || !out || index < 0 || index >= (int)plan->plan.state.size()) return fail(CUNET_ERR_INVALID, "bad state index");
+    const StateEntry& e = plan->plan.state[index];
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->name, sizeof(out->name), "%s", e.name.c_str());
+    out->kind = e.kind;
+    out->ndim = (int)e.shape.size();
+    for (size_t i = 0; i < e.shape.size() && i < 4; ++i) out->shape[i] = e.shape[i];
+    out->offset = e.offset;
+    out->numel = e.numel;
+    return CUNET_OK;
+}
+
+int64_t cunet_param_numel(const cunet_plan_t* p) { return p ? p->plan.n_params : 0; }
+int64_t cunet_buffer_numel(const cunet_plan_t* p) { return p ? p->plan.n_buffers : 0; }
+int64_t cunet_counter_numel(const cunet_plan_t* p) { return p ? p->plan.n_counters : 0; }
+int64_t cunet_workspace_bytes(const cunet_plan_t* p, int training) {
+    return p ? (training ? p->plan.ws_bytes_train : p->plan.ws_bytes_infer) : 0;
+}
+int cunet_num_heads(const cunet_plan_t* p) { return p ? (int)p->plan.head_tensors.size() : 0; }
+int cunet_loss_anchors(const cunet_plan_t* p, int32_t* anchors, int capacity) {
+    if (!p || !anchors) return fail(CUNET_ERR_INVALID, "null argument");
+    const int n = (int)p->plan.anchors.size();
+    for (int i = 0; i < n && i < capacity; ++i) anchors[i] = p->plan.anchors[i];
+    return n;
+}
+const char* cunet_plan_describe(const cunet_plan_t* p) { return p ? p->plan.json.c_str() : ""; }
+
+int64_t cunet_debug_tensor_offset(const cunet_plan_t* p, const char* name, int which) {
+    if (!p || !name) return -1;
+    const int t = p->plan.tensor_by_name(name);
+    if (t < 0) return -1;
+    const TensorInfo& ti = p->plan.tensors[t];
+    const int64_t f = which == 0 ? ti.act : ti.grad;
+    if (f < 0) return -1;
+    return p->plan.off_floats + 4 * f;
+}
+
+int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int64_t* counters, void* workspace,
+               int64_t workspace_bytes, int training, void* stream) {
+    if (!h || !params || !buffers || !counters || !workspace) return fail(CUNET_ERR_INVALID, "null device pointer");
+    if (training && !grads) return fail(CUNET_ERR_INVALID, "training bind needs a gradient arena");
+    Plan& P = h->plan;
+    const int64_t need = training ? P.ws_bytes_train : P.ws_bytes_infer;
+    if (workspace_bytes < need) return fail(CUNET_ERR_INVALID, "workspace too small");
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)buffers & 15) || (grads && ((uintptr_t)grads & 15)))
+        return fail(CUNET_ERR_INVALID, "device pointers must be aligned (workspace 256 B, arenas 16 B)");
+    h->params = params; h->grads = grads; h->buffers = buffers; h->counters = counters;
+    h->ws = (char*)workspace; h->ws_bytes = workspace_bytes; h->bound_training = training;
+    int dev = 0, cus = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    h->num_cus = cus > 0 ? cus : 256;
+
+    h->repack.clear();
+    for (auto& c : P.convs) {
+        RepackEntry e{};
+        e.src = c.w; e.dstF = c.wF; e.dstB = c.wB;
+        e.Cout = c.Cout; e.Cin = c.Cin; e.taps = c.taps;
+        e.KpadF = c.KpadF; e.NpadF = c.NpadF; e.KpadB = c.KpadB; e.NpadB = c.NpadB;
+        h->repack.push_back(e);
+    }
+    h->runstat.clear();
+    for (auto& n : P.nodes) {
+        if (n.type == N_CONV) {
+            const BnInfo& b = P.bns[n.bn];
+            int choff = 0;
+            for (size_t s = 0; s < n.segs.size(); ++s) {
+                const TensorInfo& t = P.tensors[n.segs[s].tensor];
+                RunStatEntry e{};
+                e.stats = t.stats; e.rmean = b.rmean + choff; e.rvar = b.rvar + choff;
+                e.counter = s == 0 ? b.counter : -1;
+                e.count = (double)t.rows(); e.C = t.C; e.times = b.ckpt ? 2 : 1;
+                h->runstat.push_back(e);
+                choff += t.C;
+            }
+        } else if (n.type == N_STEM_BNPOOL) {
+            const BnInfo& b = P.bns[n.bn];
+            const TensorInfo& t = P.tensors[n.segs[0].tensor];
+            RunStatEntry e{};
+            e.stats = t.stats; e.rmean = b.rmean; e.rvar = b.rvar; e.counter = b.counter;
+            e.count = (double)t.rows(); e.C = t.C; e.times = 1;
+            h->runstat.push_back(e);
+        }
+    }
+    if ((int)h->runstat.size() != P.n_runstat) return fail(CUNET_ERR_STATE, "internal: running-stat table size");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(h->ws + P.off_repack_tab, h->repack.data(), h->repack.size() * sizeof(RepackEntry), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->ws + P.off_runstat_tab, h->runstat.data(), h->runstat.size() * sizeof(RunStatEntry), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->fwd_training_done = 0; h->loss_done = 0;
+    return CUNET_OK;
+}
+
+}  // extern "C"
+
+// ---- executor helpers -----------------------------------------------------------------------
+namespace {
+
+struct Exec {
+    cunet_plan* h;
+    Plan& P;
+    float* wsf;        // float region
+    double* zero;      // fp64 region
+    explicit Exec(cunet_plan* hh) : h(hh), P(hh->plan) {
+        wsf = reinterpret_cast<float*>(h->ws + P.off_floats);
+        zero = reinterpret_cast<double*>(h->ws + P.off_zero);
+    }
+    float* act(int t) const { return wsf + P.tensors[t].act; }
+    float* grad(int t) const { return wsf + P.tensors[t].grad; }
+    double* stats(int t) const { return P.tensors[t].stats >= 0 ? zero + P.tensors[t].stats : nullptr; }
+
+    int fill_segs(const Node& n, Seg* segs) const {
+        int choff = 0;
+        for (size_t i = 0; i < n.segs.size(); ++i) {
+            const TensorInfo& t = P.tensors[n.segs[i].tensor];
+            Seg& s = segs[i];
+            s.x = act(n.segs[i].tensor);
+            s.gx = h->bound_training ? grad(n.segs[i].tensor) : nullptr;
+            s.stats = stats(n.segs[i].tensor);
+            s.count = (double)t.rows();
+            s.C = t.C; s.ld = t.ld; s.ups = n.segs[i].ups; s.gfirst = n.segs[i].gfirst; s.choff = choff; s.pad_ = 0;
+            choff += t.C;
+        }
+        return (int)n.segs.size();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int training, void* stream) {
+    if (!h || !x) return fail(CUNET_ERR_INVALID, "null argument");
+    if (!h->ws) return fail(CUNET_ERR_STATE, "cunet_bind has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    Exec E(h);
+    Plan& P = h->plan;
+    const int cus = h->num_cus;
+    HIPCHK(hipMemsetAsync(h->ws + P.off_zero, 0, (size_t)P.zero_bytes, s));
+    HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
+    for (const Node& n : P.nodes) {
+        const TensorInfo& o = P.tensors[n.out];
+        if (n.type == N_STEM_CONV) {
+            const ConvInfo& c = P.convs[n.conv];
+            ConvArgs a{};
+            a.nseg = 0; a.Ccat = 0; a.training = training;
+            a.K = c.Cin; a.taps = 1; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
+            a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
+            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            a.img = x; a.IH = P.cfg.height; a.IW = P.cfg.width;
+            HIPCHK(launch_conv(a, LD_STEM, EP_FWD, cus, s));
+        } else if (n.type == N_STEM_BNPOOL || n.type == N_POOL) {
+            const int tin = n.segs[0].tensor;
+            const TensorInfo& ti = P.tensors[tin];
+            PoolArgs a{};
+            a.x = E.act(tin); a.y = E.act(n.out); a.ystats = training ? E.stats(n.out) : nullptr;
+            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = training;
+            if (n.type == N_STEM_BNPOOL) {
+                const BnInfo& b = P.bns[n.bn];
+                a.xstats = E.stats(tin); a.count = (double)ti.rows();
+                a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+                a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+                HIPCHK(launch_pool_fwd(a, 1, cus, s));
+            } else {
+                HIPCHK(launch_pool_fwd(a, 0, cus, s));
+            }
+        } else {  // N_CONV
+            const ConvInfo& c = P.convs[n.conv];
+            const BnInfo& b = P.bns[n.bn];
+            ConvArgs a{};
+            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+            a.training = training;
+            a.K = n.Ccat; a.taps = c.taps; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
+            a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
+            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            HIPCHK(launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
+        }
+    }
+    if (training)
+        HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
+                                     E.zero, h->buffers, h->counters, 0, s));
+    if (heat) {
+        for (size_t i = 0; i < P.head_tensors.size(); ++i) {
+            if (!heat[i]) continue;
+            const TensorInfo& t = P.tensors[P.head_tensors[i]];
+            HIPCHK(launch_transpose(E.act(P.head_tensors[i]), heat[i], t.N, t.C, t.H * t.W, t.ld, 0, s));
+        }
+    }
+    h->fwd_training_done = training ? 1 : 0;
+    h->loss_done = 0;
+    h->last_x = x;
+    return CUNET_OK;
+}
+
+int cunet_loss_mse(cunet_plan_t* h, const float* target, float* loss, void* stream) {
+    if (!h || !target || !loss) return fail(CUNET_ERR_INVALID, "null argument");
+    if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
+    hipStream_t s = (hipStream_t)stream;
+    Exec E(h);
+    Plan& P = h->plan;
+    const TensorInfo& t0 = P.tensors[P.head_tensors[0]];
+    float* tgt = E.wsf + P.target_off;
+    HIPCHK(launch_transpose(target, tgt, t0.N, t0.C, t0.H * t0.W, t0.ld, 1, s));
+    double* acc = E.zero + P.loss_acc;
+    HIPCHK(hipMemsetAsync(acc, 0, 8, s));
+    for (int ht : P.head_tensors) {
+        const TensorInfo& t = P.tensors[ht];
+        HIPCHK(launch_mse(E.act(ht), tgt, E.grad(ht), acc, (long)t.rows(), t.C, t.ld, h->num_cus, s));
+    }
+    HIPCHK(launch_loss_finalize(acc, loss, s));
+    h->loss_done = 1;
+    return CUNET_OK;
+}
+
+int cunet_num_buckets(const cunet_plan_t* p) { return p ? (int)p->plan.bucket_begin.size() : 0; }
+
+int cunet_bucket_range(const cunet_plan_t* p, int bucket, int64_t* begin, int64_t* count) {
+    if (!p || !begin || !count || bucket < 0 || bucket >= (int)p->plan.bucket_begin.size())
+        return fail(CUNET_ERR_INVALID, "bad bucket index");
+    *begin = p->plan.bucket_begin[bucket];
+    *count = p->plan.bucket_count[bucket];
+    return CUNET_OK;
+}
+
+int cunet_backward(cunet_plan_t* h, const float* const* grad_heat, void* stream) {
+    return cunet_backward_ex(h, grad_heat, stream, nullptr, nullptr);
+}
+
+int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stream, cunet_bucket_cb on_bucket,
+                      void* user) {
+    if (!h) return fail(CUNET_ERR_INVALID, "null argument");
+    if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
+    if (!h->fwd_training_done) return fail(CUNET_ERR_STATE, "cunet_backward needs a preceding training-mode cunet_forward");
+    if (!grad_heat && !h->loss_done) return fail(CUNET_ERR_STATE, "no staged loss gradient: call cunet_loss_mse or pass grad_heat");
+    hipStream_t s = (hipStream_t)stream;
+    Exec E(h);
+    Plan& P = h->plan;
+    const int cus = h->num_cus;
+    if (grad_heat) {
+        for (size_t i = 0; i < P.head_tensors.size(); ++i) {
+            const TensorInfo& t = P.tensors[P.head_tensors[i]];
+            if (!grad_heat[i]) {
+                HIPCHK(hipMemsetAsync(E.grad(P.head_tensors[i]), 0, (size_t)t.rows() * t.ld * 4, s));
+            } else {
+                HIPCHK(launch_transpose(grad_heat[i], E.grad(P.head_tensors[i]), t.N, t.C, t.H * t.W, t.ld, 1, s));
+            }
+        }
+    }
+    HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
+    float* dz = E.wsf + P.dz_off;
+    int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
+    for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
+        const Node& n = P.nodes[k];
+        const TensorInfo& o = P.tensors[n.out];
+        if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
+            if (on_bucket) on_bucket(cur_bucket, user);
+            cur_bucket = n.bucket;
+        }
+        if (n.type == N_CONV) {
+            const ConvInfo& c = P.convs[n.conv];
+            const BnInfo& b = P.bns[n.bn];
+            double* red = E.zero + n.red;
+            {   // data gradient + ReLU mask + BN reductions
+                ConvArgs a{};
+                a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+                a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+                a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+                a.training = 1;
+                a.a = E.grad(n.out); a.lda = o.ld;
+                a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
+                a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
+                a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+                HIPCHK(launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
+            }
+            {   // weight gradient
+                WgradArgs w{};
+                w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
+                w.nseg = E.fill_segs(n, w.seg); w.Ccat = n.Ccat;
+                w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
+                w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
+                w.dw = h->grads + c.w;
+                HIPCHK(launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, s));
+            }
+            {   // BN backward apply into the segments' gradient buffers
+                BnApplyArgs a{};
+                a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+                a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+                a.dz = dz; a.lddz = n.Ccat; a.red = red;
+                a.dgamma = h->grads + b.gamma; a.dbeta = h->grads + b.beta;
+                a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+                HIPCHK(launch_bn_apply(a, cus, s));
+            }
+        } else if (n.type == N_POOL) {
+            const int tin = n.segs[0].tensor;
+            const TensorInfo& ti = P.tensors[tin];
+            PoolArgs a{};
+            a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
+            HIPCHK(launch_pool_bwd(a, cus, s));
+        } else if (n.type == N_STEM_BNPOOL) {
+            const int tin = n.segs[0].tensor;
+            const TensorInfo& ti = P.tensors[tin];
+            const BnInfo& b = P.bns[n.bn];
+            PoolArgs a{};
+            a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+            a.xstats = E.stats(tin); a.count = (double)ti.rows();
+            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 1;
+            a.red = E.zero + n.red;
+            HIPCHK(launch_stem_bwd(a, 0, nullptr, nullptr, cus, s));
+            HIPCHK(launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
+        } else {  // N_STEM_CONV: weight gradient only (the image needs no gradient)
+            const ConvInfo& c = P.convs[n.conv];
+            WgradArgs w{};
+            w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
+            w.nseg = 0; w.Ccat = c.Cin; w.taps = 1;
+            w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
+            w.dw = h->grads + c.w;
+            w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
+            HIPCHK(launch_wgrad(w, WGL_STEM, cus, s));
+        }
+    }
+    if (on_bucket && cur_bucket >= 0) on_bucket(cur_bucket, user);
+    // the reference re-runs every checkpointed cat->BN->ReLU->conv during backward, which updates
+    // those BNs' running statistics a second time (models/cu_net.py:30-31,58-59)
+    HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
+                                 E.zero, h->buffers, h->counters, 1, s));
+    h->fwd_training_done = 0;
+    return CUNET_OK;
+}
+
+int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n, float lr, float alpha,
+                       float eps, float grad_scale, void* stream) {
+    if (!params || !grads || !square_avg || n < 0) return fail(CUNET_ERR_INVALID, "null argument");
+    if (((uintptr_t)params & 15) || ((uintptr_t)grads & 15) || ((uintptr_t)square_avg & 15))
+        return fail(CUNET_ERR_INVALID, "arenas must be 16-byte aligned");
+    HIPCHK(launch_rmsprop(params, grads, square_avg, (long)n, lr, alpha, eps, grad_scale, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_get_preds(const float* heat, float* preds, int n, int k, int hh, int w, void* stream) {
+    if (!heat || !preds || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_get_preds(heat, preds, n * k, hh, w, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+}  // extern "C"

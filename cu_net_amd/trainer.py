@@ -1,0 +1,113 @@
+"""Fused train step and decode on the HIP path.
+
+`FusedTrainer.step(img, heatmap)` is the body of the reference's training loop
+(cu-net.py:171-183: forward, sum of per-head MSE, zero_grad/backward, RMSprop step) executed
+without leaving the HIP library: loss and d(loss)/d(out) come from the MSE kernel, gradients land
+in the flat arena, optional RCCL all-reduce runs per gradient bucket while backward is still in
+flight, and one fused RMSprop kernel updates every parameter.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import CUNetError, check, lib
+from .module import CUNet, _ptr, _stream_ptr
+
+
+class FusedTrainer:
+    def __init__(self, net: CUNet, lr: float = 2.5e-4, alpha: float = 0.99, eps: float = 1e-8,
+                 process_group=None, overlap: bool = True):
+        """RMSprop hyper-parameters default to cu-net.py:60-61. `process_group`: a torch.distributed
+        group (backend nccl == RCCL) for data parallelism, or None."""
+        if not isinstance(net, CUNet):
+            raise CUNetError('FusedTrainer needs a cu_net_amd.CUNet')
+        self.net = net
+        self.lr, self.alpha, self.eps = float(lr), float(alpha), float(eps)
+        self.square_avg = None
+        self.pg = process_group
+        self.world = 1
+        self.overlap = overlap
+        self._comm_stream = None
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+
+    # ---- data parallel plumbing (cu-net.py:59 DataParallel -> one process per GPU + RCCL) --------
+    def broadcast_parameters(self, src: int = 0):
+        """One-time replacement of DataParallel's per-iteration replicate."""
+        if self.pg is None:
+            return
+        import torch.distributed as dist
+        dist.broadcast(self.net._param_arena, src, group=self.pg)
+        dist.broadcast(self.net._buffer_arena, src, group=self.pg)
+        dist.broadcast(self.net._counter_arena, src, group=self.pg)
+
+    def _allreduce_bucket(self, b: int):
+        import torch.distributed as dist
+        begin, count = self.net._buckets[b]
+        if count == 0:
+            return
+        g = self.net._grad_arena[begin:begin + count]
+        dev = g.device
+        if self.overlap and dev.type == 'cuda':
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))       # everything writing bucket b is enqueued
+            self._comm_stream.wait_event(ev)
+            with torch.cuda.stream(self._comm_stream):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def step(self, img: torch.Tensor, heatmap: torch.Tensor) -> torch.Tensor:
+        """One optimisation step; returns the loss as a 0-dim device tensor (no host sync)."""
+        net = self.net
+        if not img.is_cuda or not heatmap.is_cuda:
+            raise CUNetError('FusedTrainer.step needs GPU tensors (no CPU fallback)')
+        if not net.training:
+            raise CUNetError('call net.train() before FusedTrainer.step')
+        net._check_aliasing()
+        img = img.contiguous()
+        heatmap = heatmap.contiguous()
+        n, _, h, w = img.shape
+        if tuple(heatmap.shape) != (n, net._hyper[3], h // 4, w // 4):
+            raise CUNetError(f'heatmap must be {n} x {net._hyper[3]} x {h // 4} x {w // 4}')
+        plan = net._get_plan(n, h, w, True)
+        plan.forward(img, True, want_outputs=False)
+        loss = plan.loss_mse(heatmap)
+        if self.pg is None:
+            plan.backward(None)
+        else:
+            plan.backward(None, on_bucket=self._allreduce_bucket)
+            if self._comm_stream is not None:
+                torch.cuda.current_stream(img.device).wait_stream(self._comm_stream)
+        if self.square_avg is None or self.square_avg.device != net._param_arena.device:
+            self.square_avg = torch.zeros_like(net._param_arena)
+        check(lib().cunet_rmsprop_step(_ptr(net._param_arena), _ptr(net._grad_arena), _ptr(self.square_avg),
+                                       net._n_params, self.lr, self.alpha, self.eps, 1.0 / self.world,
+                                       _stream_ptr(img.device)), 'cunet_rmsprop_step')
+        return loss
+
+    def last_outputs(self, img_shape):
+        """Heat maps of the last step (NCHW copies), e.g. for the per-step accuracy of cu-net.py:191."""
+        n, _, h, w = img_shape
+        plan = self.net._get_plan(n, h, w, True)
+        d = plan.handle.describe()
+        heads = sorted((nd['head'], d['tensors'][nd['out']]['name']) for nd in d['nodes'] if nd.get('head', -1) >= 0)
+        return [plan.debug_tensor(name) for _, name in heads]
+
+
+def get_preds(scores: torch.Tensor) -> torch.Tensor:
+    """pylib/Evaluation.py:6-23 on the GPU: N x K x H x W heat maps -> N x K x 2 float (x, y), 1-based,
+    zeros where the map's maximum is <= 0. Bit-exact with the reference (ties -> lowest index)."""
+    assert scores.dim() == 4, 'Score maps should be 4-dim'
+    if not scores.is_cuda:
+        raise CUNetError('get_preds: GPU tensor required (the CPU oracle is oracle/decode_ref.py)')
+    s = scores.contiguous().float()
+    n, k, h, w = s.shape
+    preds = torch.empty((n, k, 2), dtype=torch.float32, device=s.device)
+    check(lib().cunet_get_preds(_ptr(s), _ptr(preds), n, k, h, w, _stream_ptr(s.device)), 'cunet_get_preds')
+    return preds

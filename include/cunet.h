@@ -1,0 +1,134 @@
+/*
+ * cunet.h -- C ABI of the MI355X-native CU-Net hot path (libcunet_hip.so).
+ *
+ * The reference (zhiqiangdon/CU-Net) is pure Python on top of torch.nn and has no FFI of its
+ * own; this header is the boundary a maintainer would bind from Python (ctypes, see
+ * INTEGRATION.md) to replace the body of
+ *     models/cu_net.py:336-360   _CU_Net_Wrapper.forward
+ *     cu-net.py:175-183          loss + backward + optimizer.step
+ * while keeping `models/cu_net.py:362-368 create_cu_net(...)` as the user-facing surface.
+ *
+ * Conventions
+ *   - plain C types only; every device buffer is CALLER-OWNED (torch-allocated) and passed as a
+ *     raw device pointer; the plan owns no device memory.
+ *   - all work is enqueued on the hipStream_t the caller passes (void* here); no hidden sync.
+ *   - every function returns 0 on success or a negative cunet_status; cunet_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - one plan per (config, batch, H, W); a plan is not thread-safe, distinct plans are independent.
+ *   - activations are fp32; public image/heat-map tensors are NCHW like the reference's.
+ */
+#ifndef CUNET_H
+#define CUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cunet_plan cunet_plan_t;
+
+typedef enum {
+    CUNET_OK = 0,
+    CUNET_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    CUNET_ERR_STATE = -2,     /* call order violated (e.g. backward before forward) */
+    CUNET_ERR_HIP = -3,       /* a HIP runtime call failed */
+    CUNET_ERR_NOMEM = -4
+} cunet_status;
+
+/* Mirrors create_cu_net(neck_size, growth_rate, init_chan_num, class_num, layer_num, order,
+ * loss_num) -- models/cu_net.py:362-368 -- plus the input geometry the plan is specialised for. */
+typedef struct {
+    int32_t neck_size, growth_rate, init_chan_num, class_num, layer_num, order, loss_num;
+    int32_t batch, height, width;   /* input N x 3 x height x width; height, width % 64 == 0 */
+} cunet_cfg;
+
+/* One state_dict entry (reference key order, models/cu_net.py:299-320). */
+typedef struct {
+    char name[160];
+    int32_t kind;        /* 0 = parameter (float arena), 1 = running stat (buffer arena),
+                            2 = num_batches_tracked (int64 counter arena) */
+    int32_t ndim;
+    int64_t shape[4];
+    int64_t offset;      /* element offset inside its arena */
+    int64_t numel;
+} cunet_state_desc;
+
+const char* cunet_last_error(void);
+const char* cunet_version(void);
+
+/* ---- plan lifetime (host only; touches no device) ------------------------------------------ */
+int cunet_plan_create(const cunet_cfg* cfg, cunet_plan_t** out);
+void cunet_plan_destroy(cunet_plan_t* plan);
+
+/* ---- state layout: lets the host alias nn.Parameters onto flat arenas ----------------------- */
+int cunet_state_count(const cunet_plan_t* plan);
+int cunet_state_entry(const cunet_plan_t* plan, int index, cunet_state_desc* out);
+int64_t cunet_param_numel(const cunet_plan_t* plan);     /* floats: parameter arena == gradient arena */
+int64_t cunet_buffer_numel(const cunet_plan_t* plan);    /* floats: running_mean / running_var arena */
+int64_t cunet_counter_numel(const cunet_plan_t* plan);   /* int64: num_batches_tracked arena */
+int64_t cunet_workspace_bytes(const cunet_plan_t* plan, int training);
+int cunet_num_heads(const cunet_plan_t* plan);           /* == loss_num */
+/* anchors[i] = 1-based U-Net index whose head produces output i (models/cu_net.py:275-283) */
+int cunet_loss_anchors(const cunet_plan_t* plan, int32_t* anchors, int capacity);
+
+/* JSON description of tensors and nodes (tests and tooling; valid until the plan is destroyed) */
+const char* cunet_plan_describe(const cunet_plan_t* plan);
+
+/* ---- binding caller-owned device memory ------------------------------------------------------
+ * params/grads: cunet_param_numel floats each; buffers: cunet_buffer_numel floats;
+ * counters: cunet_counter_numel int64; workspace: cunet_workspace_bytes bytes, 256-B aligned.
+ * Uploads the plan's small device-side tables into the workspace on `stream`. */
+int cunet_bind(cunet_plan_t* plan, float* params, float* grads, float* buffers, int64_t* counters,
+               void* workspace, int64_t workspace_bytes, int training, void* stream);
+
+/* ---- the hot path ---------------------------------------------------------------------------
+ * forward: replaces _CU_Net_Wrapper.forward (models/cu_net.py:336-360).
+ *   x      : N x 3 x H x W fp32 NCHW (device)
+ *   heat[i]: N x class_num x H/4 x W/4 fp32 NCHW (device), i < loss_num; may be NULL to skip the copy-out
+ *   training != 0: BatchNorm uses batch statistics and running stats / counters are updated
+ *                  (once per BN; the reference's extra checkpoint-recompute update is applied
+ *                  by cunet_backward, as in the reference where it happens inside backward()). */
+int cunet_forward(cunet_plan_t* plan, const float* x, float* const* heat, int training, void* stream);
+
+/* loss: replaces cu-net.py:175-178. Writes sum_k mean((out_k - target)^2) to *loss (device float)
+ * and stages d(loss)/d(out_k) for cunet_backward. target is N x class_num x H/4 x W/4 NCHW. */
+int cunet_loss_mse(cunet_plan_t* plan, const float* target, float* loss, void* stream);
+
+/* backward: replaces loss.backward() (cu-net.py:182) for this network.
+ *   grad_heat: NULL -> use the gradients staged by cunet_loss_mse;
+ *              else loss_num NCHW tensors d(loss)/d(heat[i]) (autograd path).
+ *   Fills the bound gradient arena (overwrites; parameters that received no gradient stay 0). */
+int cunet_backward(cunet_plan_t* plan, const float* const* grad_heat, void* stream);
+
+/* Gradient buckets for data parallelism.  The parameter/gradient arena is laid out bucket-major:
+ * bucket i < layer_num holds every parameter used by U-Net index i, bucket layer_num the stem.
+ * cunet_backward_ex calls on_bucket(b, user) on the calling thread right after the LAST kernel
+ * writing bucket b has been enqueued on `stream` (order: layer_num-1, ..., 0, stem), so the host
+ * can record an event and start that bucket's RCCL all-reduce on another stream while the rest
+ * of backward runs.  (Replaces the grad reduce inside torch.nn.DataParallel, cu-net.py:59.) */
+typedef void (*cunet_bucket_cb)(int bucket, void* user);
+int cunet_num_buckets(const cunet_plan_t* plan);
+int cunet_bucket_range(const cunet_plan_t* plan, int bucket, int64_t* begin, int64_t* count);
+int cunet_backward_ex(cunet_plan_t* plan, const float* const* grad_heat, void* stream,
+                      cunet_bucket_cb on_bucket, void* user);
+
+/* fused RMSprop over a flat arena: torch.optim.RMSprop(lr, alpha, eps, momentum=0, weight_decay=0)
+ * (cu-net.py:60-61,183). g is multiplied by grad_scale first (1/world_size under data parallelism). */
+int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n,
+                       float lr, float alpha, float eps, float grad_scale, void* stream);
+
+/* argmax landmark decode: replaces pylib/Evaluation.py:6-23 get_preds.
+ *   heat : N x K x H x W fp32 NCHW; preds: N x K x 2 fp32 (1-based x, y; 0,0 where max <= 0) */
+int cunet_get_preds(const float* heat, float* preds, int n, int k, int h, int w, void* stream);
+
+/* ---- introspection for tests ------------------------------------------------------------------
+ * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);
+ * negative if unknown. Names are those listed by cunet_plan_describe. */
+int64_t cunet_debug_tensor_offset(const cunet_plan_t* plan, const char* name, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUNET_H */

@@ -1,0 +1,193 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the reference's golden vectors and
+against a tensor-by-tensor CPU execution of the same plan.
+
+Tolerance (BASELINE.json north_star): fp32 heat maps within 1e-4 relative; here every tensor is
+checked as  max|hip - ref| <= RTOL * max|ref| + ATOL  with RTOL = 1e-4 for activations and 5e-4 for
+gradients (fp32 reduction order differs: MFMA k-ordered fma chains, fp64 BN statistics, atomics).
+Integer outputs (num_batches_tracked) are bit-exact.  A per-tensor report is written to gpurun_out/.
+"""
+import os
+
+import pytest
+import torch
+
+import cu_net_amd
+from cu_net_amd.trainer import FusedTrainer
+from oracle import cunet_ref as O
+from tests._golden import TINY, Golden
+from tests._plan_interp import run_plan
+
+pytestmark = pytest.mark.gpu
+RTOL_ACT, RTOL_GRAD, ATOL = 1e-4, 5e-4, 1e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _report(tag, lines):
+    d = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f'parity_{tag}.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    except OSError:
+        pass
+
+
+def _cmp(name, got, ref, rtol, lines, bad):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    ok = err <= rtol * mag + ATOL and bool(torch.isfinite(got).all())
+    lines.append(f'{"ok " if ok else "BAD"} {name:70s} err={err:.3e} mag={mag:.3e} rel={err / (mag + 1e-30):.2e}')
+    if not ok:
+        bad.append(name)
+
+
+def _make_net(g):
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(g.group('state0'))
+    return net.cuda()
+
+
+@pytest.mark.parametrize('tag', TINY)
+def test_train_step_tensorwise(tag):
+    g = Golden(tag)
+    x, target = g.t('x'), g.t('target')
+    net = _make_net(g)
+    net.train()
+    tr = FusedTrainer(net)
+    xd, td = x.cuda(), target.cuda()
+    n, _, h, w = x.shape
+    # CPU execution of the same plan for per-tensor references
+    plan = net._get_plan(n, h, w, True)
+    st = g.group('state0')
+    for k in st:
+        if st[k].is_floating_point() and 'running' not in k:
+            st[k].requires_grad_(True)
+    outs_ref, acts_ref, grads_ref, loss_ref = run_plan(plan.handle.describe(), st, x, True, True, target)
+
+    lines, bad = [], []
+    loss = tr.step(xd, td)
+    torch.cuda.synchronize()
+    desc = plan.handle.describe()
+    for t in desc['tensors']:
+        _cmp('act  ' + t['name'], plan.debug_tensor(t['name']), acts_ref[t['name']], RTOL_ACT, lines, bad)
+    for a, b in zip(tr.last_outputs(x.shape), g.list('out')):
+        _cmp('golden out', a, b, RTOL_ACT, lines, bad)
+    _cmp('loss', loss, g.t('loss'), RTOL_ACT, lines, bad)
+    for t in reversed(desc['tensors']):
+        if t['name'] in grads_ref:
+            _cmp('grad ' + t['name'], plan.debug_tensor(t['name'], grad=True), grads_ref[t['name']], RTOL_GRAD, lines, bad)
+    gg = g.group('grad')
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    for k, v in gg.items():
+        o, nmel, shape = off[k]
+        _cmp('dparam ' + k, net._grad_arena[o:o + nmel].view(shape), v, RTOL_GRAD, lines, bad)
+    for k in g.z['grad_none'].tolist():
+        o, nmel, shape = off[k]
+        assert float(net._grad_arena[o:o + nmel].abs().max()) == 0.0
+    sd = net.state_dict()
+    for k, v in g.group('state1').items():
+        if 'num_batches_tracked' in k:
+            assert int(sd[k]) == int(v), k
+        elif 'running' in k:
+            _cmp('state1 ' + k, sd[k], v, 1e-4, lines, bad)
+        else:
+            # RMSprop's first step moves every weight by ~lr regardless of |g|: compare the update
+            _cmp('state1 ' + k, sd[k], v, 1e-4, lines, bad)
+    _report(tag, lines)
+    assert not bad, f'{len(bad)} tensors out of tolerance, first: {bad[:5]} (see gpurun_out/parity_{tag}.txt)'
+
+
+@pytest.mark.parametrize('tag', ['G1_L2_o1', 'G2_L3_o2'])
+def test_eval_and_nograd_forward(tag):
+    g = Golden(tag)
+    x = g.t('x').cuda()
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(g.group('state1'))
+    net.cuda().eval()
+    with torch.no_grad():
+        outs = net(x)
+    for a, b in zip(outs, g.list('eval')):
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= RTOL_ACT * b.abs().max().item() + ATOL, err
+    # train-mode forward without backward: single running-stat update, counters +1 (bit-exact)
+    net.train()
+    with torch.no_grad():
+        net(x)
+    sd = net.state_dict()
+    for k, v in g.group('state2').items():
+        if 'tracked' in k:
+            assert int(sd[k]) == int(v), k
+        else:
+            assert (sd[k].cpu() - v).abs().max().item() <= 1e-4 * v.abs().max().item() + ATOL, k
+
+
+@pytest.mark.parametrize('tag', ['G1_L2_o1', 'G3_L4_o1_ln2'])
+def test_autograd_path_matches_reference(tag):
+    """The drop-in loop of cu-net.py:171-183 with torch's own loss, backward() and RMSprop."""
+    g = Golden(tag)
+    x, target = g.t('x').cuda(), g.t('target').cuda()
+    net = _make_net(g)
+    net.train()
+    opt = torch.optim.RMSprop(net.parameters(), lr=2.5e-4, alpha=0.99, eps=1e-8, momentum=0, weight_decay=0)
+    out = net(x)
+    loss = 0
+    for o in out:
+        t = (o - target) ** 2
+        loss = loss + t.sum() / t.numel()
+    opt.zero_grad()
+    loss.backward()
+    gg = g.group('grad')
+    none = set(g.z['grad_none'].tolist())
+    for k, p in net.named_parameters():
+        if k in none:
+            assert p.grad is None, k
+        else:
+            err = (p.grad.cpu() - gg[k]).abs().max().item()
+            assert err <= RTOL_GRAD * gg[k].abs().max().item() + ATOL, (k, err)
+    opt.step()
+    assert abs(float(loss) - float(g.t('loss'))) <= 1e-4 * abs(float(g.t('loss')))
+    sd = net.state_dict()
+    for k, v in g.group('state1').items():
+        if 'tracked' in k:
+            assert int(sd[k]) == int(v), k
+
+
+def test_full_width_matches_reference():
+    """Full-width CU-Net-2 (K=68), N=1, 256x256 on the oracle's deterministic init."""
+    g = Golden('G5_full_L2K68')
+    spec = O.Spec(**g.cfg)
+    st = O.init_state(spec, seed=int(g.z['init_seed']))
+    x, target = O.synthetic_batch(1, spec.class_num, 256, seed=int(g.z['batch_seed']))
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(st)
+    net.cuda().train()
+    tr = FusedTrainer(net)
+    loss = tr.step(x.cuda(), target.cuda())
+    assert abs(float(loss) - float(g.z['loss'])) <= 1e-4 * float(g.z['loss'])
+    for i, o in enumerate(tr.last_outputs(x.shape)):
+        ref = g.t(f'out_sub/{i}')
+        err = (o.cpu()[:, ::4, ::4, ::4] - ref).abs().max().item()
+        assert err <= RTOL_ACT * ref.abs().max().item() + ATOL, (i, err)
+    names = g.z['grad_norm_names'].tolist()
+    off = {name: (o, nmel) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    for k, nrm in zip(names, g.z['grad_norms']):
+        o, nmel = off[k]
+        got = float(net._grad_arena[o:o + nmel].double().norm())
+        assert abs(got - nrm) <= 1e-3 * nrm + 1e-9, (k, got, nrm)
+
+
+def test_get_preds_bit_exact():
+    torch.manual_seed(3)
+    s = torch.randn(3, 5, 64, 64)
+    s[0, 0] = -1.0                      # all <= 0 -> zeros
+    s[0, 1] = 0.0
+    s[1, 2, 10, 20] = 9.0; s[1, 2, 40, 7] = 9.0     # tie -> lowest flat index
+    s[2, 4, 63, 63] = 50.0              # border maximum
+    s[2, 3, 0, 0] = 50.0
+    maxval, idx = torch.max(s.view(3, 5, -1), 2)     # pylib/Evaluation.py:11-21 restated
+    px = (idx % 64 + 1).float()
+    py = torch.floor(idx.float() / 64) + 1
+    ref = torch.stack([px, py], 2) * maxval.gt(0).unsqueeze(2).float()
+    got = cu_net_amd.get_preds(s.cuda()).cpu()
+    assert torch.equal(got, ref)
