@@ -66,6 +66,14 @@ def lib():
         'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
         'cunet_debug_tensor_offset': (i64, [vp, C.c_char_p, i32]),
+        'cunet_debug_run_node_backward': (i32, [vp, i32, vp]),
+        'cunet_profile_begin': (i32, [vp, i32, i32]),
+        'cunet_profile_reset': (i32, [vp]),
+        'cunet_profile_collect': (i32, [vp]),
+        'cunet_profile_num_classes': (i32, []),
+        'cunet_profile_class_name': (C.c_char_p, [i32]),
+        'cunet_profile_get': (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)      # AttributeError here == the ABI in include/cunet.h is not exported
@@ -80,7 +88,8 @@ EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_pla
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind',
             'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_num_buckets',
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds',
-            'cunet_debug_tensor_offset']
+            'cunet_debug_tensor_offset', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
+            'cunet_profile_num_classes', 'cunet_profile_class_name', 'cunet_profile_get']
 
 
 def check(rc: int, what: str = ''):
@@ -155,6 +164,32 @@ class PlanHandle:
             check(L.cunet_bucket_range(self.h, i, C.byref(b), C.byref(c)), 'cunet_bucket_range')
             out.append((int(b.value), int(c.value)))
         return out
+
+    # ---- per-kernel-class timing
+    def profile_begin(self, mode: int, cls: int = -1):
+        check(lib().cunet_profile_begin(self.h, mode, cls), 'cunet_profile_begin')
+
+    def profile_reset(self):
+        check(lib().cunet_profile_reset(self.h), 'cunet_profile_reset')
+
+    def profile_collect(self):
+        """dict class name -> (launches, ms, algorithmic flops, algorithmic bytes); waits for the events."""
+        L = lib()
+        check(L.cunet_profile_collect(self.h), 'cunet_profile_collect')
+        out = {}
+        cnt, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        for i in range(L.cunet_profile_num_classes()):
+            check(L.cunet_profile_get(self.h, i, C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)), 'cunet_profile_get')
+            out[L.cunet_profile_class_name(i).decode()] = (int(cnt.value), float(ms.value), float(fl.value), float(by.value))
+        return out
+
+    @staticmethod
+    def profile_class_index(name: str) -> int:
+        L = lib()
+        for i in range(L.cunet_profile_num_classes()):
+            if L.cunet_profile_class_name(i).decode() == name:
+                return i
+        raise KeyError(name)
 
     def describe(self):
         if self._desc is None:

@@ -109,7 +109,8 @@ struct RunStatEntry {      // running_mean / running_var update of one BN segmen
     int64_t rmean;         // float offset in buffer arena
     int64_t rvar;
     int64_t counter;       // int64 offset in counter arena, or -1 (only the first segment of a BN carries it)
-    double count;
+    double count;          // samples behind `stats` (source tensor rows)
+    double unbias;         // n/(n-1) with n = samples the BatchNorm saw (4x count for an upsampled segment)
     int C;
     int times;             // 1, or 2 for BNs the reference re-runs under torch.utils.checkpoint (2nd update from backward)
 };

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void running_update_kernel(const RunStatEntry*
         const double mean = stats_base[e.stats + c] / e.count;
         double var = stats_base[e.stats + e.C + c] / e.count - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        const double unb = e.count > 1.0 ? var * e.count / (e.count - 1.0) : var;
+        const double unb = var * e.unbias;
         float* rm = buffers + e.rmean + c;
         float* rv = buffers + e.rvar + c;
         *rm = (float)((1.0 - mom) * (double)*rm + mom * mean);

@@ -9,6 +9,9 @@
 #include "kernels.h"
 #include "plan.h"
 
+enum { PC_C1F = 0, PC_C3F, PC_STEMF, PC_C1D, PC_C3D, PC_C1W, PC_C3W, PC_STEMW, PC_APPLY, PC_POOLF, PC_POOLB,
+       PC_STEMBPF, PC_STEMBPB, PC_MISC, CUNET_PROF_NCLS };
+
 using namespace cunet;
 
 struct cunet_plan {
@@ -29,7 +32,50 @@ struct cunet_plan {
     int fwd_training_done = 0;
     int loss_done = 0;
     const float* last_x = nullptr;   // image of the last training forward (needed by the stem weight gradient)
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
+    int prof_mode = 0;               // 0 off, 1 every class, 2 only prof_cls
+    int prof_cls = -1;
+    struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[CUNET_PROF_NCLS] = {0};
+    double prof_flops[CUNET_PROF_NCLS] = {0};
+    double prof_bytes[CUNET_PROF_NCLS] = {0};
+    long prof_count[CUNET_PROF_NCLS] = {0};
 };
+
+static const char* kProfNames[CUNET_PROF_NCLS] = {
+    "conv1x1_fwd", "conv3x3_fwd", "stem_conv_fwd", "conv1x1_bwd_data", "conv3x3_bwd_data", "conv1x1_bwd_weight",
+    "conv3x3_bwd_weight", "stem_bwd_weight", "bn_bwd_apply", "pool_fwd", "pool_bwd", "stem_bnpool_fwd",
+    "stem_bnpool_bwd", "misc"};
+
+static hipError_t prof_begin(cunet_plan* h, int cls, hipStream_t s, int& slot) {
+    slot = -1;
+    if (h->prof_mode == 0 || (h->prof_mode == 2 && cls != h->prof_cls)) return hipSuccess;
+    cunet_plan::ProfRec r{};
+    for (hipEvent_t* e : {&r.a, &r.b}) {
+        if (!h->prof_pool.empty()) { *e = h->prof_pool.back(); h->prof_pool.pop_back(); }
+        else { hipError_t er = hipEventCreate(e); if (er != hipSuccess) return er; }
+    }
+    r.cls = cls;
+    h->prof_pending.push_back(r);
+    slot = (int)h->prof_pending.size() - 1;
+    return hipEventRecord(r.a, s);
+}
+static hipError_t prof_end(cunet_plan* h, int slot, double flops, double bytes, hipStream_t s) {
+    if (slot < 0) return hipSuccess;
+    h->prof_pending[slot].flops = flops;
+    h->prof_pending[slot].bytes = bytes;
+    return hipEventRecord(h->prof_pending[slot].b, s);
+}
+#define PROF(cls, flops, bytes, expr)                      \
+    do {                                                   \
+        int slot_;                                         \
+        HIPCHK(prof_begin(h, (cls), s, slot_));            \
+        HIPCHK(expr);                                      \
+        HIPCHK(prof_end(h, slot_, (flops), (bytes), s));   \
+    } while (0)
+
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -136,6 +182,8 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
                 e.stats = t.stats; e.rmean = b.rmean + choff; e.rvar = b.rvar + choff;
                 e.counter = s == 0 ? b.counter : -1;
                 e.count = (double)t.rows(); e.C = t.C; e.times = b.ckpt ? 2 : 1;
+                const double nfull = (double)t.rows() * (n.segs[s].ups ? 4.0 : 1.0);
+                e.unbias = nfull > 1.0 ? nfull / (nfull - 1.0) : 1.0;
                 h->runstat.push_back(e);
                 choff += t.C;
             }
@@ -145,6 +193,7 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
             RunStatEntry e{};
             e.stats = t.stats; e.rmean = b.rmean; e.rvar = b.rvar; e.counter = b.counter;
             e.count = (double)t.rows(); e.C = t.C; e.times = 1;
+            e.unbias = e.count > 1.0 ? e.count / (e.count - 1.0) : 1.0;
             h->runstat.push_back(e);
         }
     }
@@ -167,6 +216,7 @@ struct Exec {
     Plan& P;
     float* wsf;        // float region
     double* zero;      // fp64 region
+    int force_first = 0;
     explicit Exec(cunet_plan* hh) : h(hh), P(hh->plan) {
         wsf = reinterpret_cast<float*>(h->ws + P.off_floats);
         zero = reinterpret_cast<double*>(h->ws + P.off_zero);
@@ -184,7 +234,7 @@ struct Exec {
             s.gx = h->bound_training ? grad(n.segs[i].tensor) : nullptr;
             s.stats = stats(n.segs[i].tensor);
             s.count = (double)t.rows();
-            s.C = t.C; s.ld = t.ld; s.ups = n.segs[i].ups; s.gfirst = n.segs[i].gfirst; s.choff = choff; s.pad_ = 0;
+            s.C = t.C; s.ld = t.ld; s.ups = n.segs[i].ups; s.gfirst = force_first ? 1 : n.segs[i].gfirst; s.choff = choff; s.pad_ = 0;
             choff += t.C;
         }
         return (int)n.segs.size();
@@ -192,6 +242,82 @@ struct Exec {
 };
 
 }  // namespace
+
+// Backward of one node: data gradient (+ReLU mask + BN reductions), weight gradient, BN apply.
+static int bwd_node(cunet_plan* h, const Node& n, int force_first, hipStream_t s) {
+    Exec E(h);
+    Plan& P = h->plan;
+    const int cus = h->num_cus;
+    E.force_first = force_first;
+    float* dz = E.wsf + P.dz_off;
+    const TensorInfo& o = P.tensors[n.out];
+    if (n.type == N_CONV) {
+        const ConvInfo& c = P.convs[n.conv];
+        const BnInfo& b = P.bns[n.bn];
+        double* red = E.zero + n.red;
+        {   // data gradient + ReLU mask + BN reductions
+            ConvArgs a{};
+            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+            a.training = 1;
+            a.a = E.grad(n.out); a.lda = o.ld;
+            a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
+            a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
+            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
+                 launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
+        }
+        {   // weight gradient
+            WgradArgs w{};
+            w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
+            w.nseg = E.fill_segs(n, w.seg); w.Ccat = n.Ccat;
+            w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
+            w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
+            w.dw = h->grads + c.w;
+            PROF(c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
+                 launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, s));
+        }
+        {   // BN backward apply into the segments' gradient buffers
+            BnApplyArgs a{};
+            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+            a.dz = dz; a.lddz = n.Ccat; a.red = red;
+            a.dgamma = h->grads + b.gamma; a.dbeta = h->grads + b.beta;
+            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            PROF(PC_APPLY, 0.0, 4.0 * 4.0 * (double)a.M * a.Ccat, launch_bn_apply(a, cus, s));
+        }
+    } else if (n.type == N_POOL) {
+        const int tin = n.segs[0].tensor;
+        const TensorInfo& ti = P.tensors[tin];
+        PoolArgs a{};
+        a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+        a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
+        PROF(PC_POOLB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_pool_bwd(a, cus, s));
+    } else if (n.type == N_STEM_BNPOOL) {
+        const int tin = n.segs[0].tensor;
+        const TensorInfo& ti = P.tensors[tin];
+        const BnInfo& b = P.bns[n.bn];
+        PoolArgs a{};
+        a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+        a.xstats = E.stats(tin); a.count = (double)ti.rows();
+        a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+        a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 1;
+        a.red = E.zero + n.red;
+        PROF(PC_STEMBPB, 0.0, 4.0 * 1.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 0, nullptr, nullptr, cus, s));
+        PROF(PC_STEMBPB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
+    } else {  // N_STEM_CONV: weight gradient only (the image needs no gradient)
+        const ConvInfo& c = P.convs[n.conv];
+        WgradArgs w{};
+        w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
+        w.nseg = 0; w.Ccat = c.Cin; w.taps = 1;
+        w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
+        w.dw = h->grads + c.w;
+        w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
+        PROF(PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout, launch_wgrad(w, WGL_STEM, cus, s));
+    }
+    return CUNET_OK;
+}
 
 extern "C" {
 
@@ -214,7 +340,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             a.img = x; a.IH = P.cfg.height; a.IW = P.cfg.width;
-            HIPCHK(launch_conv(a, LD_STEM, EP_FWD, cus, s));
+            PROF(PC_STEMF, 2.0 * a.M * a.K * a.Nout, 4.0 * ((double)a.M * a.Nout + (double)o.N * 3 * a.IH * a.IW), launch_conv(a, LD_STEM, EP_FWD, cus, s));
         } else if (n.type == N_STEM_BNPOOL || n.type == N_POOL) {
             const int tin = n.segs[0].tensor;
             const TensorInfo& ti = P.tensors[tin];
@@ -226,9 +352,9 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
                 a.xstats = E.stats(tin); a.count = (double)ti.rows();
                 a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
                 a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-                HIPCHK(launch_pool_fwd(a, 1, cus, s));
+                PROF(PC_STEMBPF, 0.0, 4.0 * 1.25 * (double)ti.rows() * ti.C, launch_pool_fwd(a, 1, cus, s));
             } else {
-                HIPCHK(launch_pool_fwd(a, 0, cus, s));
+                PROF(PC_POOLF, 0.0, 4.0 * 1.25 * (double)ti.rows() * ti.C, launch_pool_fwd(a, 0, cus, s));
             }
         } else {  // N_CONV
             const ConvInfo& c = P.convs[n.conv];
@@ -241,7 +367,8 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             a.K = n.Ccat; a.taps = c.taps; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            HIPCHK(launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
+            PROF(c.taps == 9 ? PC_C3F : PC_C1F, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + a.Nout),
+                 launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
         }
     }
     if (training)
@@ -315,78 +442,15 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         }
     }
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
-    float* dz = E.wsf + P.dz_off;
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
-        const TensorInfo& o = P.tensors[n.out];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
             if (on_bucket) on_bucket(cur_bucket, user);
             cur_bucket = n.bucket;
         }
-        if (n.type == N_CONV) {
-            const ConvInfo& c = P.convs[n.conv];
-            const BnInfo& b = P.bns[n.bn];
-            double* red = E.zero + n.red;
-            {   // data gradient + ReLU mask + BN reductions
-                ConvArgs a{};
-                a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
-                a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-                a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-                a.training = 1;
-                a.a = E.grad(n.out); a.lda = o.ld;
-                a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
-                a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
-                a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-                HIPCHK(launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
-            }
-            {   // weight gradient
-                WgradArgs w{};
-                w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
-                w.nseg = E.fill_segs(n, w.seg); w.Ccat = n.Ccat;
-                w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
-                w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
-                w.dw = h->grads + c.w;
-                HIPCHK(launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, s));
-            }
-            {   // BN backward apply into the segments' gradient buffers
-                BnApplyArgs a{};
-                a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
-                a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-                a.dz = dz; a.lddz = n.Ccat; a.red = red;
-                a.dgamma = h->grads + b.gamma; a.dbeta = h->grads + b.beta;
-                a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-                HIPCHK(launch_bn_apply(a, cus, s));
-            }
-        } else if (n.type == N_POOL) {
-            const int tin = n.segs[0].tensor;
-            const TensorInfo& ti = P.tensors[tin];
-            PoolArgs a{};
-            a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
-            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
-            HIPCHK(launch_pool_bwd(a, cus, s));
-        } else if (n.type == N_STEM_BNPOOL) {
-            const int tin = n.segs[0].tensor;
-            const TensorInfo& ti = P.tensors[tin];
-            const BnInfo& b = P.bns[n.bn];
-            PoolArgs a{};
-            a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
-            a.xstats = E.stats(tin); a.count = (double)ti.rows();
-            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 1;
-            a.red = E.zero + n.red;
-            HIPCHK(launch_stem_bwd(a, 0, nullptr, nullptr, cus, s));
-            HIPCHK(launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
-        } else {  // N_STEM_CONV: weight gradient only (the image needs no gradient)
-            const ConvInfo& c = P.convs[n.conv];
-            WgradArgs w{};
-            w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
-            w.nseg = 0; w.Ccat = c.Cin; w.taps = 1;
-            w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
-            w.dw = h->grads + c.w;
-            w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
-            HIPCHK(launch_wgrad(w, WGL_STEM, cus, s));
-        }
+        const int rc = bwd_node(h, n, 0, s);
+        if (rc != CUNET_OK) return rc;
     }
     if (on_bucket && cur_bucket >= 0) on_bucket(cur_bucket, user);
     // the reference re-runs every checkpointed cat->BN->ReLU->conv during backward, which updates
@@ -409,6 +473,53 @@ int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int
 int cunet_get_preds(const float* heat, float* preds, int n, int k, int hh, int w, void* stream) {
     if (!heat || !preds || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
     HIPCHK(launch_get_preds(heat, preds, n * k, hh, w, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
+    if (!h || node < 0 || node >= (int)h->plan.nodes.size()) return fail(CUNET_ERR_INVALID, "bad node index");
+    if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
+    hipStream_t s = (hipStream_t)stream;
+    Plan& P = h->plan;
+    const Node& n = P.nodes[node];
+    if (n.red >= 0)
+        HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * n.red, 0, (size_t)16 * n.Ccat, s));
+    HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
+    return bwd_node(h, n, 1, s);
+}
+
+int cunet_profile_begin(cunet_plan_t* h, int mode, int cls) {
+    if (!h || mode < 0 || mode > 2 || (mode == 2 && (cls < 0 || cls >= CUNET_PROF_NCLS))) return fail(CUNET_ERR_INVALID, "bad profile mode");
+    h->prof_mode = mode;
+    h->prof_cls = cls;
+    return CUNET_OK;
+}
+
+int cunet_profile_reset(cunet_plan_t* h) {
+    if (!h) return fail(CUNET_ERR_INVALID, "null argument");
+    for (int i = 0; i < CUNET_PROF_NCLS; ++i) { h->prof_ms[i] = h->prof_flops[i] = h->prof_bytes[i] = 0; h->prof_count[i] = 0; }
+    return CUNET_OK;
+}
+
+int cunet_profile_collect(cunet_plan_t* h) {
+    if (!h) return fail(CUNET_ERR_INVALID, "null argument");
+    for (auto& r : h->prof_pending) {
+        HIPCHK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        h->prof_ms[r.cls] += ms; h->prof_flops[r.cls] += r.flops; h->prof_bytes[r.cls] += r.bytes; h->prof_count[r.cls] += 1;
+        h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b);
+    }
+    h->prof_pending.clear();
+    return CUNET_OK;
+}
+
+int cunet_profile_num_classes(void) { return CUNET_PROF_NCLS; }
+const char* cunet_profile_class_name(int cls) { return (cls >= 0 && cls < CUNET_PROF_NCLS) ? kProfNames[cls] : ""; }
+
+int cunet_profile_get(const cunet_plan_t* h, int cls, int64_t* count, double* ms, double* flops, double* bytes) {
+    if (!h || cls < 0 || cls >= CUNET_PROF_NCLS || !count || !ms || !flops || !bytes) return fail(CUNET_ERR_INVALID, "bad argument");
+    *count = h->prof_count[cls]; *ms = h->prof_ms[cls]; *flops = h->prof_flops[cls]; *bytes = h->prof_bytes[cls];
     return CUNET_OK;
 }
 

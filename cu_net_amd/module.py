@@ -90,6 +90,20 @@ class _BoundPlan:
             self._cb_keepalive = cb
             check(lib().cunet_backward_ex(self.handle.h, arr, _stream_ptr(dev), cb, None), 'cunet_backward_ex')
 
+    def debug_poke(self, name: str, value: torch.Tensor, grad: bool = True):
+        """Overwrite an internal NHWC tensor from an NCHW one (kernel unit tests only)."""
+        d = self.handle.describe()
+        t = [t for t in d['tensors'] if t['name'] == name][0]
+        off = self.handle.tensor_offset(name, 1 if grad else 0)
+        rows = t['N'] * t['H'] * t['W']
+        flat = self.workspace[off: off + rows * t['ld'] * 4].view(torch.float32).view(t['N'], t['H'], t['W'], t['ld'])
+        flat.zero_()
+        flat[..., :t['C']] = value.to(flat.device).permute(0, 2, 3, 1)
+
+    def debug_run_node_backward(self, node_index: int):
+        check(lib().cunet_debug_run_node_backward(self.handle.h, node_index, _stream_ptr(self.workspace.device)),
+              'cunet_debug_run_node_backward')
+
     def debug_tensor(self, name: str, grad: bool = False) -> torch.Tensor:
         """NCHW copy of an internal NHWC tensor (tests only)."""
         d = self.handle.describe()

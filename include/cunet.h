@@ -123,10 +123,26 @@ int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int
  *   heat : N x K x H x W fp32 NCHW; preds: N x K x 2 fp32 (1-based x, y; 0,0 where max <= 0) */
 int cunet_get_preds(const float* heat, float* preds, int n, int k, int h, int w, void* stream);
 
+/* ---- per-kernel-class timing (bench.py roofline) ------------------------------------------------
+ * HIP events are recorded on the launch stream around every launch of the selected class(es):
+ * mode 0 = off, 1 = every class, 2 = only class `cls`.  cunet_profile_collect waits for the pending
+ * events and accumulates; cunet_profile_get returns launches, total milliseconds, total ALGORITHMIC
+ * flops (2*M*K*N*taps per GEMM-shaped launch) and algorithmic bytes of the class. */
+int cunet_profile_begin(cunet_plan_t* plan, int mode, int cls);
+int cunet_profile_reset(cunet_plan_t* plan);
+int cunet_profile_collect(cunet_plan_t* plan);
+int cunet_profile_num_classes(void);
+const char* cunet_profile_class_name(int cls);
+int cunet_profile_get(const cunet_plan_t* plan, int cls, int64_t* count, double* ms, double* flops, double* bytes);
+
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);
  * negative if unknown. Names are those listed by cunet_plan_describe. */
 int64_t cunet_debug_tensor_offset(const cunet_plan_t* plan, const char* name, int which);
+/* Runs the backward of ONE node (index into the describe() node list) in isolation: clears the
+ * node's reduction scratch and the whole gradient arena, then writes (never accumulates) the input
+ * gradients.  The caller pokes d(loss)/d(output) into the workspace first.  Kernel unit tests. */
+int cunet_debug_run_node_backward(cunet_plan_t* plan, int node, void* stream);
 
 #ifdef __cplusplus
 }

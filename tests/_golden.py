@@ -6,7 +6,7 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CFG_KEYS = ('neck_size', 'growth_rate', 'init_chan_num', 'class_num', 'layer_num', 'order', 'loss_num')
-TINY = ['G1_L2_o1', 'G2_L3_o2', 'G3_L4_o1_ln2', 'G4_L2_o0', 'G9_L2_o1_c32']
+TINY = ['G1_L2_o1', 'G2_L3_o2', 'G3_L4_o1_ln2', 'G4_L2_o0', 'G9_L2_o1_c32', 'G6_L2_o1_hw64']
 
 
 class Golden:

@@ -189,13 +189,15 @@ def main():
     torch.set_num_threads(8)
     ref = load_reference_models()
     tiny = dict(neck_size=2, growth_rate=4, init_chan_num=8)
-    one_config(ref, 'G1_L2_o1', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=2, hw=64, seed=11)
-    one_config(ref, 'G2_L3_o2', dict(tiny, class_num=5, layer_num=3, order=2, loss_num=3), n=2, hw=64, seed=12)
-    one_config(ref, 'G3_L4_o1_ln2', dict(tiny, class_num=3, layer_num=4, order=1, loss_num=2), n=2, hw=64, seed=13)
-    one_config(ref, 'G4_L2_o0', dict(tiny, class_num=4, layer_num=2, order=0, loss_num=1), n=3, hw=64, seed=14)
+    one_config(ref, 'G1_L2_o1', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=2, hw=128, seed=11)
+    one_config(ref, 'G2_L3_o2', dict(tiny, class_num=5, layer_num=3, order=2, loss_num=3), n=2, hw=128, seed=12)
+    one_config(ref, 'G3_L4_o1_ln2', dict(tiny, class_num=3, layer_num=4, order=1, loss_num=2), n=2, hw=128, seed=13)
+    one_config(ref, 'G4_L2_o0', dict(tiny, class_num=4, layer_num=2, order=0, loss_num=1), n=3, hw=128, seed=14)
     # wider channels (multiples of 32 like the real net), one image, rectangular-free 128x128 input
     one_config(ref, 'G9_L2_o1_c32', dict(neck_size=2, growth_rate=16, init_chan_num=32, class_num=6,
                                          layer_num=2, order=1, loss_num=2), n=1, hw=128, seed=15)
+    # a 64x64 input: the neck is 1x1 and BatchNorm there sees N samples only (edge case, forward pins only)
+    one_config(ref, 'G6_L2_o1_hw64', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=4, hw=64, seed=16)
     full_width(ref)
 
 
