@@ -60,6 +60,7 @@ struct ConvArgs {
     // ---- stem (LD_STEM): NCHW image
     const float* img;
     int IH, IW;
+    int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 2 no A loads, 4 no MFMA, 8 no stores
 };
 
 struct WgradArgs {
@@ -129,6 +130,20 @@ struct PoolArgs {
     float* gx;             // [hi][C]
     double* red;           // stem backward reductions [2][C]
 };
+
+// Explicit global-address-space loads.  A pointer that reaches a lane through LDS or through a
+// dynamically indexed kernarg struct has lost its address space, and hipcc then emits flat_load,
+// which also counts on LGKM: the next `s_waitcnt lgkmcnt(0)` in front of an LDS-fed MFMA group would
+// wait for the whole HBM prefetch (measured: the forward conv ran at 37 % MFMA utilisation because of it).
+#if defined(__HIPCC__)
+typedef const float __attribute__((address_space(1)))* gptr_f32;
+typedef const f32x4 __attribute__((address_space(1)))* gptr_f32x4;
+__device__ __forceinline__ float ldg1(const float* p) { return *(gptr_f32)(uintptr_t)p; }
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const f32x4 v = *(gptr_f32x4)(uintptr_t)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#endif
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 __host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -6,16 +6,21 @@
 //   models/cu_net.py:300     conv0 7x7/2                  (stem, im2col gather)
 //   and the data-gradient half of autograd for those nodes (EP_BWD).
 //
-// Design (gfx950, fp32): one wave owns 32 output rows (pixels) x NT*32 output channels and
-// contracts with v_mfma_f32_32x32x2_f32.  The A operand (activations) is read straight from
-// HBM/L2 as one 16-byte NHWC piece per lane -- lane (row = l&31, half = l>>5) takes channels
-// 8q+4*half..+3 of the current 32-channel chunk -- and BatchNorm+ReLU is applied in registers,
-// so a concat is never materialised and each activation is normalised exactly once per use.
-// The B operand (weights, pre-packed [tap][k/4][n][4]) is staged through double-buffered LDS
-// and shared by the block's 4 waves.  Because the f32 MFMA issues once per 64 cycles the
-// kernel is matrix-pipe bound; loads and the BN arithmetic hide underneath.
+// Design (gfx950, fp32): WEIGHT-STATIONARY and barrier-free.  The weights of a node are tiny
+// (<= 160 KB fp32) next to its activations (tens of MB), so a block first copies its whole B operand
+// (pre-packed [tap][k/4][n][4], all taps, all K, NT*32 output channels) into the CU's 160 KB LDS
+// ONCE; after that single barrier its (up to 12) waves never synchronise again: each wave walks its
+// own 32-row tiles, reads the A operand (activations) straight from HBM/L2 as one 16-byte NHWC piece
+// per lane -- lane (row = l&31, half = l>>5) takes channels 8q+4*half..+3 of the current 32-channel
+// chunk, one chunk ahead in registers -- applies BatchNorm+ReLU in registers (a concat is never
+// materialised), fetches B fragments with conflict-free ds_read_b128 and contracts with
+// v_mfma_f32_32x32x2_f32.  Independent waves de-synchronise, so one wave's load latency is covered
+// by the other waves' MFMAs (the first, double-buffered-B version of this kernel had a barrier per
+// 32-channel chunk and reached only 37 % MFMA utilisation: its phases serialised).
 // Per-channel batch statistics of the OUTPUT (sum, sum of squares) are produced in the
 // epilogue in fp64 so every consumer BatchNorm reuses them (a BN over a concat is per channel).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cunet {
@@ -44,7 +49,7 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
     const int tid = threadIdx.x;
     for (int s = 0; s < p.nseg; ++s) {
         const Seg sg = p.seg[s];
-        for (int lc = tid; lc < sg.C; lc += 256) {
+        for (int lc = tid; lc < sg.C; lc += blockDim.x) {
             const int c = sg.choff + lc;
             double mean, istd;
             if (p.training) {
@@ -65,7 +70,7 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
                 is[c] = (float)istd;
             }
         }
-        for (int g = tid; g < (sg.C >> 2); g += 256) {
+        for (int g = tid; g < (sg.C >> 2); g += blockDim.x) {
             GrpEnt e;
             e.ptr = sg.x + 4 * g;
             e.ld = sg.ld;
@@ -75,43 +80,54 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
     }
 }
 
-template <int LD, int EP, int NT>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
+constexpr int CONV_MAX_WAVES = 12;   // 3 waves per SIMD (VGPR budget 168)
+
+template <int LD, int EP, int NT, bool FAST>
+__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
-    float4* Bs = reinterpret_cast<float4*>(smem);    // [2][8][NB]
-    GrpEnt* grp = reinterpret_cast<GrpEnt*>(Bs + 2 * 8 * NB);
+    const int kq4 = p.Kpad >> 2;
+    const int brows = p.taps * kq4;                  // float4 rows of B
+    float4* Bs = reinterpret_cast<float4*>(smem);    // [taps * Kpad/4][NB]
+    GrpEnt* grp = reinterpret_cast<GrpEnt*>(Bs + (size_t)brows * NB);
     float* sc = reinterpret_cast<float*>(grp + (p.Ccat >> 2));
     float* sh = sc + p.Ccat;
     float* mu = sh + p.Ccat;
     float* is = mu + p.Ccat;
-    double* redbuf = reinterpret_cast<double*>(is + p.Ccat + ((p.Ccat & 1) ? 1 : 0));  // [4][NB][2]
+    double* redbuf = reinterpret_cast<double*>(is + p.Ccat);   // [NB][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
     const int n0 = blockIdx.y * NB;
 
-    constexpr bool HAS_CONCAT = (LD == LD_SEG || LD == LD_3X3 || EP == EP_BWD);
-    if (HAS_CONCAT) {
-        setup_concat<EP == EP_BWD>(p, grp, sc, sh, mu, is);
-        __syncthreads();
+    // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
+    for (int idx = tid; idx < brows * NB; idx += blockDim.x) {
+        const int row = idx / NB;
+        const int n = idx - row * NB;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + n < p.Npad) v = ldg4(p.wB + ((size_t)row * p.Npad + n0 + n) * 4);
+        Bs[idx] = v;
     }
+    constexpr bool HAS_CONCAT = (LD == LD_SEG || LD == LD_3X3 || EP == EP_BWD);
+    if (HAS_CONCAT) setup_concat<EP == EP_BWD>(p, grp, sc, sh, mu, is);
+    for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
+    __syncthreads();
 
     const int HW = p.H * p.W;
     const int nck = p.Kpad >> 5;                     // 32-channel chunks per tap
     const int nchunks = p.taps * nck;
-    const int ntiles = (p.M + 127) >> 7;
-    const int kq4 = p.Kpad >> 2;
+    const int ntiles = (p.M + 31) >> 5;              // 32-row tiles, one per wave at a time
 
     double dsum[NT], dsq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m = tile * 128 + wave * 32 + li;   // this lane's A row
+    for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+        const int m = tile * 32 + li;                // this lane's A row
         const int mc = m < p.M ? m : p.M - 1;
         const int nimg = mc / HW;
         const int rem = mc - nimg * HW;
@@ -139,21 +155,20 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
             for (int q = 0; q < 4; ++q) {
                 const int kk = c * 32 + q * 8 + hi * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk < p.K) {
+                if (kk < p.K && !(p.dbg & 2)) {
                     if (LD == LD_SEG) {
                         const GrpEnt g = grp[kk >> 2];
-                        const float* src = g.ptr + (size_t)(g.ups ? rowU : mc) * g.ld;
-                        v = *reinterpret_cast<const float4*>(src);
+                        v = ldg4(g.ptr + (size_t)(g.ups ? rowU : mc) * g.ld);
                     } else if (LD == LD_3X3) {
                         bool valid;
                         const int row = tap_row(t, valid);
-                        v = *reinterpret_cast<const float4*>(p.seg[0].x + (size_t)row * p.seg[0].ld + kk);
+                        v = ldg4(p.seg[0].x + (size_t)row * p.seg[0].ld + kk);
                     } else if (LD == LD_PLAIN) {
-                        v = *reinterpret_cast<const float4*>(p.a + (size_t)mc * p.lda + kk);
+                        v = ldg4(p.a + (size_t)mc * p.lda + kk);
                     } else if (LD == LD_PLAIN3) {
                         bool valid;
                         const int row = tap_row(t, valid);
-                        v = *reinterpret_cast<const float4*>(p.a + (size_t)row * p.lda + kk);
+                        v = ldg4(p.a + (size_t)row * p.lda + kk);
                         if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {  // LD_STEM: im2col gather of the NCHW image, 7x7 stride 2 pad 3
                         float e4[4];
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
                             const int kx = r - ky * 7;
                             const int iy = 2 * py - 3 + ky, ix = 2 * px - 3 + kx;
                             const bool ok = (k < p.K) && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                            e4[e] = ok ? p.img[((size_t)(nimg * 3 + ci) * p.IH + iy) * p.IW + ix] : 0.f;
+                            e4[e] = ok ? ldg1(p.img + ((size_t)(nimg * 3 + ci) * p.IH + iy) * p.IW + ix) : 0.f;
                         }
                         v = make_float4(e4[0], e4[1], e4[2], e4[3]);
                     }
@@ -196,65 +211,107 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
                 }
             }
         };
-        auto load_b = [&](int ch, float4 (&b)[NT]) {
-            const int t = ch / nck;
-            const int c = ch - t * nck;
-#pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                const int j = tid + 256 * it;
-                const int kq = j / NB;
-                const int n = j - kq * NB;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n0 + n < p.Npad)
-                    v = *reinterpret_cast<const float4*>(
-                        p.wB + ((size_t)(t * kq4 + c * 8 + kq) * p.Npad + n0 + n) * 4);
-                b[it] = v;
-            }
-        };
-        auto store_b = [&](int buf, const float4 (&b)[NT]) {
-#pragma unroll
-            for (int it = 0; it < NT; ++it) Bs[buf * 8 * NB + tid + 256 * it] = b[it];
-        };
 
-        // ---- pipeline: A one chunk ahead in registers, B double-buffered in LDS ---------
-        float4 anext[4], bnext[NT];
-        load_a(0, anext);
-        load_b(0, bnext);
-        __syncthreads();            // previous tile's readers of Bs are done
-        store_b(0, bnext);
-        __syncthreads();
-
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int buf = ch & 1;
-            float4 acur[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acur[q] = anext[q];
-            activate(ch, acur);
-            if (ch + 1 < nchunks) {
-                load_a(ch + 1, anext);
-                load_b(ch + 1, bnext);
-            }
-            const float4* bb = Bs + buf * 8 * NB;
+        auto mfma_chunk = [&](int ch, const float4 (&acur)[4]) {
+            const float4* bb = Bs + (size_t)ch * 8 * NB;     // chunk ch = (tap, c): rows (t*kq4 + c*8) ..+7
+            if (!(p.dbg & 4))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 bv[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[nt] = bb[(2 * q + hi) * NB + nt * 32 + li];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].x, bv[nt].x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].y, bv[nt].y, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].z, bv[nt].z, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].w, bv[nt].w, acc[nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].x, bv[nt].x, acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].y, bv[nt].y, acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].z, bv[nt].z, acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].w, bv[nt].w, acc[nt], 0, 0, 0);
             }
-            if (ch + 1 < nchunks) store_b(buf ^ 1, bnext);
-            __syncthreads();
+        };
+
+        if (FAST) {
+            // ---- fast path: every segment and K are multiples of 32 channels and M of 32 rows, so a
+            // chunk never straddles a segment and nothing is predicated: straight-line code, the
+            // segment descriptor is wave-uniform (scalar loads from the kernarg), the per-lane row
+            // pointer is recomputed only when the segment (or tap) changes, loads take immediates.
+            int sidx = 0, cl = 0, ncs = 0, tap = 0;          // uniform loop state
+            const float* rowptr = nullptr;                    // per lane: &X[row][4*hi] of the current segment/tap
+            bool tvalid = true;
+            auto enter = [&]() {                              // (re)compute rowptr for (sidx | tap)
+                if (LD == LD_SEG) {
+                    const Seg sg = p.seg[sidx];
+                    rowptr = sg.x + (size_t)(sg.ups ? rowU : mc) * sg.ld + 4 * hi;
+                    ncs = sg.C >> 5;
+                } else if (LD == LD_3X3 || LD == LD_PLAIN3) {
+                    const int row = tap_row(tap, tvalid);
+                    const float* base = (LD == LD_3X3) ? p.seg[0].x : p.a;
+                    const int ld = (LD == LD_3X3) ? p.seg[0].ld : p.lda;
+                    rowptr = base + (size_t)row * ld + 4 * hi;
+                    ncs = nck;
+                } else {
+                    rowptr = p.a + (size_t)mc * p.lda + 4 * hi;
+                    ncs = nck;
+                }
+                cl = 0;
+            };
+            auto fetch = [&](float4 (&a)[4]) {                // loads chunk (sidx|tap, cl) and advances
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = ldg4(rowptr + cl * 32 + q * 8);
+                if (LD == LD_PLAIN3 && !tvalid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            enter();
+            float4 anext[4];
+            bool vcur = tvalid;
+            fetch(anext);
+            for (int ch = 0; ch < nchunks; ++ch) {
+                float4 acur[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acur[q] = anext[q];
+                const bool vthis = vcur;
+                if (ch + 1 < nchunks) {
+                    if (++cl == ncs) { ++sidx; ++tap; enter(); }
+                    vcur = tvalid;
+                    fetch(anext);
+                }
+                if (LD == LD_SEG || LD == LD_3X3) {           // BN + ReLU in registers
+                    const int cc = (LD == LD_3X3) ? (ch % nck) : ch;
+                    const float* scp = sc + cc * 32 + 4 * hi;
+                    const float* shp = sh + cc * 32 + 4 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(scp + q * 8);
+                        const float4 h4 = *reinterpret_cast<const float4*>(shp + q * 8);
+                        acur[q].x = fmaxf(fmaf(acur[q].x, s4.x, h4.x), 0.f);
+                        acur[q].y = fmaxf(fmaf(acur[q].y, s4.y, h4.y), 0.f);
+                        acur[q].z = fmaxf(fmaf(acur[q].z, s4.z, h4.z), 0.f);
+                        acur[q].w = fmaxf(fmaf(acur[q].w, s4.w, h4.w), 0.f);
+                        if (LD == LD_3X3 && !vthis) acur[q] = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding is post-activation
+                    }
+                }
+                mfma_chunk(ch, acur);
+            }
+        } else {
+            // ---- generic path: per-group table look-ups and predicates (odd channel counts, ragged M)
+            float4 anext[4];
+            load_a(0, anext);
+            for (int ch = 0; ch < nchunks; ++ch) {
+                float4 acur[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acur[q] = anext[q];
+                activate(ch, acur);
+                if (ch + 1 < nchunks) load_a(ch + 1, anext);
+                mfma_chunk(ch, acur);
+            }
         }
 
         // ---- epilogue ---------------------------------------------------------------------
         // C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        const int mrow0 = tile * 128 + wave * 32;
+        const int mrow0 = tile * 32;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + nt * 32 + li;
@@ -266,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (mm < p.M && colok) {
                         const float v = acc[nt][r];
-                        p.y[(size_t)mm * p.ldy + col] = v;
+                        if (!(p.dbg & 8)) p.y[(size_t)mm * p.ldy + col] = v;
                         s1 += v;
                         s2 = fmaf(v, v, s2);
                     }
@@ -292,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
                             const int xx = rm - yy * p.W;
                             row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
                         }
-                        const float xv = g.ptr[(size_t)row * g.ld + (col & 3)];
+                        const float xv = ldg1(g.ptr + (size_t)row * g.ld + (col & 3));
                         const float z = fmaf(xv, csc, csh);
                         const float dz = z > 0.f ? acc[nt][r] : 0.f;
                         p.y[(size_t)mm * p.ldy + col] = dz;
@@ -306,69 +363,109 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs p) {
         }
     }
 
-    // ---- per-channel reductions: lanes (l, l+32) -> 4 waves via LDS -> one fp64 atomic per channel
-    if (p.ystats != nullptr) {
+    // ---- per-channel reductions: lanes (l, l+32) -> waves (serialised through LDS) -> one fp64
+    //      atomic per channel per block
+    if (p.ystats != nullptr && !(p.dbg & 1)) {
+        double a[NT], b[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const double a = dsum[nt] + shfl_xor_d(dsum[nt], 32);
-            const double b = dsq[nt] + shfl_xor_d(dsq[nt], 32);
-            if (hi == 0) {
-                redbuf[(wave * NB + nt * 32 + li) * 2 + 0] = a;
-                redbuf[(wave * NB + nt * 32 + li) * 2 + 1] = b;
-            }
+            a[nt] = dsum[nt] + shfl_xor_d(dsum[nt], 32);
+            b[nt] = dsq[nt] + shfl_xor_d(dsq[nt], 32);
         }
-        __syncthreads();
+        for (int w = 0; w < nwaves; ++w) {
+            if (wave == w && hi == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    redbuf[(nt * 32 + li) * 2 + 0] += a[nt];
+                    redbuf[(nt * 32 + li) * 2 + 1] += b[nt];
+                }
+            }
+            __syncthreads();
+        }
         if (tid < NB) {
             const int col = n0 + tid;
             if (col < p.Nout) {
-                double a = 0.0, b = 0.0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    a += redbuf[(w * NB + tid) * 2 + 0];
-                    b += redbuf[(w * NB + tid) * 2 + 1];
-                }
-                atomic_add_f64(p.ystats + col, a);
-                atomic_add_f64(p.ystats + p.Nout + col, b);
+                atomic_add_f64(p.ystats + col, redbuf[tid * 2 + 0]);
+                atomic_add_f64(p.ystats + p.Nout + col, redbuf[tid * 2 + 1]);
             }
         }
     }
 }
 
-size_t conv_smem_bytes(int NT, int Ccat) {
-    size_t b = (size_t)2 * 8 * NT * 32 * 16;           // Bs
-    b += (size_t)(Ccat / 4) * sizeof(GrpEnt);          // group table
-    b += (size_t)(Ccat + (Ccat & 1)) * 4 * 4;          // sc, sh, mu, is (padded to keep 8-B alignment)
-    b += 16;
-    b += (size_t)4 * NT * 32 * 2 * 8;                  // reduction scratch
+static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
+    size_t b = (size_t)taps * (Kpad / 4) * NT * 32 * 16;   // resident B operand
+    b += (size_t)(Ccat / 4) * sizeof(GrpEnt);              // group table
+    b += (size_t)Ccat * 4 * 4;                             // sc, sh, mu, is
+    b += (size_t)NT * 32 * 2 * 8;                          // reduction scratch
     return b;
 }
 
-template <int LD, int EP>
-static hipError_t launch_nt(const ConvArgs& a, int NT, dim3 grid, size_t smem, hipStream_t s) {
-    switch (NT) {
-        case 1: hipLaunchKernelGGL((conv_kernel<LD, EP, 1>), grid, dim3(256), smem, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_kernel<LD, EP, 2>), grid, dim3(256), smem, s, a); break;
-        default: hipLaunchKernelGGL((conv_kernel<LD, EP, 4>), grid, dim3(256), smem, s, a); break;
+constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
+
+template <int LD, int EP, int NT, bool FAST>
+static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {       // dynamic LDS above 64 KB has to be opted into, once per instantiation
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<LD, EP, NT, FAST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BUDGET);
+        if (e != hipSuccess) return e;
+        attr_done = true;
     }
+    hipLaunchKernelGGL((conv_kernel<LD, EP, NT, FAST>), grid, dim3(threads), smem, s, a);
     return hipGetLastError();
 }
 
-// Host launcher. Chooses the channel tile (NT) so that the grid fills the chip: big-M nodes
-// take all output channels per block, small-M nodes split channels over blockIdx.y.
-hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStream_t s) {
-    const int ntiles = (a.M + 127) / 128;
+template <int LD, int EP>
+static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    if (fast && LD != LD_STEM) {
+        switch (NT) {
+            case 1: return launch_inst<LD, EP, 1, (LD != LD_STEM)>(a, grid, threads, smem, s);
+            case 2: return launch_inst<LD, EP, 2, (LD != LD_STEM)>(a, grid, threads, smem, s);
+            default: return launch_inst<LD, EP, 4, (LD != LD_STEM)>(a, grid, threads, smem, s);
+        }
+    }
+    switch (NT) {
+        case 1: return launch_inst<LD, EP, 1, false>(a, grid, threads, smem, s);
+        case 2: return launch_inst<LD, EP, 2, false>(a, grid, threads, smem, s);
+        default: return launch_inst<LD, EP, 4, false>(a, grid, threads, smem, s);
+    }
+}
+
+// Host launcher.  Picks the channel tile NT (all output channels per block when the node is big
+// and its weights fit the LDS, fewer when there are too few 32-row tiles to fill the chip), the
+// waves per block and the grid.
+hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
+    static const int dbg = getenv("CUNET_CONV_DBG") ? atoi(getenv("CUNET_CONV_DBG")) : 0;
+    ConvArgs a = a_in;
+    a.dbg = dbg;
+    const int ntiles = (a.M + 31) / 32;
     const int ncol32 = (a.Nout + 31) / 32;
+    const long target = 2L * 4 * num_cus;              // wave-tiles wanted: 2 per SIMD
     int NT = ncol32 >= 4 ? 4 : (ncol32 >= 2 ? 2 : 1);
-    while (NT > 1 && (long)ntiles * ((ncol32 + NT - 1) / NT) < 2L * num_cus) NT >>= 1;
+    while (NT > 1 && ((long)ntiles * ((ncol32 + NT - 1) / NT) < target ||
+                      conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET))
+        NT >>= 1;
+    const size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat);
+    if (smem > CONV_LDS_BUDGET) return hipErrorInvalidValue;   // weights of one 32-channel slice exceed the LDS
     const int gy = (ncol32 + NT - 1) / NT;
-    int gx = ntiles;
-    const int cap = 4 * num_cus;                       // persistent: bounds the fp64 atomics per node
-    if (gx * gy > cap) gx = (cap + gy - 1) / gy;
+    const int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
+    const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
+    int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
+    if (waves > CONV_MAX_WAVES / blocks_per_cu) waves = CONV_MAX_WAVES / blocks_per_cu;
+    if (waves < 1) waves = 1;
+    int gx = (ntiles + waves - 1) / waves;
+    if (gx > max_blocks_x) gx = max_blocks_x;
     if (gx < 1) gx = 1;
     const dim3 grid(gx, gy);
-    const size_t smem = conv_smem_bytes(NT, a.Ccat);
+    // fast path: nothing ragged (see the kernel)
+    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !getenv("CUNET_CONV_GENERIC");
+    if (load == LD_SEG) {
+        for (int i = 0; i < a.nseg; ++i) fast = fast && (a.seg[i].C % 32 == 0) && (a.seg[i].ld % 4 == 0);
+    }
+    // never fewer than 4 waves: idle waves still help copying B into LDS and building the BN tables
+    const int threads = (waves < 4 ? 4 : waves) * 64;
 #define CUNET_CASE(L, E) \
-    if (load == L && epi == E) return launch_nt<L, E>(a, NT, grid, smem, s);
+    if (load == L && epi == E) return launch_nt<L, E>(a, NT, fast, grid, threads, smem, s);
     CUNET_CASE(LD_SEG, EP_FWD)
     CUNET_CASE(LD_3X3, EP_FWD)
     CUNET_CASE(LD_STEM, EP_FWD)

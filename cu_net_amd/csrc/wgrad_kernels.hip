@@ -10,6 +10,8 @@
 // A block = 4 waves working on the SAME output tile (one 32-wide n tile x `ctw` 32-wide c tiles,
 // or x 9 taps for 3x3) over interleaved row pairs of its row chunk; partial tiles are summed
 // through LDS and committed with one fp32 atomic per element per block.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cunet {
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     // ---- job decode: blockIdx.y -> (n tile, c tile group)
     const int nct = (p.Ccat + 31) >> 5;              // c tiles in total
-    const int ctw = (LD == WG_3X3) ? 1 : p.ctw;
+    const int ctw = (LD == WG_3X3) ? 1 : (p.ctw < 0 ? -p.ctw : p.ctw);
     const int ngroups = (nct + ctw - 1) / ctw;
     const int ntile = blockIdx.y / ngroups;
     const int cgrp = blockIdx.y - ntile * ngroups;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const int m = base + 2 * u + hi;
             const bool mok = m < row_end;
             const int mc = mok ? m : row_begin;
-            av[u] = (mok && nok) ? p.dy[(size_t)mc * p.lddy + n0 + li] : 0.f;
+            av[u] = (mok && nok) ? ldg1(p.dy + (size_t)mc * p.lddy + n0 + li) : 0.f;
             int nimg = 0, py = 0, px = 0;
             if (LD != WG_SEG || true) {
                 nimg = mc / HW;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 float v = 0.f;
                 if (LD == WG_SEG) {
                     if (cok[a] && mok) {
-                        const float xv = xptr[a][(size_t)(xups[a] ? rowU : mc) * xld[a]];
+                        const float xv = ldg1(xptr[a] + (size_t)(xups[a] ? rowU : mc) * xld[a]);
                         v = fmaxf(fmaf(xv, xsc[a], xsh[a]), 0.f);
                     }
                 } else if (LD == WG_3X3) {
@@ -118,14 +120,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                     const int yy = py + dy, xx = px + dx;
                     const bool ok = cok[0] && mok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
                     if (ok) {
-                        const float xv = xptr[0][(size_t)(mc + dy * p.W + dx) * xld[0]];
+                        const float xv = ldg1(xptr[0] + (size_t)(mc + dy * p.W + dx) * xld[0]);
                         v = fmaxf(fmaf(xv, xsc[0], xsh[0]), 0.f);
                     }
                 } else {  // WG_STEM
                     const int ci = skoff[a] >> 16, ky = (skoff[a] >> 8) & 255, kx = skoff[a] & 255;
                     const int iy = 2 * py - 3 + ky, ix = 2 * px - 3 + kx;
                     const bool ok = cok[a] && mok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                    if (ok) v = p.img[((size_t)(nimg * 3 + ci) * p.IH + iy) * p.IW + ix];
+                    if (ok) v = ldg1(p.img + ((size_t)(nimg * 3 + ci) * p.IH + iy) * p.IW + ix);
                 }
                 bv[u][a] = v;
             }
@@ -137,29 +139,270 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][a], acc[a], 0, 0, 0);
     }
 
-    // ---- block reduction through LDS (one accumulator at a time: 16 KB), then one atomic per element
+    // ---- block reduction through LDS, then one atomic per element, issued in MEMORY order so that a
+    // wave's 64 atomics hit consecutive addresses (for 3x3 the torch layout [n][c][tap] interleaves the
+    // nine accumulators: committing per accumulator was a stride-9 scatter and cost half the kernel).
+    float* sum = red + 4 * 1024;                     // [NACC][1024] reduced tiles (3x3 only)
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[a][r];
         __syncthreads();
         for (int e = tid; e < 1024; e += 256) {
-            const int r = e >> 6, l = e & 63;
             const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);   // MFMA C row -> output channel
-            const int cc = l & 31;                                         // MFMA C col -> input channel
-            int c, tap;
-            if (LD == WG_3X3) { c = c0 + cc; tap = a; } else { c = c0 + a * 32 + cc; tap = 0; }
-            if (n < p.Cout && c < p.Ccat)
-                atomicAdd(p.dw + ((size_t)n * p.Ccat + c) * p.taps + tap, v);
+            if (LD == WG_3X3) {
+                sum[a * 1024 + e] = v;
+            } else {
+                const int r = e >> 6, l = e & 63;
+                const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);   // MFMA C row -> output channel
+                const int c = c0 + a * 32 + (l & 31);                        // MFMA C col -> input channel
+                if (n < p.Cout && c < p.Ccat && p.ctw >= 0) atomicAdd(p.dw + (size_t)n * p.Ccat + c, v);
+            }
         }
         __syncthreads();
     }
+    if (LD == WG_3X3 && p.ctw >= 0) {
+        // tile = 32 output channels x (32 input channels x 9 taps): per n, 288 consecutive floats
+        for (int idx = tid; idx < 32 * 288; idx += 256) {
+            const int nn = idx / 288;
+            const int rem = idx - nn * 288;
+            const int cc = rem / 9;
+            const int tap = rem - cc * 9;
+            // element (row nn, col cc) of accumulator `tap`: r*64 + l with row = (r&3)+8*(r>>2)+4*(l>>5), col = l&31
+            const int hi2 = (nn >> 2) & 1;
+            const int r = (nn & 3) | ((nn >> 3) << 2);
+            const float v = sum[tap * 1024 + r * 64 + hi2 * 32 + cc];
+            const int n = n0 + nn, c = c0 + cc;
+            if (n < p.Cout && c < p.Ccat) atomicAdd(p.dw + ((size_t)n * p.Ccat + c) * 9 + tap, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 weight gradient, second generation.  One wave owns ALL output-channel tiles (NTW <= 4) x CT
+// input-channel tiles and feeds them from two vector loads per pixel pair:
+//     dY[m][4i..4i+3]        -> A fragments of the 4 n tiles   (n tile t = channels {4i+t})
+//     X [m][c0+CT*j..+CT-1]  -> B fragments of the CT c tiles  (c tile t = channels {c0+CT*j+t})
+// (an MFMA tile may own any 32 channels as long as A, B and the final scatter agree), so X is read
+// once per group instead of once per n tile and a 4x4 wave issues 2 loads per 16 MFMAs.  Loads run
+// PD pixel pairs ahead in registers; one wave per SIMD keeps the f32 matrix pipe busy on its own.
+// blockIdx.y = channel group; groups of different width (CT = 4, 2, 1) cover Cin without padding.
+constexpr int WG2_PD = 4;
+
+struct Wg2Group { int c0; int ct; int chunk0; int nchunks; };   // per channel group
+struct Wg2Args {
+    WgradArgs w;
+    int ngroups;
+    Wg2Group grp[8];
+    int rows_per_chunk[8];
+};
+
+template <int NTW, int CT>
+__device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int chunk, int rpc, float* lds) {
+    const WgradArgs& p = q.w;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int HW = p.H * p.W;
+
+    // ---- per-lane constants of the B operand: channels cb .. cb+CT-1 (all inside one segment)
+    const int cb = g.c0 + CT * li;
+    const bool cok = cb < p.Ccat;
+    const float* xptr = nullptr;
+    int xld = 0, xups = 0;
+    float xsc[CT], xsh[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) { xsc[t] = 0.f; xsh[t] = 0.f; }
+    if (cok) {
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cb >= p.seg[t].choff) s = t;
+        const Seg sg = p.seg[s];
+        const int lc = cb - sg.choff;
+        xptr = sg.x + lc;
+        xld = sg.ld;
+        xups = sg.ups;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const double sum = sg.stats[lc + t], sq = sg.stats[sg.C + lc + t];
+            const double mean = sum / sg.count;
+            double var = sq / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+            const double scale = (double)p.gamma[cb + t] * istd;
+            xsc[t] = (float)scale;
+            xsh[t] = (float)((double)p.beta[cb + t] - mean * scale);
+        }
+    }
+    const bool nok = NTW * li < p.lddy;      // pad columns of dY are zero by construction
+
+    f32x16 acc[NTW][CT];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int row_begin = chunk * rpc;
+    int row_end = row_begin + rpc;
+    if (row_end > p.M) row_end = p.M;
+
+    float av[WG2_PD][NTW], xv[WG2_PD][CT];
+    auto issue = [&](int m0, float (&a)[NTW], float (&x)[CT]) {     // loads of pixel pair (m0, m0+1)
+        const int m = m0 + hi;
+        const bool mok = m < row_end;
+        const int mc = mok ? m : row_begin;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) a[t] = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) x[t] = 0.f;
+        if (mok && nok) {
+            const float* src = p.dy + (size_t)mc * p.lddy + NTW * li;
+            if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+            else {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) a[t] = ldg1(src + t);
+            }
+        }
+        if (mok && cok) {
+            int row = mc;
+            if (xups) {
+                const int nimg = mc / HW;
+                const int rem = mc - nimg * HW;
+                const int py = rem / p.W;
+                const int px = rem - py * p.W;
+                row = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+            }
+            const float* src = xptr + (size_t)row * xld;
+            if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+            else {
+#pragma unroll
+                for (int t = 0; t < CT; ++t) x[t] = ldg1(src + t);
+            }
+            // BN + ReLU; rows outside the chunk stay exactly 0 (they were never loaded)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) x[t] = fmaxf(fmaf(x[t], xsc[t], xsh[t]), 0.f);
+        }
+    };
+
+    // each wave takes pixel pairs  row_begin + 2*(wave + 4*k)
+    const int stride = 8;
+    int m0 = row_begin + 2 * wave;
+#pragma unroll
+    for (int u = 0; u < WG2_PD; ++u) issue(m0 + u * stride, av[u], xv[u]);
+    for (; m0 < row_end; m0 += WG2_PD * stride) {
+#pragma unroll
+        for (int u = 0; u < WG2_PD; ++u) {
+            float a[NTW], x[CT];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) a[t] = av[u][t];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) x[t] = xv[u][t];
+            issue(m0 + (u + WG2_PD) * stride, av[u], xv[u]);        // refill this slot PD pairs ahead
+#pragma unroll
+            for (int ta = 0; ta < NTW; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < CT; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], x[tb], acc[ta][tb], 0, 0, 0);
+        }
+    }
+
+    // ---- reduce the 4 waves through LDS, then commit in memory order (coalesced atomics)
+    float* red = lds;                    // [4][1024]
+    float* sum = lds + 4 * 1024;         // [NTW*CT][1024]
+#pragma unroll
+    for (int ta = 0; ta < NTW; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < CT; ++tb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[ta][tb][r];
+            __syncthreads();
+            for (int e = tid; e < 1024; e += 256)
+                sum[(ta * CT + tb) * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+            __syncthreads();
+        }
+    if (p.ctw < 0) return;               // timing experiments: skip the commit
+    const int width = 32 * CT;
+    for (int idx = tid; idx < NTW * 32 * width; idx += 256) {
+        const int n = idx / width;
+        const int cc = idx - n * width;
+        const int ta = n % NTW, i = n / NTW;          // n = NTW*i + ta
+        const int tb = cc % CT, j = cc / CT;          // c = c0 + CT*j + tb
+        const int r = (i & 3) | ((i >> 3) << 2);
+        const int e = r * 64 + ((i >> 2) & 1) * 32 + j;
+        const int c = g.c0 + cc;
+        if (n < p.Cout && c < p.Ccat) atomicAdd(p.dw + (size_t)n * p.Ccat + c, sum[(ta * CT + tb) * 1024 + e]);
+    }
+}
+
+template <int NTW>
+__global__ __launch_bounds__(256, 1) void wgrad2_kernel(const Wg2Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    // blockIdx.x enumerates (group, chunk) pairs: group g owns chunks [chunk0, chunk0 + nchunks)
+    int gi = 0;
+    for (int t = 1; t < q.ngroups; ++t)
+        if ((int)blockIdx.x >= q.grp[t].chunk0) gi = t;
+    const Wg2Group g = q.grp[gi];
+    const int chunk = blockIdx.x - g.chunk0;
+    const int rpc = q.rows_per_chunk[gi];
+    if (g.ct == 4) wg2_body<NTW, 4>(q, g, chunk, rpc, lds);
+    else if (g.ct == 2) wg2_body<NTW, 2>(q, g, chunk, rpc, lds);
+    else wg2_body<NTW, 1>(q, g, chunk, rpc, lds);
+}
+
+static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) {
+    Wg2Args q{};
+    q.w = a;
+    static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;
+    q.w.ctw = nocommit ? -1 : 1;
+    // channel groups: as many CT=4 (128-channel) groups as fit, then one CT=2 and/or CT=1 remainder
+    int c = 0, ng = 0, weight = 0;
+    const int C32 = (a.Ccat + 31) / 32;          // 32-channel tiles
+    int left = C32;
+    while (left > 0 && ng < 8) {
+        const int ct = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+        q.grp[ng].c0 = c; q.grp[ng].ct = ct;
+        c += 32 * ct; left -= ct; weight += ct; ++ng;
+    }
+    if (left > 0) return hipErrorInvalidValue;
+    q.ngroups = ng;
+    // blocks: ~1 per CU in total, split over the groups in proportion to their MFMA work
+    const int total = num_cus;
+    int chunk0 = 0;
+    for (int g = 0; g < ng; ++g) {
+        int nch = (total * q.grp[g].ct + weight - 1) / weight;
+        int rpc = (a.M + nch - 1) / nch;
+        rpc = (rpc + 7) / 8 * 8;                 // whole 4-wave sweeps of pixel pairs
+        nch = (a.M + rpc - 1) / rpc;
+        q.grp[g].chunk0 = chunk0; q.grp[g].nchunks = nch;
+        q.rows_per_chunk[g] = rpc;
+        chunk0 += nch;
+    }
+    const int ntw = a.lddy > 64 ? 4 : (a.lddy > 32 ? 2 : 1);
+    const size_t smem = (size_t)(4 + ntw * 4) * 1024 * 4;
+    const dim3 grid(chunk0);
+    auto set_attr = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); };
+    static bool done = false;
+    if (!done) {
+        hipError_t e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1>));
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    if (ntw == 4) hipLaunchKernelGGL(wgrad2_kernel<4>, grid, dim3(256), smem, s, q);
+    else if (ntw == 2) hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(256), smem, s, q);
+    else hipLaunchKernelGGL(wgrad2_kernel<1>, grid, dim3(256), smem, s, q);
+    return hipGetLastError();
 }
 
 template <int LD>
 static hipError_t launch_acc(const WgradArgs& a, int nacc, dim3 grid, hipStream_t s) {
-    const size_t smem = (size_t)4 * 1024 * 4;
+    const size_t smem = (size_t)4 * 1024 * 4 + (LD == WG_3X3 ? (size_t)9 * 1024 * 4 : 0);
 #define CUNET_WG(N) case N: hipLaunchKernelGGL((wgrad_kernel<LD, N>), grid, dim3(256), smem, s, a); break;
     switch (nacc) {
         CUNET_WG(1) CUNET_WG(2) CUNET_WG(3) CUNET_WG(4) CUNET_WG(5) CUNET_WG(9)
@@ -170,6 +413,7 @@ static hipError_t launch_acc(const WgradArgs& a, int nacc, dim3 grid, hipStream_
 }
 
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
+    if (load == WG_SEG && a.Cout <= 128 && a.lddy % 4 == 0 && !getenv("CUNET_WG_OLD")) return launch_wgrad2(a, num_cus, s);
     const int nct = (a.Ccat + 31) / 32;
     const int ntiles = (a.Cout + 31) / 32;
     int nacc, jobs;
@@ -183,7 +427,10 @@ hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
     }
     // row chunks: enough blocks to fill the chip, each chunk a multiple of 8*UNROLL rows
     const int quantum = 8 * WG_UNROLL;
-    int chunks = (2 * num_cus + jobs - 1) / jobs;
+    static const int mult = getenv("CUNET_WG_CHUNK_MULT") ? atoi(getenv("CUNET_WG_CHUNK_MULT")) : 2;   // tuning knob
+    static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;                                   // timing experiments only
+    if (nocommit) a.ctw = -a.ctw;
+    int chunks = (mult * num_cus + jobs - 1) / jobs;
     if (chunks < 1) chunks = 1;
     int rpb = (a.M + chunks - 1) / chunks;
     rpb = (rpb + quantum - 1) / quantum * quantum;
