@@ -193,8 +193,8 @@ struct Wg2Group { int c0; int ct; int chunk0; int nchunks; };   // per channel g
 struct Wg2Args {
     WgradArgs w;
     int ngroups;
-    Wg2Group grp[8];
-    int rows_per_chunk[8];
+    Wg2Group grp[12];
+    int rows_per_chunk[12];
 };
 
 template <int NTW, int CT>
@@ -251,57 +251,57 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
     if (row_end > p.M) row_end = p.M;
 
     float av[WG2_PD][NTW], xv[WG2_PD][CT];
-    auto issue = [&](int m0, float (&a)[NTW], float (&x)[CT]) {     // loads of pixel pair (m0, m0+1)
+    bool xok[WG2_PD];
+    // Branch-free: every lane always loads from a valid (clamped) address and validity is applied when
+    // the value is consumed -- a branch around a load makes hipcc wait vmcnt(0) at the join.
+    const float* xbase = cok ? xptr : p.dy;
+    const int xldc = cok ? xld : 0;
+    const int acol = nok ? NTW * li : 0;
+    auto issue = [&](int m0, float (&a)[NTW], float (&x)[CT], bool& ok) {     // RAW loads of pixel pair (m0, m0+1)
         const int m = m0 + hi;
         const bool mok = m < row_end;
         const int mc = mok ? m : row_begin;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) a[t] = 0.f;
-#pragma unroll
-        for (int t = 0; t < CT; ++t) x[t] = 0.f;
-        if (mok && nok) {
-            const float* src = p.dy + (size_t)mc * p.lddy + NTW * li;
+        {
+            const float* src = p.dy + (size_t)mc * p.lddy + acol;
             if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
             else {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) a[t] = ldg1(src + t);
             }
         }
-        if (mok && cok) {
-            int row = mc;
-            if (xups) {
-                const int nimg = mc / HW;
-                const int rem = mc - nimg * HW;
-                const int py = rem / p.W;
-                const int px = rem - py * p.W;
-                row = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
-            }
-            const float* src = xptr + (size_t)row * xld;
+        {
+            const int nimg = mc / HW;
+            const int rem = mc - nimg * HW;
+            const int py = rem / p.W;
+            const int px = rem - py * p.W;
+            const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+            const float* src = xbase + (size_t)(xups ? rowU : mc) * xldc;
             if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
             else {
 #pragma unroll
                 for (int t = 0; t < CT; ++t) x[t] = ldg1(src + t);
             }
-            // BN + ReLU; rows outside the chunk stay exactly 0 (they were never loaded)
-#pragma unroll
-            for (int t = 0; t < CT; ++t) x[t] = fmaxf(fmaf(x[t], xsc[t], xsh[t]), 0.f);
         }
+        ok = mok;
     };
 
-    // each wave takes pixel pairs  row_begin + 2*(wave + 4*k)
+    // each wave takes pixel pairs  row_begin + 2*(wave + 4*k); a slot is refilled right after it
+    // has been consumed, WG2_PD pairs ahead.  hipcc drains vmcnt(0) at the loop back-edge, so part of
+    // the latency is hidden by the second wave on the SIMD (two blocks per CU) rather than by depth.
     const int stride = 8;
     int m0 = row_begin + 2 * wave;
 #pragma unroll
-    for (int u = 0; u < WG2_PD; ++u) issue(m0 + u * stride, av[u], xv[u]);
+    for (int u = 0; u < WG2_PD; ++u) issue(m0 + u * stride, av[u], xv[u], xok[u]);
     for (; m0 < row_end; m0 += WG2_PD * stride) {
 #pragma unroll
         for (int u = 0; u < WG2_PD; ++u) {
             float a[NTW], x[CT];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) a[t] = av[u][t];
+            for (int t = 0; t < NTW; ++t) a[t] = (xok[u] && nok) ? av[u][t] : 0.f;
+            // BN + ReLU at consumption time (rows outside the chunk contribute exactly 0)
 #pragma unroll
-            for (int t = 0; t < CT; ++t) x[t] = xv[u][t];
-            issue(m0 + (u + WG2_PD) * stride, av[u], xv[u]);        // refill this slot PD pairs ahead
+            for (int t = 0; t < CT; ++t) x[t] = (xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f;
+            issue(m0 + (u + WG2_PD) * stride, av[u], xv[u], xok[u]);        // refill this slot PD pairs ahead
 #pragma unroll
             for (int ta = 0; ta < NTW; ++ta)
 #pragma unroll
@@ -339,7 +339,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
 }
 
 template <int NTW>
-__global__ __launch_bounds__(256, 1) void wgrad2_kernel(const Wg2Args q) {
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
     // blockIdx.x enumerates (group, chunk) pairs: group g owns chunks [chunk0, chunk0 + nchunks)
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void wgrad2_kernel(const Wg2Args q) {
     const Wg2Group g = q.grp[gi];
     const int chunk = blockIdx.x - g.chunk0;
     const int rpc = q.rows_per_chunk[gi];
-    if (g.ct == 4) wg2_body<NTW, 4>(q, g, chunk, rpc, lds);
+    if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2)>(q, g, chunk, rpc, lds);
     else if (g.ct == 2) wg2_body<NTW, 2>(q, g, chunk, rpc, lds);
     else wg2_body<NTW, 1>(q, g, chunk, rpc, lds);
 }
@@ -362,16 +362,18 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     // channel groups: as many CT=4 (128-channel) groups as fit, then one CT=2 and/or CT=1 remainder
     int c = 0, ng = 0, weight = 0;
     const int C32 = (a.Ccat + 31) / 32;          // 32-channel tiles
+    const int ntw = a.lddy > 64 ? 4 : (a.lddy > 32 ? 2 : 1);
+    const int ctmax = ntw == 4 ? 2 : 4;          // <= 8 accumulators: two waves per SIMD
     int left = C32;
-    while (left > 0 && ng < 8) {
-        const int ct = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    while (left > 0 && ng < 12) {
+        const int ct = (left >= 4 && ctmax >= 4) ? 4 : (left >= 2 ? 2 : 1);
         q.grp[ng].c0 = c; q.grp[ng].ct = ct;
         c += 32 * ct; left -= ct; weight += ct; ++ng;
     }
     if (left > 0) return hipErrorInvalidValue;
     q.ngroups = ng;
     // blocks: ~1 per CU in total, split over the groups in proportion to their MFMA work
-    const int total = num_cus;
+    const int total = 2 * num_cus;
     int chunk0 = 0;
     for (int g = 0; g < ng; ++g) {
         int nch = (total * q.grp[g].ct + weight - 1) / weight;
@@ -382,7 +384,6 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
         q.rows_per_chunk[g] = rpc;
         chunk0 += nch;
     }
-    const int ntw = a.lddy > 64 ? 4 : (a.lddy > 32 ? 2 : 1);
     const size_t smem = (size_t)(4 + ntw * 4) * 1024 * 4;
     const dim3 grid(chunk0);
     auto set_attr = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); };
