@@ -62,6 +62,7 @@ def lib():
         'cunet_backward': (i32, [vp, C.POINTER(vp), vp]),
         'cunet_num_buckets': (i32, [vp]),
         'cunet_bucket_range': (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+        'cunet_bucket_order': (i32, [vp, C.POINTER(C.c_int32), i32]),
         'cunet_backward_ex': (i32, [vp, C.POINTER(vp), vp, BUCKET_CB, vp]),
         'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
@@ -86,7 +87,7 @@ def lib():
 EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_plan_destroy', 'cunet_state_count',
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind',
-            'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_num_buckets',
+            'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_bucket_order', 'cunet_num_buckets',
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds',
             'cunet_debug_tensor_offset', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
             'cunet_profile_num_classes', 'cunet_profile_class_name', 'cunet_profile_get']
@@ -190,6 +191,11 @@ class PlanHandle:
             if L.cunet_profile_class_name(i).decode() == name:
                 return i
         raise KeyError(name)
+
+    def bucket_order(self):
+        buf = (C.c_int32 * 256)()
+        n = check(lib().cunet_bucket_order(self.h, buf, 256), 'cunet_bucket_order')
+        return [int(buf[i]) for i in range(n)]
 
     def describe(self):
         if self._desc is None:

@@ -417,6 +417,17 @@ int cunet_bucket_range(const cunet_plan_t* p, int bucket, int64_t* begin, int64_
     return CUNET_OK;
 }
 
+int cunet_bucket_order(const cunet_plan_t* p, int32_t* order, int capacity) {
+    if (!p || !order) return fail(CUNET_ERR_INVALID, "null argument");
+    const Plan& P = p->plan;
+    int n = 0, cur = P.nodes.empty() ? -1 : P.nodes.back().bucket;
+    for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
+        if (P.nodes[k].bucket != cur) { if (n < capacity) order[n] = cur; ++n; cur = P.nodes[k].bucket; }
+    }
+    if (cur >= 0) { if (n < capacity) order[n] = cur; ++n; }
+    return n;
+}
+
 int cunet_backward(cunet_plan_t* h, const float* const* grad_heat, void* stream) {
     return cunet_backward_ex(h, grad_heat, stream, nullptr, nullptr);
 }

@@ -29,38 +29,15 @@ class FusedTrainer:
         self.pg = process_group
         self.world = 1
         self.overlap = overlap
-        self._comm_stream = None
-        if process_group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
+        from .parallel import BucketAllReducer
+        self.reducer = BucketAllReducer(net._buckets, process_group, overlap)
+        self.world = self.reducer.world
 
     # ---- data parallel plumbing (cu-net.py:59 DataParallel -> one process per GPU + RCCL) --------
     def broadcast_parameters(self, src: int = 0):
         """One-time replacement of DataParallel's per-iteration replicate."""
-        if self.pg is None:
-            return
-        import torch.distributed as dist
-        dist.broadcast(self.net._param_arena, src, group=self.pg)
-        dist.broadcast(self.net._buffer_arena, src, group=self.pg)
-        dist.broadcast(self.net._counter_arena, src, group=self.pg)
-
-    def _allreduce_bucket(self, b: int):
-        import torch.distributed as dist
-        begin, count = self.net._buckets[b]
-        if count == 0:
-            return
-        g = self.net._grad_arena[begin:begin + count]
-        dev = g.device
-        if self.overlap and dev.type == 'cuda':
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=dev)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))       # everything writing bucket b is enqueued
-            self._comm_stream.wait_event(ev)
-            with torch.cuda.stream(self._comm_stream):
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+        from .parallel import broadcast_state
+        broadcast_state([self.net._param_arena, self.net._buffer_arena, self.net._counter_arena], src, self.pg)
 
     def step(self, img: torch.Tensor, heatmap: torch.Tensor) -> torch.Tensor:
         """One optimisation step; returns the loss as a 0-dim device tensor (no host sync)."""
@@ -81,9 +58,9 @@ class FusedTrainer:
         if self.pg is None:
             plan.backward(None)
         else:
-            plan.backward(None, on_bucket=self._allreduce_bucket)
-            if self._comm_stream is not None:
-                torch.cuda.current_stream(img.device).wait_stream(self._comm_stream)
+            self.reducer.begin_step()
+            plan.backward(None, on_bucket=lambda b: self.reducer.reduce_bucket(net._grad_arena, b))
+            self.reducer.finish(net._grad_arena)
         if self.square_avg is None or self.square_avg.device != net._param_arena.device:
             self.square_avg = torch.zeros_like(net._param_arena)
         check(lib().cunet_rmsprop_step(_ptr(net._param_arena), _ptr(net._grad_arena), _ptr(self.square_avg),

@@ -113,6 +113,8 @@ int cunet_num_buckets(const cunet_plan_t* plan);
 int cunet_bucket_range(const cunet_plan_t* plan, int bucket, int64_t* begin, int64_t* count);
 int cunet_backward_ex(cunet_plan_t* plan, const float* const* grad_heat, void* stream,
                       cunet_bucket_cb on_bucket, void* user);
+/* the order in which cunet_backward_ex reports buckets (host only; returns the count) */
+int cunet_bucket_order(const cunet_plan_t* plan, int32_t* order, int capacity);
 
 /* fused RMSprop over a flat arena: torch.optim.RMSprop(lr, alpha, eps, momentum=0, weight_decay=0)
  * (cu-net.py:60-61,183). g is multiplied by grad_scale first (1/world_size under data parallelism). */

@@ -1,0 +1,109 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing (bucket layout from the C plan, per-bucket
+all-reduce in backward's completion order, one-time state broadcast, 1/world scaling, batch sharding).
+The kernels themselves need a GPU; here the per-rank gradients come from the CPU oracle."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cu_net_amd._lib import PlanHandle
+from cu_net_amd.parallel import BucketAllReducer, broadcast_state, shard_batch
+
+CFG = dict(neck_size=2, growth_rate=4, init_chan_num=8, class_num=3, layer_num=3, order=1, loss_num=3)
+
+
+def _layout():
+    plan = PlanHandle(**CFG, batch=2, height=64, width=64)
+    return plan, plan.state_entries(), plan.buckets(), plan.param_numel, plan.bucket_order()
+
+
+def test_bucket_layout_is_bucket_major():
+    plan, ents, buckets, numel, order = _layout()
+    L = CFG['layer_num']
+    assert len(buckets) == L + 1
+    red = BucketAllReducer(buckets)
+    assert red.covers(numel)
+    # every parameter lies inside exactly the bucket its U-Net index says
+    for name, kind, shape, off, n in ents:
+        if kind != 0:
+            continue
+        if name.startswith('features.'):
+            b = L
+        elif name.startswith('intermedia.adapters.'):
+            b = int(name.split('.')[2]) + 1
+        elif name.startswith('linears.'):
+            b = int(name.split('.')[1])
+        else:
+            parts = name.split('.')
+            b = int(parts[parts.index('layers') + 1] if 'layers' in parts else
+                    parts[[i for i, p in enumerate(parts) if p.startswith('adapters_')][0] + 1])
+        begin, count = buckets[b]
+        assert begin <= off and off + n <= begin + count, (name, b)
+    # backward finishes the last U-Net first and the stem last
+    assert order == list(range(L - 1, -1, -1)) + [L]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        plan, ents, buckets, numel, order = _layout()
+        pg = dist.group.WORLD
+        # one-time broadcast: rank 1 starts from different parameters and must end up with rank 0's
+        torch.manual_seed(100 + rank)
+        params = torch.randn(numel)
+        bufs = torch.randn(64)
+        broadcast_state([params, bufs], 0, pg)
+        torch.manual_seed(100)
+        assert torch.equal(params, torch.randn(numel))
+        # per-rank gradients, reduced bucket by bucket in backward's completion order
+        torch.manual_seed(7 + rank)
+        grads = torch.randn(numel)
+        mine = grads.clone()
+        red = BucketAllReducer(buckets, pg, overlap=True)
+        red.begin_step()
+        for b in order:
+            red.reduce_bucket(grads, b)
+        red.finish(grads)
+        assert red.reduced == order
+        torch.manual_seed(7 + (1 - rank))
+        other = torch.randn(numel)
+        inside = torch.zeros(numel, dtype=torch.bool)
+        for begin, count in buckets:
+            inside[begin:begin + count] = True
+        assert torch.allclose(grads[inside], (mine + other)[inside])
+        assert torch.equal(grads[~inside], mine[~inside])           # alignment padding is never touched
+        # averaging: what the fused RMSprop sees is grads * (1/world)
+        assert abs(red.world - world) == 0
+        q.put((rank, 'ok'))
+    except Exception as e:   # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bucket_allreduce_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_shard_batch_matches_dataparallel_chunking():
+    # torch.nn.DataParallel scatters with tensor.chunk(n): contiguous, ceil-sized chunks
+    x = torch.arange(192)
+    for world in (1, 2, 4, 8):
+        chunks = x.chunk(world)
+        for r in range(world):
+            lo, hi = shard_batch(192, r, world)
+            assert torch.equal(x[lo:hi], chunks[r])
+    assert shard_batch(10, 3, 4) == (9, 10)

@@ -184,6 +184,23 @@ def full_width(ref):
     print(f'G5: full width L2/K68 N=1 loss={float(loss):.6f}  oracle == reference')
 
 
+def init_parity(ref):
+    """G_init: the reference's own initialisation (models/cu_net.py:322-334) under a fixed torch seed;
+    per-parameter checksums so that cu_net_amd.create_cu_net can be shown to draw the same values."""
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    torch.manual_seed(1234)
+    net = quiet(ref.create_cu_net, **cfg)
+    sd = net.state_dict()
+    names = [k for k, v in sd.items() if v.is_floating_point() and 'running' not in k]
+    sums = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in names])
+    probe = to_np(sd['hg.up_blocks.2.adapters_ahead.1.adapter_conv.weight'])[:4, :8, 0, 0].copy()
+    conv_order = np.array([n for n, m in net.named_modules() if isinstance(m, torch.nn.Conv2d)], dtype='U')
+    np.savez_compressed(os.path.join(OUT, 'G_init_L2K16.npz'), cfg=np.array(list(cfg.values()), dtype=np.int64),
+                        seed=np.array(1234), names=np.array(names, dtype='U'), sums=sums, probe=probe,
+                        conv_order=conv_order)
+    print(f'G_init: {len(names)} parameter tensors, {len(conv_order)} convs')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -199,6 +216,7 @@ def main():
     # a 64x64 input: the neck is 1x1 and BatchNorm there sees N samples only (edge case, forward pins only)
     one_config(ref, 'G6_L2_o1_hw64', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=4, hw=64, seed=16)
     full_width(ref)
+    init_parity(ref)
 
 
 if __name__ == '__main__':
