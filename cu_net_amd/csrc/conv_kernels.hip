@@ -312,6 +312,20 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         // ---- epilogue ---------------------------------------------------------------------
         // C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const int mrow0 = tile * 32;
+        const bool w4 = (p.W & 3) == 0;
+        int rowU4[4] = {0, 0, 0, 0};             // EP_BWD: up-sampled source row of this lane's 4 row groups
+        if (EP == EP_BWD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int m4 = mrow0 + 8 * k + 4 * hi;
+                m4 = m4 < p.M ? m4 : p.M - 1;
+                const int ni = m4 / HW;
+                const int rm = m4 - ni * HW;
+                const int yy = rm / p.W;
+                const int xx = rm - yy * p.W;
+                rowU4[k] = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + nt * 32 + li;
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (mm < p.M && colok) {
+                    if ((FAST || mm < p.M) && colok) {
                         const float v = acc[nt][r];
                         if (!(p.dbg & 8)) p.y[(size_t)mm * p.ldy + col] = v;
                         s1 += v;
@@ -337,22 +351,29 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                     g = grp[col >> 2];
                     csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col];
                 }
+                const float* xcol = g.ptr + (col & 3);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (mm < p.M && colok) {
+                    if ((FAST || mm < p.M) && colok) {
+                        // rows 4k..4k+3 of a tile share an image row (W % 4 == 0): the up-sampled source row
+                        // of row 4k+j is rowU4[k] + (j >> 1)
                         int row = mm;
                         if (g.ups) {
-                            const int ni = mm / HW;
-                            const int rm = mm - ni * HW;
-                            const int yy = rm / p.W;
-                            const int xx = rm - yy * p.W;
-                            row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                            if (w4) {
+                                row = rowU4[r >> 2] + ((r & 3) >> 1);
+                            } else {
+                                const int ni = mm / HW;
+                                const int rm = mm - ni * HW;
+                                const int yy = rm / p.W;
+                                const int xx = rm - yy * p.W;
+                                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                            }
                         }
-                        const float xv = ldg1(g.ptr + (size_t)row * g.ld + (col & 3));
+                        const float xv = (p.dbg & 16) ? 1.f : ldg1(xcol + (size_t)row * g.ld);
                         const float z = fmaf(xv, csc, csh);
                         const float dz = z > 0.f ? acc[nt][r] : 0.f;
-                        p.y[(size_t)mm * p.ldy + col] = dz;
+                        if (!(p.dbg & 8)) p.y[(size_t)mm * p.ldy + col] = dz;
                         s1 += dz;
                         s2 = fmaf(dz, (xv - cmu) * cis, s2);
                     }

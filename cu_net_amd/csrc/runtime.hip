@@ -1,6 +1,7 @@
 // C-ABI entry points (include/cunet.h) and the executor that walks a Plan and enqueues the HIP
 // kernels on the caller's stream.  Owns no device memory.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,6 +33,11 @@ struct cunet_plan {
     int fwd_training_done = 0;
     int loss_done = 0;
     const float* last_x = nullptr;   // image of the last training forward (needed by the stem weight gradient)
+    // internal side stream: weight gradients run concurrently with the data-gradient chain
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_ev;     // one per node: "d(loss)/d(out) of node k is ready"
+    hipEvent_t join_ev = nullptr;
+    int use_side = 1;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     int prof_mode = 0;               // 0 off, 1 every class, 2 only prof_cls
     int prof_cls = -1;
@@ -68,13 +74,14 @@ static hipError_t prof_end(cunet_plan* h, int slot, double flops, double bytes, 
     h->prof_pending[slot].bytes = bytes;
     return hipEventRecord(h->prof_pending[slot].b, s);
 }
-#define PROF(cls, flops, bytes, expr)                      \
+#define PROF_ON(st, cls, flops, bytes, expr)               \
     do {                                                   \
         int slot_;                                         \
-        HIPCHK(prof_begin(h, (cls), s, slot_));            \
+        HIPCHK(prof_begin(h, (cls), (st), slot_));         \
         HIPCHK(expr);                                      \
-        HIPCHK(prof_end(h, slot_, (flops), (bytes), s));   \
+        HIPCHK(prof_end(h, slot_, (flops), (bytes), (st)));\
     } while (0)
+#define PROF(cls, flops, bytes, expr) PROF_ON(s, cls, flops, bytes, expr)
 
 
 static thread_local std::string g_err;
@@ -105,7 +112,13 @@ int cunet_plan_create(const cunet_cfg* cfg, cunet_plan_t** out) {
     return CUNET_OK;
 }
 
-void cunet_plan_destroy(cunet_plan_t* plan) { delete plan; }
+void cunet_plan_destroy(cunet_plan_t* plan) {
+    if (!plan) return;
+    for (auto e : plan->fork_ev) (void)hipEventDestroy(e);
+    if (plan->join_ev) (void)hipEventDestroy(plan->join_ev);
+    if (plan->side) (void)hipStreamDestroy(plan->side);
+    delete plan;
+}
 
 int cunet_state_count(const cunet_plan_t* plan) { return plan ? (int)plan->plan.state.size() : 0; }
 
@@ -202,6 +215,13 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
     HIPCHK(hipMemcpyAsync(h->ws + P.off_repack_tab, h->repack.data(), h->repack.size() * sizeof(RepackEntry), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->ws + P.off_runstat_tab, h->runstat.data(), h->runstat.size() * sizeof(RunStatEntry), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (training && !h->side) {
+        h->use_side = getenv("CUNET_NO_SIDE_STREAM") ? 0 : 1;
+        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        h->fork_ev.resize(P.nodes.size());
+        for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+    }
     h->fwd_training_done = 0; h->loss_done = 0;
     return CUNET_OK;
 }
@@ -244,8 +264,15 @@ struct Exec {
 }  // namespace
 
 // Backward of one node: data gradient (+ReLU mask + BN reductions), weight gradient, BN apply.
-static int bwd_node(cunet_plan* h, const Node& n, int force_first, hipStream_t s) {
+static int bwd_node(cunet_plan* h, const Node& n, int node_index, int force_first, hipStream_t s) {
     Exec E(h);
+    // weight gradients only read d(loss)/d(out) and activations and only write dW: they fork to the side stream
+    hipStream_t ws = s;
+    if (h->use_side && h->side && (n.type == N_CONV || n.type == N_STEM_CONV)) {
+        HIPCHK(hipEventRecord(h->fork_ev[node_index], s));
+        HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[node_index], 0));
+        ws = h->side;
+    }
     Plan& P = h->plan;
     const int cus = h->num_cus;
     E.force_first = force_first;
@@ -275,8 +302,8 @@ static int bwd_node(cunet_plan* h, const Node& n, int force_first, hipStream_t s
             w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
             w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
             w.dw = h->grads + c.w;
-            PROF(c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
-                 launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, s));
+            PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
+                    launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));
         }
         {   // BN backward apply into the segments' gradient buffers
             BnApplyArgs a{};
@@ -314,7 +341,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int force_first, hipStream_t s
         w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
         w.dw = h->grads + c.w;
         w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
-        PROF(PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout, launch_wgrad(w, WGL_STEM, cus, s));
+        PROF_ON(ws, PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout, launch_wgrad(w, WGL_STEM, cus, ws));
     }
     return CUNET_OK;
 }
@@ -457,11 +484,21 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
-            if (on_bucket) on_bucket(cur_bucket, user);
+            if (on_bucket) {
+                if (h->use_side && h->side) {      // ... including the weight gradients on the side stream
+                    HIPCHK(hipEventRecord(h->join_ev, h->side));
+                    HIPCHK(hipStreamWaitEvent(s, h->join_ev, 0));
+                }
+                on_bucket(cur_bucket, user);
+            }
             cur_bucket = n.bucket;
         }
-        const int rc = bwd_node(h, n, 0, s);
+        const int rc = bwd_node(h, n, k, 0, s);
         if (rc != CUNET_OK) return rc;
+    }
+    if (h->use_side && h->side) {
+        HIPCHK(hipEventRecord(h->join_ev, h->side));
+        HIPCHK(hipStreamWaitEvent(s, h->join_ev, 0));
     }
     if (on_bucket && cur_bucket >= 0) on_bucket(cur_bucket, user);
     // the reference re-runs every checkpointed cat->BN->ReLU->conv during backward, which updates
@@ -496,7 +533,13 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (n.red >= 0)
         HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * n.red, 0, (size_t)16 * n.Ccat, s));
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
-    return bwd_node(h, n, 1, s);
+    const int rc = bwd_node(h, n, node, 1, s);
+    if (rc != CUNET_OK) return rc;
+    if (h->use_side && h->side) {
+        HIPCHK(hipEventRecord(h->join_ev, h->side));
+        HIPCHK(hipStreamWaitEvent(s, h->join_ev, 0));
+    }
+    return CUNET_OK;
 }
 
 int cunet_profile_begin(cunet_plan_t* h, int mode, int cls) {

@@ -292,16 +292,18 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
     int m0 = row_begin + 2 * wave;
 #pragma unroll
     for (int u = 0; u < WG2_PD; ++u) issue(m0 + u * stride, av[u], xv[u], xok[u]);
-    for (; m0 < row_end; m0 += WG2_PD * stride) {
+    constexpr int WG2_UNROLL = 1;
+    for (; m0 < row_end; m0 += WG2_UNROLL * WG2_PD * stride) {
 #pragma unroll
-        for (int u = 0; u < WG2_PD; ++u) {
+        for (int uu = 0; uu < WG2_UNROLL * WG2_PD; ++uu) {
+            const int u = uu % WG2_PD;
             float a[NTW], x[CT];
 #pragma unroll
             for (int t = 0; t < NTW; ++t) a[t] = (xok[u] && nok) ? av[u][t] : 0.f;
             // BN + ReLU at consumption time (rows outside the chunk contribute exactly 0)
 #pragma unroll
             for (int t = 0; t < CT; ++t) x[t] = (xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f;
-            issue(m0 + (u + WG2_PD) * stride, av[u], xv[u], xok[u]);        // refill this slot PD pairs ahead
+            issue(m0 + (uu + WG2_PD) * stride, av[u], xv[u], xok[u]);       // refill this slot PD pairs ahead
 #pragma unroll
             for (int ta = 0; ta < NTW; ++ta)
 #pragma unroll
