@@ -326,6 +326,33 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                 rowU4[k] = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
             }
         }
+        float xq[2][16];
+        auto bwd_fetch = [&](int nt, float (&xo)[16]) {      // X[row][col] of this lane's 16 rows, channel tile nt
+            const int col = n0 + nt * 32 + li;
+            const bool colok = col < p.Nout;
+            GrpEnt g;
+            g.ptr = p.a; g.ld = 0; g.ups = 0;                 // always a valid address: loads stay branch-free
+            if (colok) g = grp[col >> 2];
+            const float* xcol = g.ptr + (colok ? (col & 3) : 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                mm = (FAST || mm < p.M) ? mm : p.M - 1;
+                int row = mm;
+                if (g.ups) {
+                    if (w4) {
+                        row = rowU4[r >> 2] + ((r & 3) >> 1);
+                    } else {
+                        const int ni = mm / HW;
+                        const int rm = mm - ni * HW;
+                        const int yy = rm / p.W;
+                        const int xx = rm - yy * p.W;
+                        row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                    }
+                }
+                xo[r] = (p.dbg & 16) ? 1.f : ldg1(xcol + (size_t)row * g.ld);
+            }
+        };
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + nt * 32 + li;
@@ -343,34 +370,17 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                     }
                 }
             } else {
-                // BatchNorm/ReLU backward, first half: dz = relu'(z) * dA, reductions sum(dz), sum(dz*xhat)
-                GrpEnt g;
-                g.ptr = nullptr; g.ld = 0; g.ups = 0;
+                // BatchNorm/ReLU backward, first half: dz = relu'(z) * dA, reductions sum(dz), sum(dz*xhat).
+                // The 16 X values of the NEXT channel tile are requested before this tile's are consumed.
+                if (nt == 0) bwd_fetch(0, xq[0]);
+                if (nt + 1 < NT) bwd_fetch(nt + 1, xq[(nt + 1) & 1]);
                 float csc = 0.f, csh = 0.f, cmu = 0.f, cis = 0.f;
-                if (colok) {
-                    g = grp[col >> 2];
-                    csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col];
-                }
-                const float* xcol = g.ptr + (col & 3);
+                if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if ((FAST || mm < p.M) && colok) {
-                        // rows 4k..4k+3 of a tile share an image row (W % 4 == 0): the up-sampled source row
-                        // of row 4k+j is rowU4[k] + (j >> 1)
-                        int row = mm;
-                        if (g.ups) {
-                            if (w4) {
-                                row = rowU4[r >> 2] + ((r & 3) >> 1);
-                            } else {
-                                const int ni = mm / HW;
-                                const int rm = mm - ni * HW;
-                                const int yy = rm / p.W;
-                                const int xx = rm - yy * p.W;
-                                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
-                            }
-                        }
-                        const float xv = (p.dbg & 16) ? 1.f : ldg1(xcol + (size_t)row * g.ld);
+                        const float xv = xq[nt & 1][r];
                         const float z = fmaf(xv, csc, csh);
                         const float dz = z > 0.f ? acc[nt][r] : 0.f;
                         if (!(p.dbg & 8)) p.y[(size_t)mm * p.ldy + col] = dz;

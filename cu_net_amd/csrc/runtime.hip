@@ -36,6 +36,8 @@ struct cunet_plan {
     // internal side stream: weight gradients run concurrently with the data-gradient chain
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_ev;     // one per node: "d(loss)/d(out) of node k is ready"
+    std::vector<hipEvent_t> done_ev;     // forward: node k (run on the side stream) has finished
+    std::vector<int> pending;            // forward: tensor -> node whose side-stream result it is, or -1
     hipEvent_t join_ev = nullptr;
     int use_side = 1;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
@@ -115,6 +117,7 @@ int cunet_plan_create(const cunet_cfg* cfg, cunet_plan_t** out) {
 void cunet_plan_destroy(cunet_plan_t* plan) {
     if (!plan) return;
     for (auto e : plan->fork_ev) (void)hipEventDestroy(e);
+    for (auto e : plan->done_ev) (void)hipEventDestroy(e);
     if (plan->join_ev) (void)hipEventDestroy(plan->join_ev);
     if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
@@ -220,6 +223,8 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         h->fork_ev.resize(P.nodes.size());
         for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->done_ev.resize(P.nodes.size());
+        for (auto& e : h->done_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
     }
     h->fwd_training_done = 0; h->loss_done = 0;
@@ -357,8 +362,26 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     const int cus = h->num_cus;
     HIPCHK(hipMemsetAsync(h->ws + P.off_zero, 0, (size_t)P.zero_bytes, s));
     HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
-    for (const Node& n : P.nodes) {
+    const bool fork_fwd = training && h->use_side && h->side && !h->done_ev.empty();
+    h->pending.assign(P.tensors.size(), -1);
+    hipStream_t s_main = s;
+    for (size_t ni = 0; ni < P.nodes.size(); ++ni) {
+        const Node& n = P.nodes[ni];
         const TensorInfo& o = P.tensors[n.out];
+        s = s_main;
+        // join: an input produced on the side stream must be complete
+        for (const SegRef& sr : n.segs) {
+            const int pn = h->pending[sr.tensor];
+            if (pn >= 0) { HIPCHK(hipStreamWaitEvent(s_main, h->done_ev[pn], 0)); h->pending[sr.tensor] = -1; }
+        }
+        // fork: the skip adapter of a down block is consumed only on the way up (models/cu_net.py:257,267),
+        // so it runs on the side stream next to the ahead adapter / pool / next block
+        const bool forked = fork_fwd && n.type == N_CONV && n.name.find(".adapters_skip.") != std::string::npos;
+        if (forked) {
+            HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
+            HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[ni], 0));
+            s = h->side;
+        }
         if (n.type == N_STEM_CONV) {
             const ConvInfo& c = P.convs[n.conv];
             ConvArgs a{};
@@ -397,7 +420,14 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             PROF(c.taps == 9 ? PC_C3F : PC_C1F, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + a.Nout),
                  launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
         }
+        if (forked) {
+            HIPCHK(hipEventRecord(h->done_ev[ni], h->side));
+            h->pending[n.out] = (int)ni;
+        }
     }
+    s = s_main;
+    for (size_t t = 0; t < h->pending.size(); ++t)      // nothing may be left floating
+        if (h->pending[t] >= 0) { HIPCHK(hipStreamWaitEvent(s, h->done_ev[h->pending[t]], 0)); h->pending[t] = -1; }
     if (training)
         HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
                                      E.zero, h->buffers, h->counters, 0, s));
