@@ -9,4 +9,4 @@ the landmark decode (`get_preds`) and the weight quantisers (`cu_net_amd.quant`)
 """
 from ._lib import CUNetError, LIB_PATH  # noqa: F401
 from .module import CUNet, create_cu_net  # noqa: F401
-from .trainer import FusedTrainer, get_preds  # noqa: F401
+from .trainer import FusedTrainer, final_preds, get_preds  # noqa: F401

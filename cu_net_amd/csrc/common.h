@@ -131,6 +131,21 @@ struct PoolArgs {
     double* red;           // stem backward reductions [2][C]
 };
 
+struct QuantEntry {      // one target conv: weight [O][I][KK] at float offset `off` of the arena
+    int64_t off;
+    int O, I, KK, pad_;
+};
+
+struct TernArgs {
+    const float* x;          // [M][C] raw (pre-BN) activations
+    const float* scale;      // [C] folded BatchNorm (eval) scale / shift
+    const float* shift;
+    const uint64_t* wpos;    // [taps][G][Opad] bit c of word (tap,g,o) = (w[o][64g+c][tap] == +1)
+    const uint64_t* wneg;
+    float* y;                // [M][O]
+    int M, H, W, C, O, Opad, taps, bits_i;
+};
+
 // Explicit global-address-space loads.  A pointer that reaches a lane through LDS or through a
 // dynamically indexed kernarg struct has lost its address space, and hipcc then emits flat_load,
 // which also counts on LGKM: the next `s_waitcnt lgkmcnt(0)` in front of an LDS-fed MFMA group would

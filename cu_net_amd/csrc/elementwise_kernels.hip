@@ -634,6 +634,62 @@ __global__ __launch_bounds__(256) void get_preds_kernel(const float* __restrict_
     }
 }
 
+// final_preds (pylib/Evaluation.py:108-132) with rot == 0 (validation, data/mpii_for_mpii_22.py:120): arg-max,
+// quarter-pixel shift toward the larger neighbour, +0.5, inverse crop transform (Evaluation.py:152-187 with
+// size = 200): the reference builds the 3x3 matrix from float32 scalars, inverts it in float64 (LAPACK on an
+// upper-triangular matrix: inv[0][2] = -(b * (1/a))) and truncates toward zero; the same sequence is used here.
+__global__ __launch_bounds__(256) void final_preds_kernel(const float* __restrict__ heat, const float* __restrict__ center,
+                                                          const float* __restrict__ scale, float* __restrict__ preds,
+                                                          int maps, int K, int H, int W, int res0, int res1) {
+    const int lane = threadIdx.x & 63;
+    const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (map >= maps) return;
+    const int HW = H * W;
+    const float* h = heat + (size_t)map * HW;
+    float best = -INFINITY;
+    int bi = HW;
+    for (int i = lane; i < HW; i += 64) {
+        const float v = h[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane != 0) return;
+    if (bi >= HW) bi = 0;
+    float x = (float)(bi % W + 1);
+    float y = floorf((float)bi / (float)H) + 1.f;
+    if (!(best > 0.f)) { x = 0.f; y = 0.f; }
+    const int px = (int)floorf(x), py = (int)floorf(y);
+    if (px > 1 && px < res0 && py > 1 && py < res1) {
+        const float dx = h[(py - 1) * W + px] - h[(py - 1) * W + px - 2];
+        const float dy = h[py * W + px - 1] - h[(py - 2) * W + px - 1];
+        x += (float)((dx > 0.f) - (dx < 0.f)) * 0.25f;
+        y += (float)((dy > 0.f) - (dy < 0.f)) * 0.25f;
+    }
+    x += 0.5f;
+    y += 0.5f;
+    const int n = map / K;
+    const float hh = 200.f * scale[n];                       // float32 arithmetic, as numpy does for float32 scalars
+    const float a32 = (float)res0 / hh;
+    const float b32 = (float)res0 * (-center[2 * n + 0] / hh + 0.5f);
+    const float c32 = (float)res0 * (-center[2 * n + 1] / hh + 0.5f);
+    const double ia = 1.0 / (double)a32;
+    const double i02 = -((double)b32 * ia), i12 = -((double)c32 * ia);
+    const double nx = __dadd_rn(__dmul_rn(ia, (double)(x - 1.f)), i02);
+    const double ny = __dadd_rn(__dmul_rn(ia, (double)(y - 1.f)), i12);
+    preds[(size_t)map * 2 + 0] = (float)((long long)nx + 1);   // astype(int): truncation toward zero
+    preds[(size_t)map * 2 + 1] = (float)((long long)ny + 1);
+}
+
+hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,
+                              int H, int W, int res0, int res1, hipStream_t s) {
+    hipLaunchKernelGGL(final_preds_kernel, dim3((N * K + 3) / 4), dim3(256), 0, s, heat, center, scale, preds, N * K, K, H, W, res0, res1);
+    return hipGetLastError();
+}
+
 hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, int W, hipStream_t s) {
     hipLaunchKernelGGL(get_preds_kernel, dim3((maps + 3) / 4), dim3(256), 0, s, heat, preds, maps, H, W);
     return hipGetLastError();

@@ -21,6 +21,16 @@ hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* s
 hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, float* ws, hipStream_t s);
 hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
                           float gscale, hipStream_t s);
+hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,
+                              int H, int W, int res0, int res1, hipStream_t s);
 hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, int W, hipStream_t s);
+
+hipError_t launch_quant_prepare(const QuantEntry* tab, int nconv, int maxO, int maxN, float* params, float* saved,
+                                int bits_w, int bits_g, int keep_scale, hipStream_t s);
+hipError_t launch_quant_restore(const QuantEntry* tab, int nconv, float* params, const float* saved, hipStream_t s);
+hipError_t launch_quant_grad(const QuantEntry* tab, int nconv, int maxO, const float* params, float* grads,
+                             int bits_w, int bits_g, int keep_scale, hipStream_t s);
+hipError_t launch_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int O, int C, int taps, int Opad, hipStream_t s);
+hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s);
 
 }  // namespace cunet

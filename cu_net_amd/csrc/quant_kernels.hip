@@ -1,0 +1,251 @@
+// Weight / gradient quantisers and the multiplier-free ternary convolution.
+//
+// Replaces, on the flat parameter / gradient arenas (one launch per phase for ALL target convs):
+//   utils/quantize.py:104-149  QuanOp.quantization  (mean-centre, clamp, save, quantise)
+//   utils/quantize.py:151-153  QuanOp.restore
+//   utils/quantize.py:156-175  QuanOp.updateQuanGradWeight
+//   models/cu_net_prev_version.py:45-92  BinOp (keep_scale = 1, bits_g = 32)
+// and, as the non-MFMA alternative for conv with weights in {-1,0,+1} on 8-bit activations
+// (QuanInput2d placement, models/cu_net_prev_version_wig.py:96-98,277-279), an AND-popcount kernel.
+#include "common.h"
+
+namespace cunet {
+
+
+__device__ __forceinline__ float q_scale(int bits) { return exp2f((float)(bits - 1)); }     // S(bits)
+__device__ __forceinline__ float q_clamp(float x, int bits) {                                // C(x, bits)
+    const float delta = (bits > 15 || bits == 1 || bits == 2) ? 0.f : 1.f / q_scale(bits);
+    return fminf(fmaxf(x, -1.f + delta), 1.f - delta);
+}
+__device__ __forceinline__ float q_sign(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+__device__ __forceinline__ float q_round(float x, int bits) {                                // Q(x, bits)
+    if (bits > 15) return x;
+    if (bits == 1) return q_sign(x);
+    if (bits == 2) return rintf(x);                 // torch.round: half to even
+    const float sc = q_scale(bits);
+    return rintf(x * sc) / sc;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {     // 256 threads
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// One block per (conv, filter).  The filter (n = I*KK floats) lives in LDS while it is processed.
+__global__ __launch_bounds__(256) void quant_prepare_kernel(const QuantEntry* tab, float* params, float* saved,
+                                                            int bits_w, int bits_g, int keep_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w = reinterpret_cast<float*>(smem);
+    __shared__ float scratch[4];
+    __shared__ float pmean[64];
+    const QuantEntry e = tab[blockIdx.y];
+    const int o = blockIdx.x;
+    if (o >= e.O) return;
+    const int n = e.I * e.KK;
+    float* src = params + e.off + (size_t)o * n;
+    float* sv = saved + e.off + (size_t)o * n;
+    for (int i = threadIdx.x; i < n; i += 256) w[i] = src[i];
+    __syncthreads();
+    // mean over the INPUT channels for every kernel position (W.mean(1, keepdim))
+    for (int p = threadIdx.x >> 6; p < e.KK; p += 4) {       // one wave per position
+        float s = 0.f;
+        for (int i = threadIdx.x & 63; i < e.I; i += 64) s += w[i * e.KK + p];
+        for (int of = 32; of > 0; of >>= 1) s += __shfl_xor(s, of, 64);
+        if ((threadIdx.x & 63) == 0) pmean[p] = s / (float)e.I;
+    }
+    __syncthreads();
+    float asum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float c = q_clamp(w[i] + (-pmean[i % e.KK]), bits_g);
+        w[i] = c;
+        sv[i] = q_round(c, bits_g);
+        asum += fabsf(c);
+    }
+    const float m = block_sum(asum, scratch) / (float)n;     // mean |W| of the filter
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float c = w[i];
+        float out;
+        if (bits_w == 1) {
+            const float mq = q_round(m, bits_g);
+            const float t = q_sign(c) * mq;
+            out = keep_scale ? t : q_round(q_clamp(t, 1), 1);         // the reference falls through to Q(C(.,1),1)
+        } else if (bits_w == 2) {
+            const float d = m * 0.7f;
+            out = (float)(c > d) + -1.f * (float)(c < -d);
+        } else {
+            out = q_round(q_clamp(c, bits_w), bits_w);
+        }
+        src[i] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void quant_restore_kernel(const QuantEntry* tab, float* params, const float* saved) {
+    const QuantEntry e = tab[blockIdx.y];
+    const long n = (long)e.O * e.I * e.KK;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        params[e.off + i] = saved[e.off + i];
+}
+
+__global__ __launch_bounds__(256) void quant_grad_kernel(const QuantEntry* tab, const float* params, float* grads,
+                                                         int bits_w, int bits_g, int keep_scale) {
+    __shared__ float scratch[4];
+    const QuantEntry e = tab[blockIdx.y];
+    const int o = blockIdx.x;
+    if (o >= e.O) return;
+    const int n = e.I * e.KK;
+    const float* w = params + e.off + (size_t)o * n;
+    float* g = grads + e.off + (size_t)o * n;
+    if (bits_w != 1) {
+        if (!keep_scale)
+            for (int i = threadIdx.x; i < n; i += 256) g[i] = q_round(q_clamp(g[i], bits_g), bits_g);
+        return;
+    }
+    float asum = 0.f, ssum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        asum += fabsf(w[i]);
+        ssum += q_sign(w[i]) * g[i];
+    }
+    const float m = block_sum(asum, scratch) / (float)n;
+    const float sadd = block_sum(ssum, scratch) / (float)n;
+    const float mq = q_round(m, bits_g);
+    const float c1 = (float)(1.0 - 1.0 / (double)e.I);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float wi = w[i];
+        const float mi = (wi < -1.f || wi > 1.f) ? q_round(0.f, bits_g) : mq;
+        float v = ((mi * g[i] + sadd * q_sign(wi)) * c1) * (float)n;
+        if (!keep_scale) v = q_round(q_clamp(v, bits_g), bits_g);     // BinOp has no gradient rounding
+        g[i] = v;
+    }
+}
+
+hipError_t launch_quant_prepare(const QuantEntry* tab, int nconv, int maxO, int maxN, float* params, float* saved,
+                                int bits_w, int bits_g, int keep_scale, hipStream_t s) {
+    hipLaunchKernelGGL(quant_prepare_kernel, dim3(maxO, nconv), dim3(256), (size_t)maxN * 4, s, tab, params, saved,
+                       bits_w, bits_g, keep_scale);
+    return hipGetLastError();
+}
+hipError_t launch_quant_restore(const QuantEntry* tab, int nconv, float* params, const float* saved, hipStream_t s) {
+    hipLaunchKernelGGL(quant_restore_kernel, dim3(16, nconv), dim3(256), 0, s, tab, params, saved);
+    return hipGetLastError();
+}
+hipError_t launch_quant_grad(const QuantEntry* tab, int nconv, int maxO, const float* params, float* grads,
+                             int bits_w, int bits_g, int keep_scale, hipStream_t s) {
+    hipLaunchKernelGGL(quant_grad_kernel, dim3(maxO, nconv), dim3(256), 0, s, tab, params, grads, bits_w, bits_g, keep_scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ternary convolution by AND + popcount (1x1 or 3x3, NHWC):
+//     y[p][o] = sum_{tap,c} w[o][c][tap] * a[p (+) tap][c],  w in {-1,0,+1},
+//     a = QuanInput_b(relu(x*scale + shift)) = q / 2^(b-1),  q in [0, 2^(b-1) - 1]
+//   => y * 2^(b-1) = sum_bit 2^bit * ( popc(P_o & plane_bit) - popc(N_o & plane_bit) )
+// Lanes = output channels (their +1 / -1 masks P_o, N_o stay in registers); the wave walks pixels: 64
+// lanes read 64 channels of one pixel (one coalesced 256-B row piece), quantise, and 7 wave ballots
+// turn the 64 values into 7 uniform 64-bit bit-planes held in scalar registers.  No multiplier and no
+// MFMA is used; the result is exact integer arithmetic, bit-identical to an fp32 convolution of the
+// quantised activations (every partial sum is a multiple of 2^-7 below 2^17).
+constexpr int TC_MAXG1 = 6;     // 1x1: 64-channel groups kept in registers (C <= 384)
+constexpr int TC_MAXG9 = 2;     // 3x3: C <= 128 (9 taps x 2 groups x 2 masks)
+
+
+template <int TAPS, int MAXG>
+__global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = (p.C + 63) >> 6;
+    const int o = blockIdx.y * 64 + lane;                 // this lane's output channel
+    uint64_t P[TAPS][MAXG], N[TAPS][MAXG];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            P[t][g] = 0; N[t][g] = 0;
+            if (g < G && o < p.Opad) {
+                P[t][g] = p.wpos[((size_t)t * G + g) * p.Opad + o];
+                N[t][g] = p.wneg[((size_t)t * G + g) * p.Opad + o];
+            }
+        }
+    const int nb = p.bits_i - 1;                           // bit-planes (7 for 8-bit inputs)
+    const float qs = exp2f((float)nb);
+    const int HW = p.H * p.W;
+    const int nwaves = gridDim.x * 4;
+    for (int m = blockIdx.x * 4 + wave; m < p.M; m += nwaves) {
+        const int ni = m / HW;
+        const int rem = m - ni * HW;
+        const int py = rem / p.W, px = rem - py * p.W;
+        int acc = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            int row = m;
+            bool valid = true;
+            if (TAPS == 9) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const int yy = py + dy, xx = px + dx;
+                valid = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
+                row = valid ? m + dy * p.W + dx : m;
+            }
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                if (g >= G) break;
+                const int c = 64 * g + lane;
+                int q = 0;
+                if (valid && c < p.C) {
+                    float a = fmaxf(fmaf(p.x[(size_t)row * p.C + c], p.scale[c], p.shift[c]), 0.f);
+                    a = fminf(a, 1.f - 1.f / qs);                          // C(x, bits_i); relu already >= 0
+                    q = (int)rintf(a * qs);                                // Q(x, bits_i) * 2^(bits_i-1)
+                }
+                for (int b = 0; b < nb; ++b) {
+                    const uint64_t plane = __ballot((q >> b) & 1);         // uniform: bit c = bit b of channel 64g+c
+                    const int d = __popcll(P[t][g] & plane) - __popcll(N[t][g] & plane);
+                    acc += d * (1 << b);
+                }
+            }
+        }
+        if (o < p.O) p.y[(size_t)m * p.O + o] = (float)acc / qs;
+    }
+}
+
+// packs torch-layout ternary weights [O][C][taps] (values -1, 0, +1) into the two bit-mask tensors
+__global__ __launch_bounds__(256) void ternary_pack_kernel(const float* __restrict__ w, uint64_t* wpos, uint64_t* wneg,
+                                                           int O, int C, int taps, int Opad) {
+    const int G = (C + 63) >> 6;
+    const long total = (long)taps * G * Opad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int o = (int)(i % Opad);
+        const int g = (int)((i / Opad) % G);
+        const int t = (int)(i / ((long)Opad * G));
+        uint64_t pp = 0, nn = 0;
+        if (o < O)
+            for (int c = 0; c < 64; ++c) {
+                const int ch = 64 * g + c;
+                if (ch >= C) break;
+                const float v = w[((size_t)o * C + ch) * taps + t];
+                if (v > 0.f) pp |= (uint64_t)1 << c;
+                if (v < 0.f) nn |= (uint64_t)1 << c;
+            }
+        wpos[i] = pp;
+        wneg[i] = nn;
+    }
+}
+
+hipError_t launch_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int O, int C, int taps, int Opad, hipStream_t s) {
+    const long total = (long)taps * ((C + 63) / 64) * Opad;
+    hipLaunchKernelGGL(ternary_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wpos, wneg, O, C, taps, Opad);
+    return hipGetLastError();
+}
+
+hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
+    if ((a.taps != 1 && a.taps != 9) || a.bits_i < 2 || a.bits_i > 15) return hipErrorInvalidValue;
+    if ((a.C + 63) / 64 > (a.taps == 1 ? TC_MAXG1 : TC_MAXG9)) return hipErrorInvalidValue;
+    int gx = (a.M + 3) / 4;
+    if (gx > 8 * num_cus) gx = 8 * num_cus;
+    const dim3 grid(gx, a.Opad / 64);
+    if (a.taps == 1) hipLaunchKernelGGL((ternary_conv_kernel<1, TC_MAXG1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ternary_conv_kernel<9, TC_MAXG9>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cunet

@@ -554,6 +554,58 @@ int cunet_get_preds(const float* heat, float* preds, int n, int k, int hh, int w
     return CUNET_OK;
 }
 
+int cunet_final_preds(const float* heat, const float* center, const float* scale, float* preds, int n, int k, int hh,
+                      int w, int res0, int res1, void* stream) {
+    if (!heat || !center || !scale || !preds || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_final_preds(heat, center, scale, preds, n, k, hh, w, res0, res1, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+static int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+    return cus;
+}
+
+int cunet_quant_prepare(float* params, float* saved, const void* table, int nconv, int max_o, int max_n, int bits_w,
+                        int bits_g, int keep_scale, void* stream) {
+    if (!params || !saved || !table || nconv < 1 || max_o < 1 || max_n < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    if (bits_w < 1 || bits_g < 1 || (size_t)max_n * 4 > 60 * 1024) return fail(CUNET_ERR_INVALID, "unsupported bit width or filter size");
+    HIPCHK(launch_quant_prepare((const QuantEntry*)table, nconv, max_o, max_n, params, saved, bits_w, bits_g, keep_scale, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_quant_restore(float* params, const float* saved, const void* table, int nconv, void* stream) {
+    if (!params || !saved || !table || nconv < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_quant_restore((const QuantEntry*)table, nconv, params, saved, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_quant_grad(const float* params, float* grads, const void* table, int nconv, int max_o, int bits_w, int bits_g,
+                     int keep_scale, void* stream) {
+    if (!params || !grads || !table || nconv < 1 || max_o < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_quant_grad((const QuantEntry*)table, nconv, max_o, params, grads, bits_w, bits_g, keep_scale, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int o, int c, int taps, void* stream) {
+    if (!w || !wpos || !wneg || o < 1 || c < 1 || (taps != 1 && taps != 9)) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_ternary_pack(w, wpos, wneg, o, c, taps, round_up(o, 64), (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_ternary_conv(const float* x, const float* scale, const float* shift, const uint64_t* wpos, const uint64_t* wneg,
+                       float* y, int n, int hh, int w, int c, int o, int taps, int bits_i, void* stream) {
+    if (!x || !scale || !shift || !wpos || !wneg || !y || n < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    TernArgs a{};
+    a.x = x; a.scale = scale; a.shift = shift; a.wpos = wpos; a.wneg = wneg; a.y = y;
+    a.M = n * hh * w; a.H = hh; a.W = w; a.C = c; a.O = o; a.Opad = round_up(o, 64); a.taps = taps; a.bits_i = bits_i;
+    hipError_t e = launch_ternary_conv(a, device_cus(), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? CUNET_ERR_INVALID : CUNET_ERR_HIP, std::string("ternary conv: ") + hipGetErrorString(e));
+    return CUNET_OK;
+}
+
 int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (!h || node < 0 || node >= (int)h->plan.nodes.size()) return fail(CUNET_ERR_INVALID, "bad node index");
     if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");

@@ -88,3 +88,21 @@ def get_preds(scores: torch.Tensor) -> torch.Tensor:
     preds = torch.empty((n, k, 2), dtype=torch.float32, device=s.device)
     check(lib().cunet_get_preds(_ptr(s), _ptr(preds), n, k, h, w, _stream_ptr(s.device)), 'cunet_get_preds')
     return preds
+
+
+def final_preds(output: torch.Tensor, center: torch.Tensor, scale: torch.Tensor, res, rot=None) -> torch.Tensor:
+    """pylib/Evaluation.py:108-132 on the GPU for rot == 0 (the validation path, cu-net.py:272):
+    N x K x H x W heat maps + per-image crop centre / scale -> N x K x 2 original-image coordinates."""
+    if rot is not None and bool(torch.as_tensor(rot).ne(0).any()):
+        raise CUNetError('final_preds: only rot == 0 (validation) is implemented on the HIP path')
+    if not output.is_cuda:
+        raise CUNetError('final_preds: GPU tensor required (the CPU oracle is oracle/decode_ref.py)')
+    s = output.contiguous().float()
+    n, k, h, w = s.shape
+    dev = s.device
+    c = center.contiguous().float().to(dev)
+    sc = scale.contiguous().float().to(dev)
+    preds = torch.empty((n, k, 2), dtype=torch.float32, device=dev)
+    check(lib().cunet_final_preds(_ptr(s), _ptr(c), _ptr(sc), _ptr(preds), n, k, h, w, int(res[0]), int(res[1]),
+                                  _stream_ptr(dev)), 'cunet_final_preds')
+    return preds

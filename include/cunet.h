@@ -125,6 +125,27 @@ int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int
  *   heat : N x K x H x W fp32 NCHW; preds: N x K x 2 fp32 (1-based x, y; 0,0 where max <= 0) */
 int cunet_get_preds(const float* heat, float* preds, int n, int k, int h, int w, void* stream);
 
+/* ---- weight / gradient quantisers on the flat arenas (utils/quantize.py:104-175 QuanOp; with
+ * keep_scale = 1 and bits_g = 32: BinOp, models/cu_net_prev_version.py:45-92).  `table` is a DEVICE array
+ * of nconv records {int64 offset; int32 O, I, KK, pad} describing the target conv weights [O][I][KK];
+ * max_o / max_n are the largest O and I*KK in the table.  One launch per phase for all convs. */
+int cunet_quant_prepare(float* params, float* saved, const void* table, int nconv, int max_o, int max_n,
+                        int bits_w, int bits_g, int keep_scale, void* stream);
+int cunet_quant_restore(float* params, const float* saved, const void* table, int nconv, void* stream);
+int cunet_quant_grad(const float* params, float* grads, const void* table, int nconv, int max_o,
+                     int bits_w, int bits_g, int keep_scale, void* stream);
+
+/* ---- multiplier-free ternary convolution (AND + popcount over activation bit-planes): the non-MFMA
+ * alternative for conv weights in {-1,0,+1} on bits_i-bit activations (QuanInput2d placement,
+ * models/cu_net_prev_version_wig.py:96-98,277-279).  cunet_ternary_pack turns torch-layout weights
+ * [O][C][taps] into two uint64 mask tensors of taps*ceil(C/64)*roundup(O,64) words each;
+ * cunet_ternary_conv computes y[N*H*W][O] = conv(QuanInput(relu(x*scale+shift))) for NHWC x[N*H*W][C],
+ * taps = 1 (1x1) or 9 (3x3, pad 1).  Exact: bit-identical to the fp32 convolution of the quantised input. */
+int cunet_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int o, int c, int taps, void* stream);
+int cunet_ternary_conv(const float* x, const float* scale, const float* shift, const uint64_t* wpos,
+                       const uint64_t* wneg, float* y, int n, int h, int w, int c, int o, int taps,
+                       int bits_i, void* stream);
+
 /* ---- per-kernel-class timing (bench.py roofline) ------------------------------------------------
  * HIP events are recorded on the launch stream around every launch of the selected class(es):
  * mode 0 = off, 1 = every class, 2 = only class `cls`.  cunet_profile_collect waits for the pending
@@ -136,6 +157,12 @@ int cunet_profile_collect(cunet_plan_t* plan);
 int cunet_profile_num_classes(void);
 const char* cunet_profile_class_name(int cls);
 int cunet_profile_get(const cunet_plan_t* plan, int cls, int64_t* count, double* ms, double* flops, double* bytes);
+
+/* full-resolution landmark decode: replaces pylib/Evaluation.py:108-132 final_preds for rot == 0
+ * (quarter-pixel refinement, +0.5, inverse crop transform :152-187 with size 200, truncation).
+ *   center: N x 2, scale: N (fp32, device); res0/res1: heat-map resolution bounds of the refinement test */
+int cunet_final_preds(const float* heat, const float* center, const float* scale, float* preds, int n, int k,
+                      int h, int w, int res0, int res1, void* stream);
 
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);

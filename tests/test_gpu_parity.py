@@ -216,3 +216,15 @@ def test_get_preds_bit_exact():
     ref = torch.stack([px, py], 2) * maxval.gt(0).unsqueeze(2).float()
     got = cu_net_amd.get_preds(s.cuda()).cpu()
     assert torch.equal(got, ref)
+
+
+def test_decode_matches_reference_vectors():
+    """get_preds / final_preds against vectors produced by the reference's pylib/Evaluation.py (G8): bit-exact."""
+    import numpy as np
+    from tests._golden import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'G8_decode.npz'))
+    hm = torch.from_numpy(z['heat']).cuda()
+    assert torch.equal(cu_net_amd.get_preds(hm).cpu(), torch.from_numpy(z['get_preds']))
+    fp = cu_net_amd.final_preds(hm, torch.from_numpy(z['center']), torch.from_numpy(z['scale']), [64, 64],
+                                torch.zeros(hm.shape[0]))
+    assert torch.equal(fp.cpu(), torch.from_numpy(z['final_preds']))

@@ -1,0 +1,127 @@
+"""GPU (-m gpu): the quantiser kernels and the AND-popcount ternary convolution against the oracle
+(oracle/quant_ref.py, pinned bit-exact to the reference's utils/quantize.py by tools/gen_golden.py).
+
+Quantised outputs are discrete, so they are compared exactly; the per-filter / per-position means
+feeding them are fp32 sums taken in a different order than torch's, which may move a value sitting
+exactly on a rounding boundary: at most 1e-3 of the elements may differ, each by one quantisation step."""
+import numpy as np
+import pytest
+import torch
+
+import cu_net_amd
+from cu_net_amd.quant import BinOp, QuanOp, ternary_conv
+from oracle import quant_ref as QR
+from tests._golden import CFG_KEYS, GOLDEN_DIR
+import os
+
+pytestmark = pytest.mark.gpu
+
+
+def _g7():
+    z = np.load(os.path.join(GOLDEN_DIR, 'G7_quant.npz'))
+    cfg = {k: int(v) for k, v in zip(CFG_KEYS, z['cfg'])}
+    return z, cfg
+
+
+def _mismatch(a, b, step):
+    d = (a.cpu() - b).abs()
+    bad = d > 1e-6
+    assert float(d.max()) <= step + 1e-6, float(d.max())
+    return int(bad.sum()), d.numel()
+
+
+@pytest.mark.parametrize('bits_w', [1, 2, 4])
+def test_quanop_phases_match_reference(bits_w):
+    z, cfg = _g7()
+    names = z['conv_names'].tolist()
+    net = cu_net_amd.create_cu_net(**cfg)
+    sd = net.state_dict()
+    for n in names:
+        sd[n + '.weight'].copy_(torch.from_numpy(z['w0/' + n]))
+    net = net.cuda()
+    qop = QuanOp(net, bits_w=bits_w, bits_i=8, bits_g=8)
+    assert qop.target_names == [names[i] for i in z['targets'].tolist()]
+    qop.quantization()
+    sd = net.state_dict()
+    nbad = ntot = 0
+    step_w = {1: 2.0, 2: 1.0, 4: 0.125}[bits_w]
+    for n in qop.target_names:
+        b, t = _mismatch(sd[n + '.weight'], torch.from_numpy(z[f'bw{bits_w}/wq/{n}']), step_w)
+        nbad += b; ntot += t
+    assert nbad <= 1e-3 * ntot, (nbad, ntot)
+    for n in (names[0], names[-1]):                          # first and last conv are left alone
+        assert torch.equal(sd[n + '.weight'].cpu(), torch.from_numpy(z['w0/' + n]))
+    qop.restore()
+    sd = net.state_dict()
+    nbad = ntot = 0
+    for n in qop.target_names:
+        b, t = _mismatch(sd[n + '.weight'], torch.from_numpy(z[f'bw{bits_w}/saved/{n}']), 1 / 128)
+        nbad += b; ntot += t
+    assert nbad <= 1e-3 * ntot, (nbad, ntot)
+    # gradient rewrite on the flat arena
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    for n in names:
+        o, nmel, shape = off[n + '.weight']
+        net._grad_arena[o:o + nmel] = torch.from_numpy(z['g/' + n]).reshape(-1).cuda()
+    # use the reference's own latents so that the comparison isolates the gradient kernel
+    for n in qop.target_names:
+        sd[n + '.weight'].copy_(torch.from_numpy(z[f'bw{bits_w}/saved/{n}']))
+    qop.updateQuanGradWeight()
+    nbad = ntot = 0
+    for n in qop.target_names:
+        o, nmel, shape = off[n + '.weight']
+        b, t = _mismatch(net._grad_arena[o:o + nmel].view(shape), torch.from_numpy(z[f'bw{bits_w}/grad/{n}']), 1 / 128)
+        nbad += b; ntot += t
+    assert nbad <= 1e-3 * ntot, (nbad, ntot)
+    for n in (names[0], names[-1]):
+        o, nmel, shape = off[n + '.weight']
+        assert torch.equal(net._grad_arena[o:o + nmel].view(shape).cpu(), torch.from_numpy(z['g/' + n]))
+
+
+def test_binop_matches_restatement():
+    z, cfg = _g7()
+    names = z['conv_names'].tolist()
+    net = cu_net_amd.create_cu_net(**cfg)
+    sd = net.state_dict()
+    for n in names:
+        sd[n + '.weight'].copy_(torch.from_numpy(z['w0/' + n]))
+    net = net.cuda()
+    bop = BinOp(net)
+    bop.binarization()
+    sd = net.state_dict()
+    for n in bop.target_names:
+        ref, saved = QR.binop_binarization(torch.from_numpy(z['w0/' + n]))
+        torch.testing.assert_close(sd[n + '.weight'].cpu(), ref, rtol=1e-5, atol=1e-6)
+    bop.restore()
+    sd = net.state_dict()
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    for n in bop.target_names:
+        ref, saved = QR.binop_binarization(torch.from_numpy(z['w0/' + n]))
+        torch.testing.assert_close(sd[n + '.weight'].cpu(), saved, rtol=1e-5, atol=1e-6)
+        o, nmel, shape = off[n + '.weight']
+        net._grad_arena[o:o + nmel] = torch.from_numpy(z['g/' + n]).reshape(-1).cuda()
+    bop.updateBinaryGradWeight()
+    for n in bop.target_names:
+        _, saved = QR.binop_binarization(torch.from_numpy(z['w0/' + n]))
+        o, nmel, shape = off[n + '.weight']
+        ref = QR.binop_grad(saved, torch.from_numpy(z['g/' + n]))
+        torch.testing.assert_close(net._grad_arena[o:o + nmel].view(shape).cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 16, 16, 32, 3), (1, 160, 8, 8, 128, 1), (3, 72, 5, 7, 68, 1), (1, 128, 64, 64, 32, 3)])
+def test_ternary_popcount_conv_is_bit_exact(shape):
+    n, c, h, w, o, k = shape
+    g = torch.Generator().manual_seed(c + o + k)
+    x = torch.randn(n, c, h, w, generator=g)
+    scale = torch.rand(c, generator=g) * 0.5 + 0.1
+    shift = torch.randn(c, generator=g) * 0.2
+    wt = torch.randint(-1, 2, (o, c, k, k), generator=g).float()
+    ref = QR.ternary_conv_reference(x, scale, shift, wt, bits_i=8, pad=k // 2)
+    got = ternary_conv(x.cuda(), scale, shift, wt, bits_i=8).cpu()
+    assert torch.equal(got, ref)
+    # exactness claim of the oracle itself: an fp64 convolution gives the same numbers
+    ref64 = QR.ternary_conv_reference(x.double(), scale.double(), shift.double(), wt.double(), 8, k // 2)
+    a32 = torch.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    a64 = torch.relu(x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    if torch.equal(QR.quan_input(a32, 8).double(), QR.quan_input(a64, 8)):
+        assert torch.equal(ref.double(), ref64)

@@ -1,0 +1,46 @@
+"""CPU: the auxiliary oracles (quantisers, decode) reproduce the vectors generated from the reference."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import decode_ref as DR
+from oracle import quant_ref as QR
+from tests._golden import GOLDEN_DIR
+
+
+def test_quant_oracle_matches_reference_vectors():
+    z = np.load(os.path.join(GOLDEN_DIR, 'G7_quant.npz'))
+    names = z['conv_names'].tolist()
+    tgt = z['targets'].tolist()
+    assert tgt == QR.target_indices(len(names))
+    for bw in (1, 2, 4):
+        for i in tgt:
+            n = names[i]
+            w0, g = torch.from_numpy(z['w0/' + n]), torch.from_numpy(z['g/' + n])
+            wq, saved = QR.quantization(w0, bw, 8)
+            assert torch.equal(wq, torch.from_numpy(z[f'bw{bw}/wq/{n}'])), (bw, n)
+            assert torch.equal(saved, torch.from_numpy(z[f'bw{bw}/saved/{n}'])), (bw, n)
+            assert torch.equal(QR.grad_rewrite(saved, g, bw, 8), torch.from_numpy(z[f'bw{bw}/grad/{n}'])), (bw, n)
+    # bits_w == 1 drops the per-filter scale (the if/if/else fall-through of utils/quantize.py:126-149)
+    wq, _ = QR.quantization(torch.from_numpy(z['w0/' + names[3]]), 1, 8)
+    assert set(wq.unique().tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_decode_oracle_matches_reference_vectors():
+    z = np.load(os.path.join(GOLDEN_DIR, 'G8_decode.npz'))
+    hm = torch.from_numpy(z['heat'])
+    assert torch.equal(DR.get_preds(hm), torch.from_numpy(z['get_preds']))
+    fp = DR.final_preds(hm, torch.from_numpy(z['center']), torch.from_numpy(z['scale']), [64, 64], torch.zeros(hm.shape[0]))
+    assert torch.equal(fp, torch.from_numpy(z['final_preds']))
+    assert float(DR.get_preds(hm)[0, 0].abs().sum()) == 0.0            # all <= 0 -> (0, 0)
+    assert DR.get_preds(hm)[1, 2].tolist() == [21.0, 11.0]             # tie -> lowest flat index (y=10, x=20)
+
+
+def test_ternary_reference_is_exact_in_fp32():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 64, 6, 6, generator=g)
+    sc, sh = torch.rand(64, generator=g), torch.randn(64, generator=g) * 0.1
+    w = torch.randint(-1, 2, (8, 64, 3, 3), generator=g).float()
+    y = QR.ternary_conv_reference(x, sc, sh, w, 8, 1)
+    assert torch.equal(y * 128, torch.round(y * 128))                  # multiples of 2^-7

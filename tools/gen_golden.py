@@ -201,6 +201,110 @@ def init_parity(ref):
     print(f'G_init: {len(names)} parameter tensors, {len(conv_order)} convs')
 
 
+def load_reference_quantize():
+    """Execute the reference's utils/quantize.py with a stub for its import-time option parsing
+    (`opt = TrainOptions().parse()` at :8 would need sys.argv and would mkdir the experiment dir)."""
+    import argparse
+    stub = types.ModuleType('options.train_options')
+
+    class TrainOptions:                       # noqa: N801 - mirrors the imported name
+        def parse(self):
+            return argparse.Namespace(bits_w=1, bits_i=8, bits_g=8)
+    stub.TrainOptions = TrainOptions
+    pkg = types.ModuleType('options')
+    sys.modules['options'] = pkg
+    sys.modules['options.train_options'] = stub
+    src = open(os.path.join(REF, 'utils', 'quantize.py')).read()
+    mod = types.ModuleType('ref_quantize')
+    exec(compile(src, '<reference utils/quantize.py>', 'exec'), mod.__dict__)
+    return mod
+
+
+def quant_parity(ref, rq):
+    """G7: QuanOp phases of the reference on a reference model, bits_w in {1, 2, 4}, bits_g = 8."""
+    from oracle import quant_ref as QR
+    cfg = dict(neck_size=2, growth_rate=4, init_chan_num=8, class_num=3, layer_num=2, order=1, loss_num=2)
+    torch.manual_seed(77)
+    net = quiet(ref.create_cu_net, **cfg)
+    convs = [(n, m) for n, m in net.named_modules() if isinstance(m, torch.nn.Conv2d)]
+    g = torch.Generator().manual_seed(78)
+    with torch.no_grad():
+        for i, (n, m) in enumerate(convs):      # make some weights large so the clamps and |W|>1 masks act
+            m.weight.mul_(40.0 if i % 3 == 0 else 3.0)
+    w0 = {n: m.weight.detach().clone() for n, m in convs}
+    grads = {n: torch.randn(m.weight.shape, generator=g) * (0.02 if i % 2 else 0.3) for i, (n, m) in enumerate(convs)}
+    tgt = QR.target_indices(len(convs))
+    fx = {'cfg': np.array(list(cfg.values()), dtype=np.int64), 'conv_names': np.array([n for n, _ in convs], dtype='U'),
+          'targets': np.array(tgt, dtype=np.int64)}
+    for n, _ in convs:
+        fx['w0/' + n] = to_np(w0[n])
+        fx['g/' + n] = to_np(grads[n])
+    for bw in (1, 2, 4):
+        rq.bitsW, rq.bitsI, rq.bitsG = bw, 8, 8
+        with torch.no_grad():
+            for n, m in convs:
+                m.weight.copy_(w0[n])
+        qop = rq.QuanOp(net)
+        assert len(qop.target_modules) == len(tgt)
+        qop.quantization()
+        wq = {n: m.weight.detach().clone() for n, m in convs}
+        saved = [t.clone() for t in qop.saved_params]
+        qop.restore()
+        for n, m in convs:
+            m.weight.grad = grads[n].clone()
+        qop.updateQuanGradWeight()
+        for k, i in enumerate(tgt):
+            n, m = convs[i]
+            o_wq, o_saved = QR.quantization(w0[n], bw, 8)
+            check(f'G7/bw{bw}/wq/{n}', wq[n], o_wq)
+            check(f'G7/bw{bw}/saved/{n}', saved[k], o_saved)
+            check(f'G7/bw{bw}/restored/{n}', m.weight, o_saved)
+            o_g = QR.grad_rewrite(o_saved, grads[n], bw, 8)
+            check(f'G7/bw{bw}/grad/{n}', m.weight.grad, o_g)
+            fx[f'bw{bw}/wq/{n}'] = to_np(wq[n])
+            fx[f'bw{bw}/saved/{n}'] = to_np(saved[k])
+            fx[f'bw{bw}/grad/{n}'] = to_np(m.weight.grad)
+        for i in (0, len(convs) - 1):           # first / last conv are left alone
+            n, m = convs[i]
+            check(f'G7/bw{bw}/untouched/{n}', m.weight, w0[n])
+    np.savez_compressed(os.path.join(OUT, 'G7_quant.npz'), **fx)
+    print(f'G7: QuanOp on {len(tgt)} of {len(convs)} convs, bits_w in (1,2,4): oracle == reference')
+
+
+def decode_parity():
+    """G8: get_preds / final_preds of the reference (pylib/Evaluation.py) on random and adversarial heat maps."""
+    from oracle import decode_ref as DR
+    sys.modules.setdefault('HumanAug', types.ModuleType('HumanAug'))     # py2 implicit-relative import at :4, unused here
+    src = open(os.path.join(REF, 'pylib', 'Evaluation.py')).read()
+    ev = types.ModuleType('ref_evaluation')
+    exec(compile(src, '<reference pylib/Evaluation.py>', 'exec'), ev.__dict__)
+    g = torch.Generator().manual_seed(5)
+    n, k = 4, 16
+    hm = torch.randn(n, k, 64, 64, generator=g) * 0.1
+    for a in range(n):                                   # a blob per map, like real predictions
+        for b in range(k):
+            cy, cx = int(torch.randint(0, 64, (1,), generator=g)), int(torch.randint(0, 64, (1,), generator=g))
+            hm[a, b, cy, cx] += 1.0
+            if 0 < cx < 63:
+                hm[a, b, cy, cx + 1] += 0.5
+    hm[0, 0] = -1.0                                       # max <= 0 -> zeros
+    hm[0, 1] = 0.0
+    hm[1, 2] = 0.0; hm[1, 2, 10, 20] = 9.0; hm[1, 2, 40, 7] = 9.0      # tie -> lowest flat index
+    hm[2, 3] = 0.0; hm[2, 3, 63, 63] = 5.0                             # border maxima
+    hm[2, 4] = 0.0; hm[2, 4, 0, 0] = 5.0
+    hm[3, 5] = 0.0; hm[3, 5, 1, 1] = 5.0; hm[3, 5, 1, 2] = 4.0         # px == 2 boundary of the refinement window
+    center = torch.rand(n, 2, generator=g) * 400 + 300
+    scale = torch.rand(n, generator=g) * 2.0 + 0.8
+    rot = torch.zeros(n)
+    ref_gp = ev.get_preds(hm)
+    ref_fp = ev.final_preds(hm, center, scale, [64, 64], rot)
+    check('G8/get_preds', ref_gp, DR.get_preds(hm))
+    check('G8/final_preds', ref_fp, DR.final_preds(hm, center, scale, [64, 64], rot))
+    np.savez_compressed(os.path.join(OUT, 'G8_decode.npz'), heat=to_np(hm), center=to_np(center), scale=to_np(scale),
+                        get_preds=to_np(ref_gp), final_preds=to_np(ref_fp))
+    print('G8: get_preds / final_preds on 4x16 maps: oracle == reference')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -217,6 +321,8 @@ def main():
     one_config(ref, 'G6_L2_o1_hw64', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=4, hw=64, seed=16)
     full_width(ref)
     init_parity(ref)
+    quant_parity(ref, load_reference_quantize())
+    decode_parity()
 
 
 if __name__ == '__main__':
