@@ -18,7 +18,7 @@ from .module import CUNet, _ptr, _stream_ptr
 
 class FusedTrainer:
     def __init__(self, net: CUNet, lr: float = 2.5e-4, alpha: float = 0.99, eps: float = 1e-8,
-                 process_group=None, overlap: bool = True):
+                 process_group=None, overlap: bool = True, quan_op=None):
         """RMSprop hyper-parameters default to cu-net.py:60-61. `process_group`: a torch.distributed
         group (backend nccl == RCCL) for data parallelism, or None."""
         if not isinstance(net, CUNet):
@@ -26,6 +26,7 @@ class FusedTrainer:
         self.net = net
         self.lr, self.alpha, self.eps = float(lr), float(alpha), float(eps)
         self.square_avg = None
+        self.quan_op = quan_op        # cu_net_amd.quant.QuanOp / BinOp: quantised training (cu-net-prev-version-wig.py:163-190)
         self.pg = process_group
         self.world = 1
         self.overlap = overlap
@@ -53,6 +54,8 @@ class FusedTrainer:
         if tuple(heatmap.shape) != (n, net._hyper[3], h // 4, w // 4):
             raise CUNetError(f'heatmap must be {n} x {net._hyper[3]} x {h // 4} x {w // 4}')
         plan = net._get_plan(n, h, w, True)
+        if self.quan_op is not None:
+            self.quan_op.quantization()
         plan.forward(img, True, want_outputs=False)
         loss = plan.loss_mse(heatmap)
         if self.pg is None:
@@ -61,10 +64,17 @@ class FusedTrainer:
             self.reducer.begin_step()
             plan.backward(None, on_bucket=lambda b: self.reducer.reduce_bucket(net._grad_arena, b))
             self.reducer.finish(net._grad_arena)
+        gscale = 1.0 / self.world
+        if self.quan_op is not None:
+            self.quan_op.restore()
+            if self.world > 1:                      # the reference rewrites the already averaged gradient
+                net._grad_arena.mul_(gscale)
+                gscale = 1.0
+            self.quan_op.updateQuanGradWeight()
         if self.square_avg is None or self.square_avg.device != net._param_arena.device:
             self.square_avg = torch.zeros_like(net._param_arena)
         check(lib().cunet_rmsprop_step(_ptr(net._param_arena), _ptr(net._grad_arena), _ptr(self.square_avg),
-                                       net._n_params, self.lr, self.alpha, self.eps, 1.0 / self.world,
+                                       net._n_params, self.lr, self.alpha, self.eps, gscale,
                                        _stream_ptr(img.device)), 'cunet_rmsprop_step')
         return loss
 

@@ -270,16 +270,34 @@ def param_names(spec: Spec) -> List[str]:
     return [n for n, _, k in state_entries(spec) if k == 'param']
 
 
+def conv_weight_names(spec: Spec) -> List[str]:
+    """nn.Conv2d weights in the reference's modules() order (== state_dict order)."""
+    return [n for n, shape, k in state_entries(spec) if k == 'param' and len(shape) == 4]
+
+
 def train_step(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor, target: torch.Tensor,
                opt_state: Dict[str, torch.Tensor] | None = None, lr: float = 2.5e-4,
-               alpha: float = 0.99, eps: float = 1e-8, apply_update: bool = True):
+               alpha: float = 0.99, eps: float = 1e-8, apply_update: bool = True, quant=None):
     """One optimisation step (cu-net.py:171-183) with RMSprop(lr, alpha, eps) (cu-net.py:60-61).
 
+    `quant=(bits_w, bits_g)` wraps the step in QuanOp.quantization / restore / updateQuanGradWeight
+    (utils/quantize.py:104-175, loop placement cu-net-prev-version-wig.py:163-190).
     Returns (loss, outputs, grads dict).  `state` is updated in place (running stats always,
     parameters when `apply_update`).  Parameters whose gradient is None (non-anchor heads)
     are skipped by the optimiser, as torch.optim.RMSprop does.
     """
     names = param_names(spec)
+    qnames = []
+    if quant is not None:       # (bits_w, bits_g): cu-net-prev-version-wig.py:163-190 around the same step
+        from oracle import quant_ref as QR
+        convs = conv_weight_names(spec)
+        qnames = [convs[i] for i in QR.target_indices(len(convs))]
+        latents = {}
+        with torch.no_grad():
+            for n in qnames:
+                wq, saved = QR.quantization(state[n].detach(), quant[0], quant[1])
+                latents[n] = saved
+                state[n].copy_(wq)
     for n in names:
         state[n].requires_grad_(True)
         state[n].grad = None
@@ -289,6 +307,11 @@ def train_step(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor, targ
     loss.backward()
     finish_backward_stat_updates(ctxs[0])
     grads = {n: (state[n].grad.detach().clone() if state[n].grad is not None else None) for n in names}
+    if quant is not None:
+        with torch.no_grad():
+            for n in qnames:
+                state[n].copy_(latents[n])                                   # restore()
+                grads[n] = QR.grad_rewrite(latents[n], grads[n], quant[0], quant[1])   # updateQuanGradWeight()
     if apply_update:
         if opt_state is None:
             opt_state = {}
