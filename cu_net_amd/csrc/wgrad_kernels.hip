@@ -192,6 +192,7 @@ constexpr int WG2_PD = 4;
 struct Wg2Group { int c0; int ct; int chunk0; int nchunks; };   // per channel group
 struct Wg2Args {
     WgradArgs w;
+    int dbg;                 // timing experiments (CUNET_WG_DBG): 2 no operand loads, 4 no MFMA
     int ngroups;
     Wg2Group grp[12];
     int rows_per_chunk[12];
@@ -263,7 +264,10 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         const int mc = mok ? m : row_begin;
         {
             const float* src = p.dy + (size_t)mc * p.lddy + acol;
-            if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+            if (q.dbg & 2) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) a[t] = 1.f;
+            } else if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
             else {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) a[t] = ldg1(src + t);
@@ -276,7 +280,10 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             const int px = rem - py * p.W;
             const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
             const float* src = xbase + (size_t)(xups ? rowU : mc) * xldc;
-            if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+            if (q.dbg & 2) {
+#pragma unroll
+                for (int t = 0; t < CT; ++t) x[t] = 1.f;
+            } else if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
             else {
 #pragma unroll
                 for (int t = 0; t < CT; ++t) x[t] = ldg1(src + t);
@@ -304,11 +311,15 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
 #pragma unroll
             for (int t = 0; t < CT; ++t) x[t] = (xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f;
             issue(m0 + (uu + WG2_PD) * stride, av[u], xv[u], xok[u]);       // refill this slot PD pairs ahead
+            if (!(q.dbg & 4)) {
 #pragma unroll
             for (int ta = 0; ta < NTW; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < CT; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], x[tb], acc[ta][tb], 0, 0, 0);
+            } else {
+                acc[0][0][0] += a[0] * x[0];
+            }
         }
     }
 
@@ -361,6 +372,8 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     q.w = a;
     static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;
     q.w.ctw = nocommit ? -1 : 1;
+    static const int wdbg = getenv("CUNET_WG_DBG") ? atoi(getenv("CUNET_WG_DBG")) : 0;
+    q.dbg = wdbg;
     // channel groups: as many CT=4 (128-channel) groups as fit, then one CT=2 and/or CT=1 remainder
     int c = 0, ng = 0, weight = 0;
     const int C32 = (a.Ccat + 31) / 32;          // 32-channel tiles
@@ -375,7 +388,15 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     if (left > 0) return hipErrorInvalidValue;
     q.ngroups = ng;
     // blocks: ~1 per CU in total, split over the groups in proportion to their MFMA work
-    const int total = 2 * num_cus;
+    // two blocks per CU for the big nodes; small nodes get fewer blocks (>= WG2_MIN_ROWS rows each): every block
+    // commits a whole output tile with atomics, which is a fixed ~8-16K atomics per block whatever M is
+    static const int min_rows = getenv("CUNET_WG_MIN_ROWS") ? atoi(getenv("CUNET_WG_MIN_ROWS")) : 64;
+    static const int blocks_per_cu = getenv("CUNET_WG_BPC") ? atoi(getenv("CUNET_WG_BPC")) : 2;
+    int total = blocks_per_cu * num_cus;
+    {
+        const long cap = ((long)a.M * ng + min_rows - 1) / min_rows;
+        if (total > cap) total = (int)(cap < ng ? ng : cap);
+    }
     int chunk0 = 0;
     for (int g = 0; g < ng; ++g) {
         int nch = (total * q.grp[g].ct + weight - 1) / weight;
