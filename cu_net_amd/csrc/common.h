@@ -60,7 +60,9 @@ struct ConvArgs {
     // ---- stem (LD_STEM): NCHW image
     const float* img;
     int IH, IW;
-    int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 2 no A loads, 4 no MFMA, 8 no stores
+    int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
+                           // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
+                           // element loop is a branch around a load and serialises it)
 };
 
 struct WgradArgs {

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     const int n0 = blockIdx.y * NB;
 
     // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
+    if (!(p.dbg & 32))
     for (int idx = tid; idx < brows * NB; idx += blockDim.x) {
         const int row = idx / NB;
         const int n = idx - row * NB;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         Bs[idx] = v;
     }
     constexpr bool HAS_CONCAT = (LD == LD_SEG || LD == LD_3X3 || EP == EP_BWD);
-    if (HAS_CONCAT) setup_concat<EP == EP_BWD>(p, grp, sc, sh, mu, is);
+    if (HAS_CONCAT && !(p.dbg & 64)) setup_concat<EP == EP_BWD>(p, grp, sc, sh, mu, is);
     for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
     __syncthreads();
 
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
+    if (!(p.dbg & 128))
     for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
         const int m = tile * 32 + li;                // this lane's A row
         const int mc = m < p.M ? m : p.M - 1;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             for (int q = 0; q < 4; ++q) {
                 const int kk = c * 32 + q * 8 + hi * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk < p.K && !(p.dbg & 2)) {
+                if (kk < p.K) {
                     if (LD == LD_SEG) {
                         const GrpEnt g = grp[kk >> 2];
                         v = ldg4(g.ptr + (size_t)(g.ups ? rowU : mc) * g.ld);
@@ -312,18 +314,39 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         // ---- epilogue ---------------------------------------------------------------------
         // C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const int mrow0 = tile * 32;
-        const bool w4 = (p.W & 3) == 0;
-        int rowU4[4] = {0, 0, 0, 0};             // EP_BWD: up-sampled source row of this lane's 4 row groups
+        // EP_BWD: rows of this lane's 16 accumulator registers, plain and through the nearest-upsample map.
+        // Everything below is branch-free per element: a branch around a load makes hipcc wait for that load
+        // before issuing the next one (the first version of this epilogue spent 59 us of 177 in 64 serialised loads).
+        int rowP[16], rowUp[16];
         if (EP == EP_BWD) {
+            const bool w4 = (p.W & 3) == 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 int m4 = mrow0 + 8 * k + 4 * hi;
-                m4 = m4 < p.M ? m4 : p.M - 1;
-                const int ni = m4 / HW;
-                const int rm = m4 - ni * HW;
-                const int yy = rm / p.W;
-                const int xx = rm - yy * p.W;
-                rowU4[k] = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                int base = 0;
+                if (w4) {                         // rows 4k..4k+3 share an image row: one division per group (uniform branch)
+                    const int mq = m4 < p.M ? m4 : p.M - 1;
+                    const int ni = mq / HW;
+                    const int rm = mq - ni * HW;
+                    const int yy = rm / p.W;
+                    const int xx = rm - yy * p.W;
+                    base = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int mm = m4 + j;
+                    mm = (FAST || mm < p.M) ? mm : p.M - 1;
+                    rowP[4 * k + j] = mm;
+                    if (w4) {
+                        rowUp[4 * k + j] = base + (j >> 1);
+                    } else {
+                        const int ni = mm / HW;
+                        const int rm = mm - ni * HW;
+                        const int yy = rm / p.W;
+                        const int xx = rm - yy * p.W;
+                        rowUp[4 * k + j] = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                    }
+                }
             }
         }
         float xq[2][16];
@@ -334,23 +357,11 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             g.ptr = p.a; g.ld = 0; g.ups = 0;                 // always a valid address: loads stay branch-free
             if (colok) g = grp[col >> 2];
             const float* xcol = g.ptr + (colok ? (col & 3) : 0);
+            const bool up = g.ups != 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                mm = (FAST || mm < p.M) ? mm : p.M - 1;
-                int row = mm;
-                if (g.ups) {
-                    if (w4) {
-                        row = rowU4[r >> 2] + ((r & 3) >> 1);
-                    } else {
-                        const int ni = mm / HW;
-                        const int rm = mm - ni * HW;
-                        const int yy = rm / p.W;
-                        const int xx = rm - yy * p.W;
-                        row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
-                    }
-                }
-                xo[r] = (p.dbg & 16) ? 1.f : ldg1(xcol + (size_t)row * g.ld);
+                const int row = up ? rowUp[r] : rowP[r];
+                xo[r] = ldg1(xcol + (size_t)row * g.ld);
             }
         };
 #pragma unroll
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if ((FAST || mm < p.M) && colok) {
                         const float v = acc[nt][r];
-                        if (!(p.dbg & 8)) p.y[(size_t)mm * p.ldy + col] = v;
+                        p.y[(size_t)mm * p.ldy + col] = v;
                         s1 += v;
                         s2 = fmaf(v, v, s2);
                     }
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                         const float xv = xq[nt & 1][r];
                         const float z = fmaf(xv, csc, csh);
                         const float dz = z > 0.f ? acc[nt][r] : 0.f;
-                        if (!(p.dbg & 8)) p.y[(size_t)mm * p.ldy + col] = dz;
+                        p.y[(size_t)mm * p.ldy + col] = dz;
                         s1 += dz;
                         s2 = fmaf(dz, (xv - cmu) * cis, s2);
                     }
