@@ -105,13 +105,28 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     const int n0 = blockIdx.y * NB;
 
     // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
-    if (!(p.dbg & 32))
-    for (int idx = tid; idx < brows * NB; idx += blockDim.x) {
-        const int row = idx / NB;
-        const int n = idx - row * NB;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + n < p.Npad) v = ldg4(p.wB + ((size_t)row * p.Npad + n0 + n) * 4);
-        Bs[idx] = v;
+    if (!(p.dbg & 32)) {
+        // 8 independent 16-byte loads in flight per thread (a load-then-store loop would expose one full
+        // L2/HBM round trip per iteration: the copy of a 147 KB 3x3 operand dominated the small launches)
+        const int total = brows * NB;
+        for (int base = tid; base < total; base += blockDim.x * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * blockDim.x;
+                const int ic = idx < total ? idx : 0;
+                const int row = ic / NB;
+                const int n = ic - row * NB;
+                const int nn = (n0 + n < p.Npad) ? n0 + n : 0;
+                v[u] = ldg4(p.wB + ((size_t)row * p.Npad + nn) * 4);
+                if (n0 + n >= p.Npad) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * blockDim.x;
+                if (idx < total) Bs[idx] = v[u];
+            }
+        }
     }
     constexpr bool HAS_CONCAT = (LD == LD_SEG || LD == LD_3X3 || EP == EP_BWD);
     if (HAS_CONCAT && !(p.dbg & 64)) setup_concat<EP == EP_BWD>(p, grp, sc, sh, mu, is);

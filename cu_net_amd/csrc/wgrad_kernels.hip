@@ -89,54 +89,62 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     if (row_end > p.M) row_end = p.M;
     const bool nok = (n0 + li) < p.Cout;
 
-    // each wave takes row pairs  row_begin + 2*(wave + 4*j)
+    // each wave takes row pairs  row_begin + 2*(wave + 4*j).  Loads are branch-free (clamped addresses; validity
+    // and BN+ReLU are applied when the value is consumed): a branch around a load serialises it behind its wait.
+    const float* xbase0 = (LD != WG_STEM && cok[0]) ? xptr[0] : p.dy;
+    const int xld0 = (LD != WG_STEM && cok[0]) ? xld[0] : 0;
     for (int base = row_begin + 2 * wave * WG_UNROLL; base < row_end; base += 2 * 4 * WG_UNROLL) {
         float av[WG_UNROLL];
         float bv[WG_UNROLL][NACC];
+        unsigned vmask[WG_UNROLL];
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; ++u) {
             const int m = base + 2 * u + hi;
             const bool mok = m < row_end;
             const int mc = mok ? m : row_begin;
-            av[u] = (mok && nok) ? ldg1(p.dy + (size_t)mc * p.lddy + n0 + li) : 0.f;
-            int nimg = 0, py = 0, px = 0;
-            if (LD != WG_SEG || true) {
-                nimg = mc / HW;
-                const int rem = mc - nimg * HW;
-                py = rem / p.W;
-                px = rem - py * p.W;
-            }
+            av[u] = ldg1(p.dy + (size_t)mc * p.lddy + (nok ? n0 + li : 0));
+            const int nimg = mc / HW;
+            const int rem = mc - nimg * HW;
+            const int py = rem / p.W;
+            const int px = rem - py * p.W;
             const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+            unsigned vm = 0;
 #pragma unroll
             for (int a = 0; a < NACC; ++a) {
-                float v = 0.f;
                 if (LD == WG_SEG) {
-                    if (cok[a] && mok) {
-                        const float xv = ldg1(xptr[a] + (size_t)(xups[a] ? rowU : mc) * xld[a]);
-                        v = fmaxf(fmaf(xv, xsc[a], xsh[a]), 0.f);
-                    }
+                    const float* src = (cok[a] ? xptr[a] : p.dy) + (size_t)(xups[a] ? rowU : mc) * (cok[a] ? xld[a] : 0);
+                    bv[u][a] = ldg1(src);
+                    vm |= (unsigned)(cok[a] && mok) << a;
                 } else if (LD == WG_3X3) {
                     const int dy = a / 3 - 1, dx = a - (a / 3) * 3 - 1;
                     const int yy = py + dy, xx = px + dx;
                     const bool ok = cok[0] && mok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                    if (ok) {
-                        const float xv = ldg1(xptr[0] + (size_t)(mc + dy * p.W + dx) * xld[0]);
-                        v = fmaxf(fmaf(xv, xsc[0], xsh[0]), 0.f);
-                    }
+                    const int row = ok ? mc + dy * p.W + dx : mc;
+                    bv[u][a] = ldg1(xbase0 + (size_t)row * xld0);
+                    vm |= (unsigned)ok << a;
                 } else {  // WG_STEM
                     const int ci = skoff[a] >> 16, ky = (skoff[a] >> 8) & 255, kx = skoff[a] & 255;
                     const int iy = 2 * py - 3 + ky, ix = 2 * px - 3 + kx;
                     const bool ok = cok[a] && mok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                    if (ok) v = ldg1(p.img + ((size_t)(nimg * 3 + ci) * p.IH + iy) * p.IW + ix);
+                    const int iyc = ok ? iy : 0, ixc = ok ? ix : 0;
+                    bv[u][a] = ldg1(p.img + ((size_t)(nimg * 3 + ci) * p.IH + iyc) * p.IW + ixc);
+                    vm |= (unsigned)ok << a;
                 }
-                bv[u][a] = v;
             }
+            vmask[u] = vm | ((unsigned)(mok && nok) << 31);
         }
 #pragma unroll
-        for (int u = 0; u < WG_UNROLL; ++u)
+        for (int u = 0; u < WG_UNROLL; ++u) {
+            const float a_ = (vmask[u] >> 31) ? av[u] : 0.f;
 #pragma unroll
-            for (int a = 0; a < NACC; ++a)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][a], acc[a], 0, 0, 0);
+            for (int a = 0; a < NACC; ++a) {
+                float v = bv[u][a];
+                if (LD == WG_SEG) v = fmaxf(fmaf(v, xsc[a], xsh[a]), 0.f);
+                else if (LD == WG_3X3) v = fmaxf(fmaf(v, xsc[0], xsh[0]), 0.f);
+                v = ((vmask[u] >> a) & 1) ? v : 0.f;
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, v, acc[a], 0, 0, 0);
+            }
+        }
     }
 
     // ---- block reduction through LDS, then one atomic per element, issued in MEMORY order so that a
