@@ -7,6 +7,7 @@ namespace cunet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MAXSEG = 8;        // segments of one virtual concat (2 inputs + order carried + 1 new)
 constexpr int WAVE = 64;

@@ -272,10 +272,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         const int mc = mok ? m : row_begin;
         {
             const float* src = p.dy + (size_t)mc * p.lddy + acol;
-            if (q.dbg & 2) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) a[t] = 1.f;
-            } else if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+            if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
             else {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) a[t] = ldg1(src + t);
@@ -288,10 +285,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             const int px = rem - py * p.W;
             const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
             const float* src = xbase + (size_t)(xups ? rowU : mc) * xldc;
-            if (q.dbg & 2) {
-#pragma unroll
-                for (int t = 0; t < CT; ++t) x[t] = 1.f;
-            } else if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+            if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
             else {
 #pragma unroll
                 for (int t = 0; t < CT; ++t) x[t] = ldg1(src + t);
@@ -300,6 +294,68 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         ok = mok;
     };
 
+    if constexpr (NTW == 4 && (CT == 2 || CT == 1)) {
+        // ---- counted-vmcnt pipeline.  hipcc drains vmcnt(0) at a loop back-edge, so with compiler-visible loads the
+        // prefetch depth collapses to "whatever was issued in this iteration".  Here the loads are inline asm (invisible
+        // to hipcc's wait bookkeeping) and every slot is awaited with an explicit, COUNTED s_waitcnt: when slot u is
+        // consumed, the 2*(PD-1) loads of the younger slots may stay in flight (loads return in order).  The wait
+        // statement names the slot's registers as read-write operands, which pins every consumer behind it.
+        constexpr int PD = 6;
+        f32x4 A4[PD];
+        f32x2 X2[PD];
+        float X1[PD];
+        bool OK[PD];
+        auto issue_asm = [&](int mm0, f32x4& a4, f32x2& x2, float& x1, bool& ok) {
+            const int m = mm0 + hi;
+            const bool mok = m < row_end;
+            const int mc = mok ? m : row_begin;
+            const float* asrc = p.dy + (size_t)mc * p.lddy + acol;
+            const int nimg = mc / HW;
+            const int rem = mc - nimg * HW;
+            const int py = rem / p.W;
+            const int px = rem - py * p.W;
+            const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+            const float* xsrc = xbase + (size_t)(xups ? rowU : mc) * xldc;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a4) : "v"(asrc) : "memory");
+            if constexpr (CT == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(x2) : "v"(xsrc) : "memory");
+            else asm volatile("global_load_dword %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
+            ok = mok;
+        };
+        int mm = row_begin + 2 * wave;
+#pragma unroll
+        for (int u = 0; u < PD; ++u) issue_asm(mm + u * 8, A4[u], X2[u], X1[u], OK[u]);
+        for (; mm < row_end; mm += PD * 8) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                if constexpr (CT == 2)
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A4[u]), "+v"(X2[u]) : "n"(2 * (PD - 1)) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A4[u]), "+v"(X1[u]) : "n"(2 * (PD - 1)) : "memory");
+                float a[4], x[CT];
+                const bool okk = OK[u];
+                a[0] = (okk && nok) ? A4[u].x : 0.f; a[1] = (okk && nok) ? A4[u].y : 0.f;
+                a[2] = (okk && nok) ? A4[u].z : 0.f; a[3] = (okk && nok) ? A4[u].w : 0.f;
+                if constexpr (CT == 2) {
+                    x[0] = (okk && cok) ? fmaxf(fmaf(X2[u].x, xsc[0], xsh[0]), 0.f) : 0.f;
+                    x[1] = (okk && cok) ? fmaxf(fmaf(X2[u].y, xsc[1], xsh[1]), 0.f) : 0.f;
+                } else {
+                    x[0] = (okk && cok) ? fmaxf(fmaf(X1[u], xsc[0], xsh[0]), 0.f) : 0.f;
+                }
+                issue_asm(mm + (u + PD) * 8, A4[u], X2[u], X1[u], OK[u]);        // refill this slot PD pairs ahead
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < CT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], x[tb], acc[ta][tb], 0, 0, 0);
+            }
+        }
+        // drain: the tail refills are still in flight and own their registers until they land
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            if constexpr (CT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X2[u]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X1[u]) : : "memory");
+        }
+    } else {
     // each wave takes pixel pairs  row_begin + 2*(wave + 4*k); a slot is refilled right after it
     // has been consumed, WG2_PD pairs ahead.  hipcc drains vmcnt(0) at the loop back-edge, so part of
     // the latency is hidden by the second wave on the SIMD (two blocks per CU) rather than by depth.
@@ -319,17 +375,15 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
 #pragma unroll
             for (int t = 0; t < CT; ++t) x[t] = (xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f;
             issue(m0 + (uu + WG2_PD) * stride, av[u], xv[u], xok[u]);       // refill this slot PD pairs ahead
-            if (!(q.dbg & 4)) {
 #pragma unroll
             for (int ta = 0; ta < NTW; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < CT; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], x[tb], acc[ta][tb], 0, 0, 0);
-            } else {
-                acc[0][0][0] += a[0] * x[0];
-            }
         }
     }
+
+    }   // generic (compiler-scheduled) pipeline
 
     // ---- reduce the 4 waves through LDS, then commit in memory order (coalesced atomics)
     float* red = lds;                    // [4][1024]
