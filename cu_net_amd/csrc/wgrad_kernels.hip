@@ -200,13 +200,14 @@ constexpr int WG2_PD = 4;
 struct Wg2Group { int c0; int ct; int chunk0; int nchunks; };   // per channel group
 struct Wg2Args {
     WgradArgs w;
-    int dbg;                 // timing experiments (CUNET_WG_DBG): 2 no operand loads, 4 no MFMA
+    int dbg;                 // unused (timing experiments)
+    int any_ups;             // some segment is read through the nearest-upsample map
     int ngroups;
     Wg2Group grp[12];
     int rows_per_chunk[12];
 };
 
-template <int NTW, int CT>
+template <int NTW, int CT, bool UPS>
 __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int chunk, int rpc, float* lds) {
     const WgradArgs& p = q.w;
     const int tid = threadIdx.x;
@@ -279,12 +280,16 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             }
         }
         {
-            const int nimg = mc / HW;
-            const int rem = mc - nimg * HW;
-            const int py = rem / p.W;
-            const int px = rem - py * p.W;
-            const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
-            const float* src = xbase + (size_t)(xups ? rowU : mc) * xldc;
+            int xrow = mc;
+            if constexpr (UPS) {
+                const int nimg = mc / HW;
+                const int rem = mc - nimg * HW;
+                const int py = rem / p.W;
+                const int px = rem - py * p.W;
+                const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+                xrow = xups ? rowU : mc;
+            }
+            const float* src = xbase + (size_t)xrow * xldc;
             if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
             else {
 #pragma unroll
@@ -310,12 +315,16 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             const bool mok = m < row_end;
             const int mc = mok ? m : row_begin;
             const float* asrc = p.dy + (size_t)mc * p.lddy + acol;
-            const int nimg = mc / HW;
-            const int rem = mc - nimg * HW;
-            const int py = rem / p.W;
-            const int px = rem - py * p.W;
-            const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
-            const float* xsrc = xbase + (size_t)(xups ? rowU : mc) * xldc;
+            int xrow = mc;
+            if constexpr (UPS) {       // ~60 VALU instructions of index math per pixel pair: only for nodes that need it
+                const int nimg = mc / HW;
+                const int rem = mc - nimg * HW;
+                const int py = rem / p.W;
+                const int px = rem - py * p.W;
+                const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+                xrow = xups ? rowU : mc;
+            }
+            const float* xsrc = xbase + (size_t)xrow * xldc;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a4) : "v"(asrc) : "memory");
             if constexpr (CT == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(x2) : "v"(xsrc) : "memory");
             else asm volatile("global_load_dword %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
@@ -424,9 +433,15 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
     const Wg2Group g = q.grp[gi];
     const int chunk = blockIdx.x - g.chunk0;
     const int rpc = q.rows_per_chunk[gi];
-    if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2)>(q, g, chunk, rpc, lds);
-    else if (g.ct == 2) wg2_body<NTW, 2>(q, g, chunk, rpc, lds);
-    else wg2_body<NTW, 1>(q, g, chunk, rpc, lds);
+    if (q.any_ups) {
+        if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), true>(q, g, chunk, rpc, lds);
+        else if (g.ct == 2) wg2_body<NTW, 2, true>(q, g, chunk, rpc, lds);
+        else wg2_body<NTW, 1, true>(q, g, chunk, rpc, lds);
+    } else {
+        if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), false>(q, g, chunk, rpc, lds);
+        else if (g.ct == 2) wg2_body<NTW, 2, false>(q, g, chunk, rpc, lds);
+        else wg2_body<NTW, 1, false>(q, g, chunk, rpc, lds);
+    }
 }
 
 static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) {
@@ -436,6 +451,8 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     q.w.ctw = nocommit ? -1 : 1;
     static const int wdbg = getenv("CUNET_WG_DBG") ? atoi(getenv("CUNET_WG_DBG")) : 0;
     q.dbg = wdbg;
+    q.any_ups = 0;
+    for (int i = 0; i < a.nseg; ++i) q.any_ups |= a.seg[i].ups;
     // channel groups: as many CT=4 (128-channel) groups as fit, then one CT=2 and/or CT=1 remainder
     int c = 0, ng = 0, weight = 0;
     const int C32 = (a.Ccat + 31) / 32;          // 32-channel tiles
