@@ -80,10 +80,11 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
     }
 }
 
-constexpr int CONV_MAX_WAVES = 12;   // 3 waves per SIMD (VGPR budget 168)
+constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
+constexpr int CONV_MAX_WAVES_NT1 = 16;   // one accumulator tile: 4 waves per SIMD (VGPR budget 128)
 
 template <int LD, int EP, int NT, bool FAST>
-__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
+__global__ __launch_bounds__((NT == 1 ? CONV_MAX_WAVES_NT1 : CONV_MAX_WAVES) * 64) void conv_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
     const int kq4 = p.Kpad >> 2;
@@ -231,7 +232,6 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 
         auto mfma_chunk = [&](int ch, const float4 (&acur)[4]) {
             const float4* bb = Bs + (size_t)ch * 8 * NB;     // chunk ch = (tap, c): rows (t*kq4 + c*8) ..+7
-            if (!(p.dbg & 4))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 bv[NT];
@@ -478,12 +478,14 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
         switch (NT) {
             case 1: return launch_inst<LD, EP, 1, (LD != LD_STEM)>(a, grid, threads, smem, s);
             case 2: return launch_inst<LD, EP, 2, (LD != LD_STEM)>(a, grid, threads, smem, s);
+            case 3: return launch_inst<LD, EP, 3, (LD != LD_STEM)>(a, grid, threads, smem, s);
             default: return launch_inst<LD, EP, 4, (LD != LD_STEM)>(a, grid, threads, smem, s);
         }
     }
     switch (NT) {
         case 1: return launch_inst<LD, EP, 1, false>(a, grid, threads, smem, s);
         case 2: return launch_inst<LD, EP, 2, false>(a, grid, threads, smem, s);
+        case 3: return launch_inst<LD, EP, 3, false>(a, grid, threads, smem, s);
         default: return launch_inst<LD, EP, 4, false>(a, grid, threads, smem, s);
     }
 }
@@ -498,17 +500,38 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     const int ntiles = (a.M + 31) / 32;
     const int ncol32 = (a.Nout + 31) / 32;
     const long target = 2L * 4 * num_cus;              // wave-tiles wanted: 2 per SIMD
-    int NT = ncol32 >= 4 ? 4 : (ncol32 >= 2 ? 2 : 1);
-    while (NT > 1 && ((long)ntiles * ((ncol32 + NT - 1) / NT) < target ||
-                      conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET))
-        NT >>= 1;
+    // channel tiles per block.  Every slice of NT tiles re-reads (and re-activates) the A operand and the
+    // last slice is padded with zero tiles, so the cost of a choice is slices * (NT + overhead) tile-times:
+    // a 160-channel dgrad (5 tiles) runs 2 x 3 instead of 2 x 4, a 288-channel one 3 x 3 instead of 3 x 4.
+    static const float nt_ovh = getenv("CUNET_CONV_NT_OVH") ? (float)atof(getenv("CUNET_CONV_NT_OVH")) : 0.3f;
+    int NT = 1;
+    if (nt_ovh < 0.f) {                                  // powers of two only (first version of this launcher)
+        NT = ncol32 >= 4 ? 4 : (ncol32 >= 2 ? 2 : 1);
+        while (NT > 1 && ((long)ntiles * ((ncol32 + NT - 1) / NT) < target ||
+                          conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET))
+            NT >>= 1;
+    } else {
+        float best = 1e30f;
+        static const int nt_max = getenv("CUNET_CONV_NT_MAX") ? atoi(getenv("CUNET_CONV_NT_MAX")) : 4;
+        static const int nt_max_bwd = getenv("CUNET_CONV_NT_MAX_BWD") ? atoi(getenv("CUNET_CONV_NT_MAX_BWD")) : 1;
+        for (int c = (epi == EP_BWD ? nt_max_bwd : nt_max); c >= 1; --c) {
+            if (conv_smem_bytes(c, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET) continue;
+            const int slices = (ncol32 + c - 1) / c;
+            if (c > 1 && (long)ntiles * slices < target) continue;
+            const float cost = slices * ((float)c + nt_ovh);
+            if (cost < best) { best = cost; NT = c; }
+        }
+    }
     const size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat);
     if (smem > CONV_LDS_BUDGET) return hipErrorInvalidValue;   // weights of one 32-channel slice exceed the LDS
     const int gy = (ncol32 + NT - 1) / NT;
     const int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
-    if (waves > CONV_MAX_WAVES / blocks_per_cu) waves = CONV_MAX_WAVES / blocks_per_cu;
+    static const int w1 = getenv("CUNET_CONV_W1") ? atoi(getenv("CUNET_CONV_W1")) : 12;
+    static const int w1b = getenv("CUNET_CONV_W1_BWD") ? atoi(getenv("CUNET_CONV_W1_BWD")) : 12;
+    const int maxw = NT == 1 ? (epi == EP_BWD ? w1b : w1) : CONV_MAX_WAVES;
+    if (waves > maxw / blocks_per_cu) waves = maxw / blocks_per_cu;
     if (waves < 1) waves = 1;
     int gx = (ntiles + waves - 1) / waves;
     if (gx > max_blocks_x) gx = max_blocks_x;
