@@ -84,18 +84,34 @@ struct WgradArgs {
     int IH, IW;
 };
 
-struct BnApplyArgs {       // dX (+)= scale * (dz - mean(dz) - xhat * mean(dz*xhat)) per segment
-    int nseg;
-    int Ccat;
-    Seg seg[MAXSEG];
-    const float* gamma;
-    const float* beta;
-    const float* dz;       // [M][lddz]
-    int lddz;
-    const double* red;     // [2][Ccat]
-    float* dgamma;         // param-grad destinations (written, fp32)
-    float* dbeta;
-    int M, H, W;           // geometry of the concat (full resolution)
+constexpr int MAXGSRC = 8;  // conv consumers gathered per launch (more: further launches with accumulate = 1)
+
+struct GradSrc {           // one conv node that reads the tensor: its BN backward contributes A*dz + E - D*x
+    const float* dz;       // that node's masked data gradient [Mc][lddz] (EP_BWD epilogue of conv_kernel)
+    const double* red;     // that node's reductions [2][lddz]: sum(dz), sum(dz*xhat)
+    const float* gamma;    // that node's BN weight [lddz]
+    int lddz;              // channels of that node's concat
+    int choff;             // where this tensor sits in that concat
+    int ups;               // 1: read through the nearest-upsample map (that node runs at 2H x 2W)
+    int pad_;
+};
+
+struct GradGatherArgs {    // dX = sum_consumers scale*(dz - mean(dz) - xhat*mean(dz*xhat)), written once per tensor
+    int nsrc;
+    int accumulate;        // 0: store, 1: add to what is there
+    GradSrc src[MAXGSRC];
+    const float* x;        // the tensor [rows][ld]
+    float* gx;             // its gradient [rows][ld]
+    const double* stats;   // its batch statistics [2][C]
+    double count;          // rows behind stats
+    int C, ld;
+    int rows, H, W;        // geometry of the tensor itself
+};
+
+constexpr int MAXBNG = 32;
+struct BnParamGradArgs {   // dgamma = sum(dz*xhat), dbeta = sum(dz) for a batch of BatchNorms
+    int n;
+    struct { const double* red; float* dgamma; float* dbeta; int C; int pad_; } e[MAXBNG];
 };
 
 // device-side tables (uploaded once at bind)

@@ -8,7 +8,8 @@ enum WgLoadSel { WGL_SEG = 0, WGL_3X3 = 1, WGL_STEM = 2 };
 
 hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStream_t s);
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
-hipError_t launch_bn_apply(const BnApplyArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_bn_param_grad(const BnParamGradArgs& a, hipStream_t s);
 hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t s);
 hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_stem_bwd(const PoolArgs& a, int pass, float* dgamma, float* dbeta, int num_cus, hipStream_t s);

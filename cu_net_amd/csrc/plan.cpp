@@ -363,6 +363,21 @@ bool Plan::build(const cunet_cfg& c) {
         }
     }
 
+    // ---- backward gather lists: the gradient of a tensor is assembled once, from the dz slices of all
+    //      conv nodes that read it (a pooled tensor gets its gradient from the pool node alone)
+    {
+        std::vector<std::vector<Contrib>> by_t(tensors.size());
+        for (int k = 0; k < (int)nodes.size(); ++k)
+            if (nodes[k].type == N_CONV)
+                for (int j = 0; j < (int)nodes[k].segs.size(); ++j) by_t[nodes[k].segs[j].tensor].push_back({k, j});
+        contribs.clear();
+        for (size_t t = 0; t < tensors.size(); ++t) {
+            tensors[t].cfirst = (int)contribs.size();
+            tensors[t].ccount = (int)by_t[t].size();
+            contribs.insert(contribs.end(), by_t[t].begin(), by_t[t].end());
+        }
+    }
+
     layout_workspace();
     describe();
     return true;
@@ -402,7 +417,10 @@ void Plan::layout_workspace() {
             dzmax = std::max(dzmax, o.rows() * (int64_t)n.Ccat);
         }
     for (auto& t : tensors) t.grad = take(t.rows() * t.ld);
-    dz_off = take(dzmax);
+    dz_off = f;
+    for (auto& n : nodes)
+        if (n.type == N_CONV) n.dz = take(tensors[n.out].rows() * (int64_t)n.Ccat);
+    (void)dzmax;
     const TensorInfo& h0 = tensors[head_tensors[0]];
     target_off = take(h0.rows() * h0.ld);
     n_floats_train = f;

@@ -28,7 +28,10 @@ struct TensorInfo {
     int64_t act = -1;         // float offset in workspace
     int64_t grad = -1;        // float offset in workspace (training)
     int64_t stats = -1;       // double offset in the zeroed region ([2][C]) or -1
+    int cfirst = 0, ccount = 0;   // slice of Plan::contribs: the conv nodes that read this tensor (backward gather)
 };
+
+struct Contrib { int node, seg; };   // node's segs[seg] is the tensor: its dz slice contributes to the tensor's gradient
 
 struct BnInfo {
     std::string name;         // module path, e.g. hg.down_blocks.0.layers.0.norm1
@@ -67,6 +70,7 @@ struct Node {
     int Ccat = 0;             // channels of the concat
     int64_t red = -1;         // double offset in the zeroed region: [2][Ccat] backward reductions
     int bucket = 0;           // gradient bucket this node's parameters live in
+    int64_t dz = -1;          // float offset of this node's own [M][Ccat] dz buffer (training)
 };
 
 struct Plan {
@@ -81,6 +85,7 @@ struct Plan {
     std::vector<BnInfo> bns;
     std::vector<ConvInfo> convs;
     std::vector<Node> nodes;
+    std::vector<Contrib> contribs;
     std::vector<int> head_tensors;   // per output index: tensor id of the NHWC heat map
 
     // workspace layout (bytes)

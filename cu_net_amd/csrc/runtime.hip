@@ -268,6 +268,62 @@ struct Exec {
 
 }  // namespace
 
+// Gradient of tensor `t`: one gather over the dz slices of the conv nodes that read it (all of them have
+// run their data-gradient kernel: they come later in the forward order).  `only_node` >= 0 restricts the
+// gather to one consumer (node-local debugging / tests).
+static int gather_tensor_grad(cunet_plan* h, int t, int only_node, hipStream_t s) {
+    Exec E(h);
+    Plan& P = h->plan;
+    const TensorInfo& ti = P.tensors[t];
+    int accumulate = 0;
+    for (int ups = 0; ups < 2; ++ups) {
+        GradGatherArgs a{};
+        auto flush = [&]() -> int {
+            if (a.nsrc == 0) return CUNET_OK;
+            a.accumulate = accumulate;
+            a.x = E.act(t); a.gx = E.grad(t); a.stats = E.stats(t); a.count = (double)ti.rows();
+            a.C = ti.C; a.ld = ti.ld; a.rows = (int)ti.rows(); a.H = ti.H; a.W = ti.W;
+            PROF(PC_APPLY, 0.0, 4.0 * (double)ti.rows() * ti.C * (2.0 + accumulate + a.nsrc * (ups ? 4.0 : 1.0)),
+                 launch_grad_gather(a, h->num_cus, s));
+            accumulate = 1;
+            a = GradGatherArgs{};
+            return CUNET_OK;
+        };
+        for (int i = 0; i < ti.ccount; ++i) {
+            const Contrib& c = P.contribs[ti.cfirst + i];
+            const Node& n = P.nodes[c.node];
+            if (only_node >= 0 && c.node != only_node) continue;
+            if (n.segs[c.seg].ups != ups) continue;
+            int choff = 0;
+            for (int j = 0; j < c.seg; ++j) choff += P.tensors[n.segs[j].tensor].C;
+            GradSrc& g = a.src[a.nsrc++];
+            g.dz = E.wsf + n.dz; g.red = E.zero + n.red; g.gamma = h->params + P.bns[n.bn].gamma;
+            g.lddz = n.Ccat; g.choff = choff; g.ups = ups; g.pad_ = 0;
+            if (a.nsrc == MAXGSRC) { const int rc = flush(); if (rc != CUNET_OK) return rc; }
+        }
+        const int rc = flush();
+        if (rc != CUNET_OK) return rc;
+    }
+    return CUNET_OK;
+}
+
+// dgamma / dbeta of the conv nodes [k0, k1) with bucket == `bucket` (or every bucket if < 0)
+static int bn_param_grads(cunet_plan* h, int k0, int k1, int bucket, hipStream_t s) {
+    Exec E(h);
+    Plan& P = h->plan;
+    BnParamGradArgs a{};
+    for (int k = k0; k < k1; ++k) {
+        const Node& n = P.nodes[k];
+        if (n.type != N_CONV || (bucket >= 0 && n.bucket != bucket)) continue;
+        const BnInfo& b = P.bns[n.bn];
+        auto& e = a.e[a.n++];
+        e.red = E.zero + n.red; e.dgamma = h->grads + b.gamma; e.dbeta = h->grads + b.beta; e.C = n.Ccat; e.pad_ = 0;
+        if (a.n == MAXBNG) { HIPCHK(launch_bn_param_grad(a, s)); a.n = 0; }
+    }
+    HIPCHK(launch_bn_param_grad(a, s));
+    return CUNET_OK;
+}
+
 // Backward of one node: data gradient (+ReLU mask + BN reductions), weight gradient, BN apply.
 static int bwd_node(cunet_plan* h, const Node& n, int node_index, int force_first, hipStream_t s) {
     Exec E(h);
@@ -281,7 +337,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, int force_firs
     Plan& P = h->plan;
     const int cus = h->num_cus;
     E.force_first = force_first;
-    float* dz = E.wsf + P.dz_off;
+    float* dz = n.dz >= 0 ? E.wsf + n.dz : nullptr;
     const TensorInfo& o = P.tensors[n.out];
     if (n.type == N_CONV) {
         const ConvInfo& c = P.convs[n.conv];
@@ -309,15 +365,6 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, int force_firs
             w.dw = h->grads + c.w;
             PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
                     launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));
-        }
-        {   // BN backward apply into the segments' gradient buffers
-            BnApplyArgs a{};
-            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
-            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-            a.dz = dz; a.lddz = n.Ccat; a.red = red;
-            a.dgamma = h->grads + b.gamma; a.dbeta = h->grads + b.beta;
-            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            PROF(PC_APPLY, 0.0, 4.0 * 4.0 * (double)a.M * a.Ccat, launch_bn_apply(a, cus, s));
         }
     } else if (n.type == N_POOL) {
         const int tin = n.segs[0].tensor;
@@ -511,9 +558,12 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     }
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
+    int bucket_hi = (int)P.nodes.size();                       // nodes [k+1, bucket_hi) belong to cur_bucket
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
+            const int rcg = bn_param_grads(h, k + 1, bucket_hi, cur_bucket, s);
+            if (rcg != CUNET_OK) return rcg;
             if (on_bucket) {
                 if (h->use_side && h->side) {      // ... including the weight gradients on the side stream
                     HIPCHK(hipEventRecord(h->join_ev, h->side));
@@ -522,9 +572,18 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
                 on_bucket(cur_bucket, user);
             }
             cur_bucket = n.bucket;
+            bucket_hi = k + 1;
+        }
+        if (P.tensors[n.out].ccount > 0) {  // d(loss)/d(out): gather from the consumers (heads get theirs from the loss)
+            const int rcg = gather_tensor_grad(h, n.out, -1, s);
+            if (rcg != CUNET_OK) return rcg;
         }
         const int rc = bwd_node(h, n, k, 0, s);
         if (rc != CUNET_OK) return rc;
+    }
+    {
+        const int rcg = bn_param_grads(h, 0, bucket_hi, cur_bucket, s);
+        if (rcg != CUNET_OK) return rcg;
     }
     if (h->use_side && h->side) {
         HIPCHK(hipEventRecord(h->join_ev, h->side));
@@ -617,6 +676,17 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
     const int rc = bwd_node(h, n, node, 1, s);
     if (rc != CUNET_OK) return rc;
+    if (n.type == N_CONV) {                // this node's contribution to each of its inputs, and its BN parameter gradients
+        for (size_t j = 0; j < n.segs.size(); ++j) {
+            bool seen = false;
+            for (size_t i = 0; i < j; ++i) seen |= (n.segs[i].tensor == n.segs[j].tensor);
+            if (seen) continue;
+            const int rcg = gather_tensor_grad(h, n.segs[j].tensor, node, s);
+            if (rcg != CUNET_OK) return rcg;
+        }
+        const int rcg = bn_param_grads(h, node, node + 1, -1, s);
+        if (rcg != CUNET_OK) return rcg;
+    }
     if (h->use_side && h->side) {
         HIPCHK(hipEventRecord(h->join_ev, h->side));
         HIPCHK(hipStreamWaitEvent(s, h->join_ev, 0));
