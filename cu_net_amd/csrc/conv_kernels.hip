@@ -449,6 +449,149 @@ __global__ __launch_bounds__((NT == 1 ? CONV_MAX_WAVES_NT1 : CONV_MAX_WAVES) * 6
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 forward, tap-split (models/cu_net.py:45-48,62: norm2 -> relu2 -> conv2, 128 -> 32 channels).
+// The weight-stationary kernel above walks all 9 taps x K/32 chunks in ONE wave: 36 dependent
+// load -> MFMA steps, ~40 us whatever the resolution (14 of the 18 3x3 launches of a CU-Net-2 step sit on
+// that floor).  Here a block is 9 waves and wave t owns tap t: its slice of the weights (K x 32) lives in
+// REGISTERS for the whole launch (no LDS operand at all), every lane issues the K/8 16-byte loads of its
+// shifted row together, contracts them in K/2 MFMAs, and the nine partial 32x32 tiles meet in LDS, where
+// eight waves add them, store the tile and keep the per-channel batch statistics.  The loads of the next
+// tile are in flight across the reduction.
+template <int NCK>       // K = 32 * NCK input channels
+__global__ __launch_bounds__(576) void conv3x3_tapsplit_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 32 * NCK;
+    float* part = reinterpret_cast<float*>(smem);                 // [9][1024] partial tiles
+    float* sc = part + 9 * 1024;                                  // [K]
+    float* sh = sc + K;                                           // [K]
+    double* redbuf = reinterpret_cast<double*>(sh + K);           // [32][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int tap = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const Seg sg = p.seg[0];
+
+    for (int c = tid; c < K; c += 576) {
+        double mean, istd;
+        if (p.training) {
+            mean = sg.stats[c] / sg.count;
+            double var = sg.stats[sg.C + c] / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            istd = 1.0 / sqrt(var + (double)BN_EPS);
+        } else {
+            mean = (double)p.rmean[c];
+            istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+        }
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+    }
+    if (tid < 64) redbuf[tid] = 0.0;
+
+    // this wave's tap of the packed weights [tap][K/4][Npad][4]: element (k = 32c + 8q + 4hi + j, n = li).
+    // The first half of K stays in registers, the second half in LDS (64 + 64 registers of operands would spill).
+    constexpr int NR = NCK * 2;                                   // 16-byte pieces kept in registers
+    float4 bw[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        bw[i] = ldg4(p.wB + ((size_t)(tap * (K / 4) + 2 * i + hi) * p.Npad + li) * 4);
+    float4* bl = reinterpret_cast<float4*>(redbuf + 64) + tap * (NR * 64);   // [9][NR][64] float4
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        bl[i * 64 + lane] = ldg4(p.wB + ((size_t)(tap * (K / 4) + 2 * (NR + i) + hi) * p.Npad + li) * 4);
+    __syncthreads();
+    const int HW = p.H * p.W;
+    const int ntiles = p.M >> 5;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    float4 a[NCK * 4];
+    bool valid = false;
+    auto fetch = [&](int tile) {                      // raw loads of this wave's shifted rows (always a valid address)
+        const int m = tile * 32 + li;
+        const int nimg = m / HW;
+        const int rem = m - nimg * HW;
+        const int py = rem / p.W;
+        const int px = rem - py * p.W;
+        const int yy = py + dy, xx = px + dx;
+        valid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+        const float* src = sg.x + (size_t)(valid ? m + dy * p.W + dx : m) * sg.ld + 4 * hi;
+#pragma unroll
+        for (int i = 0; i < NCK * 4; ++i) a[i] = ldg4(src + i * 8);
+    };
+    double dsum = 0.0, dsq = 0.0;
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {        // block-uniform trip count
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bool v = valid;
+#pragma unroll
+        for (int i = 0; i < NCK * 4; ++i) {
+            float4 t = a[i];
+            const float4 s4 = *reinterpret_cast<const float4*>(sc + i * 8 + 4 * hi);
+            const float4 h4 = *reinterpret_cast<const float4*>(sh + i * 8 + 4 * hi);
+            t.x = v ? fmaxf(fmaf(t.x, s4.x, h4.x), 0.f) : 0.f;            // zero padding is post-activation
+            t.y = v ? fmaxf(fmaf(t.y, s4.y, h4.y), 0.f) : 0.f;
+            t.z = v ? fmaxf(fmaf(t.z, s4.z, h4.z), 0.f) : 0.f;
+            t.w = v ? fmaxf(fmaf(t.w, s4.w, h4.w), 0.f) : 0.f;
+            const float4 b = i < NR ? bw[i < NR ? i : 0] : bl[(i - NR) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w, b.w, acc, 0, 0, 0);
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);               // in flight across the reduction below
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[tap * 1024 + r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (tid < 512) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + 512 * u;
+                float vsum = part[e];
+#pragma unroll
+                for (int w = 1; w < 9; ++w) vsum += part[w * 1024 + e];
+                const int r = e >> 6;                 // C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                p.y[(size_t)(tile * 32 + row) * p.ldy + li] = vsum;
+                dsum += (double)vsum;
+                dsq += (double)vsum * (double)vsum;
+            }
+        }
+        __syncthreads();
+    }
+    if (p.ystats != nullptr) {
+        const double a1 = dsum + shfl_xor_d(dsum, 32);
+        const double b1 = dsq + shfl_xor_d(dsq, 32);
+        for (int w = 0; w < 8; ++w) {
+            if (tap == w && hi == 0) { redbuf[li * 2 + 0] += a1; redbuf[li * 2 + 1] += b1; }
+            __syncthreads();
+        }
+        if (tid < 32 && tid < p.Nout) {
+            atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
+            atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
+        }
+    }
+}
+
+static hipError_t launch_conv3x3_tapsplit(const ConvArgs& a, int num_cus, hipStream_t s) {
+    const int ntiles = a.M / 32;
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    const size_t smem = (size_t)9 * 1024 * 4 + (size_t)a.K * 8 + 64 * 8 + (size_t)9 * (a.K / 16) * 64 * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tapsplit_kernel<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_tapsplit_kernel<4>, dim3(grid), dim3(576), smem, s, a);
+    return hipGetLastError();
+}
+
 static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
     size_t b = (size_t)taps * (Kpad / 4) * NT * 32 * 16;   // resident B operand
     b += (size_t)(Ccat / 4) * sizeof(GrpEnt);              // group table
@@ -494,6 +637,10 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
 // and its weights fit the LDS, fewer when there are too few 32-row tiles to fill the chip), the
 // waves per block and the grid.
 hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
+    static const int use_ts = getenv("CUNET_CONV_TS") ? atoi(getenv("CUNET_CONV_TS")) : 1;
+    if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
+        a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups)
+        return launch_conv3x3_tapsplit(a_in, num_cus, s);
     static const int dbg = getenv("CUNET_CONV_DBG") ? atoi(getenv("CUNET_CONV_DBG")) : 0;
     ConvArgs a = a_in;
     a.dbg = dbg;
