@@ -639,7 +639,8 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
 hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
     static const int use_ts = getenv("CUNET_CONV_TS") ? atoi(getenv("CUNET_CONV_TS")) : 1;
     if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
-        a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups)
+        a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups &&
+        a_in.M / 32 <= use_ts * 4 * num_cus)      // beyond ~4 tiles per CU the barrier-free kernel is ahead (93 vs 106 us at 64x64, bs 24)
         return launch_conv3x3_tapsplit(a_in, num_cus, s);
     static const int dbg = getenv("CUNET_CONV_DBG") ? atoi(getenv("CUNET_CONV_DBG")) : 0;
     ConvArgs a = a_in;

@@ -202,6 +202,29 @@ def test_full_width_matches_reference():
         assert abs(got - nrm) <= 5e-2 * nrm + 1e-9, (k, got, nrm)   # whole-net fp32 gradients: sanity bound only
 
 
+def test_full_width_eval_forward_matches_oracle():
+    """Inference path at full width (running statistics, every full-width kernel variant incl. the tap-split 3x3):
+    HIP eval forward vs the oracle's eval forward on the same state, after one training step moved the
+    running statistics away from their initial values.  N=2 so that the 8x8 and 4x4 levels have several tiles."""
+    g = Golden('G5_full_L2K68')
+    spec = O.Spec(**g.cfg)
+    st = O.init_state(spec, seed=int(g.z['init_seed']))
+    x, target = O.synthetic_batch(2, spec.class_num, 256, seed=7)
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(st)
+    net.cuda().train()
+    FusedTrainer(net).step(x.cuda(), target.cuda())
+    st1 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    net.eval()
+    with torch.no_grad():
+        outs = net(x.cuda())
+    refs = O.forward(spec, st1, x, training=False)
+    assert len(outs) == len(refs)
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        err = (o.cpu() - r).abs().max().item()
+        assert err <= RTOL_ACT * r.abs().max().item() + ATOL, (i, err, r.abs().max().item())
+
+
 def test_get_preds_bit_exact():
     torch.manual_seed(3)
     s = torch.randn(3, 5, 64, 64)
