@@ -179,6 +179,19 @@ def main():
             roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS,
                     'unit': 'GB/s', 'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
                     'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
+        # HBM bytes per launch of that kernel class from the committed PMC passes (rocprofv3 --pmc cannot run inside
+        # this process): profiles/r01_traffic.json, produced by tools/profile_round.sh + tools/pmc_traffic.py on
+        # this workload.  null when the file has no entry for the class or the workload is not the profiled one.
+        try:
+            if (L, K, bs) == (2, 68, 24):
+                tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')))
+                ent = tj['classes'].get(dominant)
+                if ent:
+                    roof['traffic'] = ent['hbm_bytes_per_launch']
+                    roof['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)'
+                    roof['algorithmic_bytes_per_launch'] = round(by / max(cnt, 1))
+        except Exception:
+            pass
         out = {
             'metric': 'images/sec train step, 256x256x3 -> 64x64xK heatmaps, CU-Net-%d' % L,
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

@@ -1,0 +1,59 @@
+"""HBM traffic per launch and kernel class from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
+
+usage: pmc_traffic.py <dir of the --pmc FETCH_SIZE run> <dir of the --pmc WRITE_SIZE run> <out.json>
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KiB; on gfx950
+FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B, so it is doubled.
+WRITE_SIZE is taken as reported (uncalibrated).  Classes are the ones bench.py's `roofline.kernel` names.
+"""
+import glob
+import json
+import re
+import sys
+
+import pandas as pd
+
+CLASSES = [
+    (r'wgrad2_kernel', 'conv1x1_bwd_weight'),
+    (r'wgrad_kernel<\(?cunet::\)?1|wgrad_kernel<1,', 'conv3x3_bwd_weight'),
+    (r'wgrad_kernel<2,', 'stem_bwd_weight'),
+    (r'conv3x3_tapsplit_kernel', 'conv3x3_fwd'),
+    (r'conv_kernel<0, 0,', 'conv1x1_fwd'),
+    (r'conv_kernel<1, 0,', 'conv3x3_fwd'),
+    (r'conv_kernel<4, 0,', 'stem_conv_fwd'),
+    (r'conv_kernel<2, 1,', 'conv1x1_bwd_data'),
+    (r'conv_kernel<3, 1,', 'conv3x3_bwd_data'),
+    (r'grad_gather_kernel', 'bn_bwd_apply'),
+    (r'pool_fwd_kernel<0>', 'pool_fwd'),
+    (r'pool_bwd_kernel', 'pool_bwd'),
+]
+
+
+def classify(name):
+    for pat, cls in CLASSES:
+        if re.search(pat, name):
+            return cls
+    return None
+
+
+def load(d, counter):
+    cc = pd.read_csv(glob.glob(d + '/*counter_collection.csv')[0])
+    cc = cc[cc.Counter_Name == counter].copy()
+    cc['name'] = cc['Kernel_Name'].str.replace('cunet::', '').str.replace(r'\(.*', '', regex=True).str.replace('void ', '')
+    cc['cls'] = cc['name'].map(classify)
+    cc = cc[cc.cls.notna()]
+    return cc.groupby('cls').Counter_Value.agg(['mean', 'size'])
+
+
+rd = load(sys.argv[1], 'FETCH_SIZE')
+wr = load(sys.argv[2], 'WRITE_SIZE')
+out = {}
+for cls in rd.index:
+    f = float(rd.loc[cls, 'mean']) * 1024.0 * 2.0
+    w = float(wr.loc[cls, 'mean']) * 1024.0 if cls in wr.index else 0.0
+    out[cls] = {'launches_sampled': int(rd.loc[cls, 'size']), 'fetch_bytes_per_launch': round(f),
+                'write_bytes_per_launch': round(w), 'hbm_bytes_per_launch': round(f + w)}
+json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE (KiB, x2 on gfx950) and --pmc WRITE_SIZE (KiB), separate passes, '
+                     'bench.py --steps 3 --warmup 2', 'classes': out}, open(sys.argv[3], 'w'), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch']):
+    print(f"{k:22s} fetch {v['fetch_bytes_per_launch'] / 1e6:9.2f} MB  write {v['write_bytes_per_launch'] / 1e6:9.2f} MB  per launch ({v['launches_sampled']} launches)")

@@ -19,3 +19,5 @@ python tools/trace_summary.py $(ls gpurun_out/prof_$TAG/*kernel_trace.csv | head
 python tools/pmc_summary.py gpurun_out/pmc_${TAG}_rd '' 40 > gpurun_out/pmc_${TAG}_rd.txt 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_${TAG}_wr '' 40 > gpurun_out/pmc_${TAG}_wr.txt 2>&1
 head -30 gpurun_out/prof_${TAG}_by_grid.txt
+python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr gpurun_out/traffic_$TAG.json > gpurun_out/traffic_$TAG.txt 2>&1
+cat gpurun_out/traffic_$TAG.txt
