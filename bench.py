@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default='')
+    ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,7 +112,11 @@ def main():
     net = cu_net_amd.create_cu_net(neck_size=4, growth_rate=32, init_chan_num=128, class_num=K,
                                    layer_num=L, order=1, loss_num=L).to(dev)
     net.train()
-    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg)
+    quan = None
+    if args.bits_w > 0:
+        from cu_net_amd.quant import QuanOp
+        quan = QuanOp(net, bits_w=args.bits_w, bits_i=8, bits_g=8)
+    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan)
     tr.broadcast_parameters(0)
     x, t = synthetic_batch(bs, K, 256, seed=1000 + rank, device=dev)
 
@@ -198,7 +203,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
-                                   'fp32 train step (fwd + MSE + bwd + RMSprop'
+                                   + (f'QuanOp bits_w={args.bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if args.bits_w > 0 else '')
+                                   + 'fp32 train step (fwd + MSE + bwd + RMSprop'
                                    + (' + RCCL bucketed grad all-reduce)' if world > 1 else ')'),
                        'global_batch': world * bs, 'parallelism': f'dp{world}'},
             'roofline': roof,
