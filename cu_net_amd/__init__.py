@@ -5,8 +5,8 @@
 Public surface mirrors the reference (zhiqiangdon/CU-Net):
     create_cu_net(neck_size, growth_rate, init_chan_num, class_num, layer_num, order, loss_num)
 plus the fused train step (`FusedTrainer`), data parallelism over RCCL (`cu_net_amd.parallel`),
-the landmark decode (`get_preds`) and the weight quantisers (`cu_net_amd.quant`).
+the validation-loop pieces (`get_preds`, `final_preds`, `flip_merge`, `accuracy`) and the weight quantisers (`cu_net_amd.quant`).
 """
 from ._lib import CUNetError, LIB_PATH  # noqa: F401
 from .module import CUNet, create_cu_net  # noqa: F401
-from .trainer import FusedTrainer, final_preds, get_preds  # noqa: F401
+from .trainer import FusedTrainer, accuracy, accuracy_origin_res, final_preds, flip_merge, get_preds  # noqa: F401

@@ -728,4 +728,30 @@ hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, in
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flip test-time augmentation (cu-net.py:240-249): average the heat maps of an image with the
+// un-flipped, channel-swapped heat maps of its mirror image.  One row of W floats per thread group.
+__global__ __launch_bounds__(256) void flip_merge_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const int* __restrict__ perm, float* __restrict__ out,
+                                                          int K, int H, int W, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const long row = idx / W;                  // (n*K + c)*H + y
+        const int y = (int)(row % H);
+        const long nc = row / H;
+        const int c = (int)(nc % K);
+        const long n = nc / K;
+        const long src = ((n * K + perm[c]) * H + y) * (long)W + (W - 1 - x);
+        out[idx] = (a[idx] + b[src]) / 2.0f;
+    }
+}
+
+hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, float* out, int N, int K, int H, int W, hipStream_t s) {
+    const long total = (long)N * K * H * W;
+    long gx = (total + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(flip_merge_kernel, dim3((unsigned)gx), dim3(256), 0, s, a, b, perm, out, K, H, W, total);
+    return hipGetLastError();
+}
+
 }  // namespace cunet

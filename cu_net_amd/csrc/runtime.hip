@@ -620,6 +620,13 @@ int cunet_final_preds(const float* heat, const float* center, const float* scale
     return CUNET_OK;
 }
 
+int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float* out, int n, int k, int hh, int w,
+                     void* stream) {
+    if (!a || !b || !perm || !out || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_flip_merge(a, b, perm, out, n, k, hh, w, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
 static int device_cus() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;

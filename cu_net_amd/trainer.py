@@ -116,3 +116,69 @@ def final_preds(output: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
     check(lib().cunet_final_preds(_ptr(s), _ptr(c), _ptr(sc), _ptr(preds), n, k, h, w, int(res[0]), int(res[1]),
                                   _stream_ptr(dev)), 'cunet_final_preds')
     return preds
+
+
+def flip_merge(out1: torch.Tensor, out2: torch.Tensor, flip_indxs) -> torch.Tensor:
+    """Flip test-time augmentation of the validation loop (cu-net.py:240-249) on the GPU:
+    `(out1 + shuffle_channels_for_horizontal_flipping(flip_channels(out2), flip_indxs)) / 2`
+    (pylib/HumanAug.py:177-208), where out2 = net(img flipped along the width).  N x K x H x W."""
+    if not (out1.is_cuda and out2.is_cuda):
+        raise CUNetError('flip_merge: GPU tensors required (the CPU oracle is oracle/decode_ref.py)')
+    a = out1.contiguous().float()
+    b = out2.contiguous().float()
+    if a.shape != b.shape or a.dim() != 4:
+        raise CUNetError('flip_merge: two N x K x H x W tensors of equal shape expected')
+    n, k, h, w = a.shape
+    perm = list(range(k))
+    for p in flip_indxs:                              # the reference swaps the pairs one after the other
+        i1, i2 = int(p[0]), int(p[1])
+        perm[i1], perm[i2] = perm[i2], perm[i1]
+    pd = torch.tensor(perm, dtype=torch.int32, device=a.device)
+    out = torch.empty_like(a)
+    check(lib().cunet_flip_merge(_ptr(a), _ptr(b), _ptr(pd), _ptr(out), n, k, h, w, _stream_ptr(a.device)), 'cunet_flip_merge')
+    return out
+
+
+def _calc_dists(preds: torch.Tensor, target: torch.Tensor, normalize: torch.Tensor, use_zero: bool) -> torch.Tensor:
+    """pylib/Evaluation.py:24-39 without the N x K python loop: K x N, -1 where the ground truth is missing.
+    Coordinates are integer valued, so the fp32 distance is the same number on either device."""
+    boundary = 0 if use_zero else 1
+    d = (preds.float() - target.float()).pow(2).sum(-1).sqrt() / normalize.float().view(-1, 1)
+    ok = (target[..., 0] > boundary) & (target[..., 1] > boundary)
+    return torch.where(ok, d, torch.full_like(d, -1.0)).t().contiguous()
+
+
+def _acc_from_dists(dists: torch.Tensor, idxs, thr: float) -> torch.Tensor:
+    """pylib/Evaluation.py:41-53,69-83 on a K x N distance matrix; returns the reference's CPU vector
+    [mean over the joints that have ground truth, per-joint accuracies (or -1)]."""
+    sel = dists[torch.as_tensor(list(idxs), dtype=torch.long, device=dists.device)]
+    valid = sel.ne(-1)
+    nvalid = valid.sum(1)
+    hit = sel.le(thr).eq(valid).sum(1).float()
+    per = torch.where(nvalid > 0, hit / nvalid.clamp(min=1).float(), torch.full_like(hit, -1.0))
+    acc = torch.zeros(len(idxs) + 1)
+    per_cpu = per.cpu()
+    acc[1:] = per_cpu
+    has = per_cpu >= 0
+    if bool(has.any()):
+        avg = torch.zeros(())
+        for v in per_cpu[has]:                        # same left-to-right fp32 sum as the reference's loop
+            avg = avg + v
+        acc[0] = avg / int(has.sum())
+    return acc
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, idxs, thr: float = 0.5) -> torch.Tensor:
+    """pylib/Evaluation.py:55-83 (PCK on heat-map resolution) with the arg-max decode and distances on the GPU."""
+    preds, gts = get_preds(output), get_preds(target)
+    norm = torch.ones(preds.size(0), device=preds.device) * output.size(3) / 10
+    return _acc_from_dists(_calc_dists(preds, gts, norm, False), idxs, thr)
+
+
+def accuracy_origin_res(output: torch.Tensor, center, scale, res, grnd_pts, normalizers, rot=None) -> torch.Tensor:
+    """pylib/Evaluation.py:86-106 (PCKh in original-image coordinates; the reference's fixed MPII joint list)."""
+    idxs = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15]
+    pred_pts = final_preds(output, center, scale, res, rot)
+    dev = pred_pts.device
+    dists = _calc_dists(pred_pts, torch.as_tensor(grnd_pts).to(dev), torch.as_tensor(normalizers).to(dev), True)
+    return _acc_from_dists(dists, idxs, 0.5)

@@ -164,6 +164,14 @@ int cunet_profile_get(const cunet_plan_t* plan, int cls, int64_t* count, double*
 int cunet_final_preds(const float* heat, const float* center, const float* scale, float* preds, int n, int k,
                       int h, int w, int res0, int res1, void* stream);
 
+/* flip test-time augmentation merge: replaces cu-net.py:247-249 + pylib/HumanAug.py:177-208
+ * (flip_channels, shuffle_channels_for_horizontal_flipping), which the reference runs on the CPU:
+ *   out[n][c][y][x] = (a[n][c][y][x] + b[n][perm[c]][y][w-1-x]) / 2
+ * a = heat maps of the image, b = heat maps of the horizontally flipped image, perm = channel
+ * permutation built from the flip index pairs (int32[k], device).  All N x K x H x W fp32 NCHW, device. */
+int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float* out, int n, int k, int hh, int w,
+                     void* stream);
+
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);
  * negative if unknown. Names are those listed by cunet_plan_describe. */

@@ -81,3 +81,56 @@ def final_preds(output: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
         pts = transform_pts(coords[i].numpy(), center[i].numpy(), scale[i].numpy(), float(rot[i]), res[0], size=200, invert=1)
         preds[i] = torch.from_numpy(pts)
     return preds
+
+
+# ---- flip test-time augmentation and PCK accuracy (validation loop, cu-net.py:240-258) -----------------
+def flip_merge(out1: torch.Tensor, out2: torch.Tensor, flip_indxs) -> torch.Tensor:
+    """(output1 + shuffle(flip(output2))) / 2 -- cu-net.py:247-249 with pylib/HumanAug.py:196-208
+    (flip_channels: reverse the width axis) and :177-194 (shuffle_channels_for_horizontal_flipping:
+    swap the channel pairs of `flip_indxs`, in order)."""
+    m = out2.flip(3).clone()
+    for idx1, idx2 in [tuple(int(v) for v in p) for p in flip_indxs]:
+        tmp = m[:, idx1].clone()
+        m[:, idx1] = m[:, idx2]
+        m[:, idx2] = tmp
+    return (out1 + m) / 2
+
+
+def calc_dists(preds: torch.Tensor, target: torch.Tensor, normalize: torch.Tensor, use_zero: bool = False) -> torch.Tensor:
+    """pylib/Evaluation.py:24-39: K x N distances, -1 where the ground truth is missing (coordinate <= boundary)."""
+    preds, target, normalize = preds.float(), target.float(), normalize.float()
+    dists = torch.zeros(preds.size(1), preds.size(0))
+    boundary = 0 if use_zero else 1
+    for n in range(preds.size(0)):
+        for c in range(preds.size(1)):
+            if target[n, c, 0] > boundary and target[n, c, 1] > boundary:
+                dists[c, n] = torch.dist(preds[n, c, :], target[n, c, :]) / normalize[n]
+            else:
+                dists[c, n] = -1
+    return dists
+
+
+def dist_acc(dists: torch.Tensor, thr: float = 0.5):
+    """pylib/Evaluation.py:41-53 (NB `le(thr).eq(ne(-1))`: a -1 entry counts as a hit of the numerator's
+    equality test only when both sides are False, i.e. never -- but a valid entry ABOVE thr does not, and
+    a -1 entry is `le(thr)` yet `ne(-1)` False, so it is not counted either)."""
+    if dists.ne(-1).sum() > 0:
+        return dists.le(thr).eq(dists.ne(-1)).sum().float() / dists.ne(-1).sum().float()
+    return -1
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, idxs, thr: float = 0.5) -> torch.Tensor:
+    """pylib/Evaluation.py:55-83."""
+    preds, gts = get_preds(output), get_preds(target)
+    norm = torch.ones(preds.size(0)) * output.size(3) / 10
+    dists = calc_dists(preds, gts, norm)
+    acc = torch.zeros(len(idxs) + 1)
+    avg_acc, cnt = 0, 0
+    for i in range(len(idxs)):
+        acc[i + 1] = dist_acc(dists[idxs[i]], thr)
+        if acc[i + 1] >= 0:
+            avg_acc = avg_acc + acc[i + 1]
+            cnt += 1
+    if cnt != 0:
+        acc[0] = avg_acc / cnt
+    return acc

@@ -251,3 +251,36 @@ def test_decode_matches_reference_vectors():
     fp = cu_net_amd.final_preds(hm, torch.from_numpy(z['center']), torch.from_numpy(z['scale']), [64, 64],
                                 torch.zeros(hm.shape[0]))
     assert torch.equal(fp.cpu(), torch.from_numpy(z['final_preds']))
+
+
+def test_flip_merge_and_accuracy_bit_exact():
+    """Validation-loop pieces on the GPU vs the reference's vectors (G10) and the oracle: flip-TTA merge is
+    bit-exact ((a + b) / 2 in fp32), PCK accuracy is exact (integer coordinates, IEEE sqrt / divide)."""
+    import numpy as np
+    from oracle import decode_ref as DR
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G10_tta_accuracy.npz'))
+    o1, o2, tgt = (torch.from_numpy(z[k]) for k in ('out1', 'out2', 'target'))
+    m = cu_net_amd.flip_merge(o1.cuda(), o2.cuda(), z['flip_index'])
+    assert torch.equal(m.cpu(), DR.flip_merge(o1, o2, z['flip_index']))
+    assert torch.equal(m.cpu()[:, :, ::4, ::4], torch.from_numpy(z['merged_sub']))
+    acc = cu_net_amd.accuracy(m, tgt.cuda(), z['idxs'].tolist())
+    assert torch.equal(acc, torch.from_numpy(z['accuracy']))
+    # original-resolution PCKh against the oracle's composition of final_preds + calc_dists + dist_acc
+    z8 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G8_decode.npz'))
+    hm, center, scale = (torch.from_numpy(z8[k]) for k in ('heat', 'center', 'scale'))
+    gen = torch.Generator().manual_seed(3)
+    fp = DR.final_preds(hm, center, scale, [64, 64], torch.zeros(hm.shape[0]))
+    gt = fp + torch.randint(-6, 7, fp.shape, generator=gen).float()
+    gt[0, 2] = 0.0                                          # missing joint
+    normalizers = torch.rand(hm.shape[0], generator=gen) * 30 + 20
+    idxs = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15]
+    d = DR.calc_dists(fp, gt, normalizers, use_zero=True)
+    ref = torch.zeros(len(idxs) + 1)
+    avg, cnt = 0, 0
+    for i, j in enumerate(idxs):
+        ref[i + 1] = DR.dist_acc(d[j])
+        if ref[i + 1] >= 0:
+            avg = avg + ref[i + 1]; cnt += 1
+    ref[0] = avg / cnt
+    got = cu_net_amd.accuracy_origin_res(hm.cuda(), center, scale, [64, 64], gt, normalizers)
+    assert torch.equal(got, ref), (got, ref)

@@ -44,3 +44,19 @@ def test_ternary_reference_is_exact_in_fp32():
     w = torch.randint(-1, 2, (8, 64, 3, 3), generator=g).float()
     y = QR.ternary_conv_reference(x, sc, sh, w, 8, 1)
     assert torch.equal(y * 128, torch.round(y * 128))                  # multiples of 2^-7
+
+
+def test_flip_merge_and_accuracy_match_reference_vectors():
+    """G10: flip-TTA merge (cu-net.py:247-249) and PCK accuracy (pylib/Evaluation.py:55-83) of the oracle
+    against vectors produced by the reference's own functions (tools/gen_golden.py --only tta)."""
+    import numpy as np
+    import os
+    import torch
+    from oracle import decode_ref as DR
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G10_tta_accuracy.npz'))
+    o1, o2, tgt = (torch.from_numpy(z[k]) for k in ('out1', 'out2', 'target'))
+    m = DR.flip_merge(o1, o2, z['flip_index'])
+    assert torch.equal(m[:, :, ::4, ::4], torch.from_numpy(z['merged_sub']))
+    acc = DR.accuracy(m, tgt, z['idxs'].tolist())
+    assert torch.equal(acc, torch.from_numpy(z['accuracy']))
+    assert float(acc[7]) == -1.0          # the joint without ground truth anywhere

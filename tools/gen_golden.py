@@ -305,9 +305,58 @@ def decode_parity():
     print('G8: get_preds / final_preds on 4x16 maps: oracle == reference')
 
 
+
+def tta_accuracy_parity():
+    """G10: flip test-time-augmentation merge (pylib/HumanAug.py flip_channels + shuffle_channels_for_horizontal_flipping,
+    cu-net.py:247-249) and PCK accuracy (pylib/Evaluation.py accuracy / calc_dists / dist_acc).  HumanAug.py does not
+    import under scipy >= 1.3 (scipy.misc), so its two pure-numpy/torch functions are compiled from the reference
+    file's AST in memory; Evaluation.py is executed whole as in G8."""
+    import ast
+    from oracle import decode_ref as DR
+    sys.modules.setdefault('HumanAug', types.ModuleType('HumanAug'))
+    ev = types.ModuleType('ref_evaluation')
+    exec(compile(open(os.path.join(REF, 'pylib', 'Evaluation.py')).read(), '<reference pylib/Evaluation.py>', 'exec'), ev.__dict__)
+    import re
+    hsrc = open(os.path.join(REF, 'pylib', 'HumanAug.py')).read()
+    hsrc = re.sub(r"(?m)^(\s*)print (.+)$", r"\1print(\2)", hsrc)      # py2 print statements elsewhere in the file
+    tree = ast.parse(hsrc)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('flip_channels', 'shuffle_channels_for_horizontal_flipping')]
+    assert len(keep) == 2
+    ha = types.ModuleType('ref_humanaug_subset')
+    ha.__dict__.update(np=np, torch=torch)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), '<reference pylib/HumanAug.py subset>', 'exec'), ha.__dict__)
+    flip_index = np.array([[1, 4], [0, 5], [12, 13], [11, 14], [10, 15], [2, 3]])      # cu-net.py:34-35
+    g = torch.Generator().manual_seed(9)
+    n, k = 3, 16
+    o1 = torch.randint(-64, 64, (n, k, 64, 64), generator=g).float() / 1024      # 7-bit noise: keeps the fixture small
+    o2 = torch.randint(-64, 64, (n, k, 64, 64), generator=g).float() / 1024
+    tgt = torch.zeros(n, k, 64, 64)
+    for a in range(n):
+        for b in range(k):
+            cy, cx = int(torch.randint(2, 62, (1,), generator=g)), int(torch.randint(2, 62, (1,), generator=g))
+            tgt[a, b, cy, cx] = 1.0
+            dy, dx = int(torch.randint(-4, 5, (1,), generator=g)), int(torch.randint(-4, 5, (1,), generator=g))
+            o1[a, b, min(max(cy + dy, 0), 63), min(max(cx + dx, 0), 63)] += 1.0
+            o2[a, b, min(max(cy + dy, 0), 63), 63 - min(max(cx + dx, 0), 63)] += 0.7
+    tgt[0, 3] = 0.0                                   # missing joint -> get_preds 0 -> dist -1
+    tgt[1, 7] = 0.0; tgt[1, 7, 0, 0] = 1.0            # ground truth at (1,1): not > 1 -> -1
+    tgt[:, 9] = 0.0                                   # a joint missing everywhere -> dist_acc -1
+    ref_m = (o1 + ha.shuffle_channels_for_horizontal_flipping(ha.flip_channels(o2.clone()), flip_index)) / 2
+    check('G10/flip_merge', ref_m, DR.flip_merge(o1, o2, flip_index))
+    idxs = [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15]
+    ref_acc = ev.accuracy(ref_m, tgt, idxs)
+    check('G10/accuracy', ref_acc, DR.accuracy(ref_m, tgt, idxs))
+    np.savez_compressed(os.path.join(OUT, 'G10_tta_accuracy.npz'), out1=to_np(o1), out2=to_np(o2), target=to_np(tgt),
+                        flip_index=flip_index, idxs=np.array(idxs), merged_sub=to_np(ref_m[:, :, ::4, ::4]), accuracy=to_np(ref_acc))
+    print('G10: flip-TTA merge and PCK accuracy: oracle == reference')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[1] == '--only':       # regenerate one fixture
+        {'decode': decode_parity, 'tta': tta_accuracy_parity}[sys.argv[2]]()
+        return
     ref = load_reference_models()
     tiny = dict(neck_size=2, growth_rate=4, init_chan_num=8)
     one_config(ref, 'G1_L2_o1', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=2, hw=128, seed=11)
@@ -323,6 +372,7 @@ def main():
     init_parity(ref)
     quant_parity(ref, load_reference_quantize())
     decode_parity()
+    tta_accuracy_parity()
 
 
 if __name__ == '__main__':
