@@ -98,9 +98,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run even one rank goes through RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
@@ -122,7 +123,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if pg is not None:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -162,7 +163,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = plan.handle.profile_collect()
     plan.handle.profile_begin(0)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -220,7 +220,16 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
     HIPCHK(hipStreamSynchronize(s));
     if (training && !h->side) {
         h->use_side = getenv("CUNET_NO_SIDE_STREAM") ? 0 : 1;
-        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        // HIP multiplexes streams onto a few hardware queues; a same-priority side stream can land on the queue of the
+        // caller's stream and then nothing overlaps (seen once RCCL had created its own streams).  A different
+        // priority gets its own queue; the weight gradients are off the critical path, so: lowest priority.
+        {
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int mode = getenv("CUNET_SIDE_PRIO") ? atoi(getenv("CUNET_SIDE_PRIO")) : 1;
+            if (mode == 0) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            else HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, mode == 1 ? least : greatest));
+        }
         h->fork_ev.resize(P.nodes.size());
         for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->done_ev.resize(P.nodes.size());
@@ -532,6 +541,15 @@ int cunet_bucket_order(const cunet_plan_t* p, int32_t* order, int capacity) {
     return n;
 }
 
+int cunet_side_stream_join(cunet_plan_t* h, void* stream) {
+    if (!h) return fail(CUNET_ERR_INVALID, "null argument");
+    if (h->use_side && h->side) {
+        HIPCHK(hipEventRecord(h->join_ev, h->side));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->join_ev, 0));
+    }
+    return CUNET_OK;
+}
+
 int cunet_backward(cunet_plan_t* h, const float* const* grad_heat, void* stream) {
     return cunet_backward_ex(h, grad_heat, stream, nullptr, nullptr);
 }
@@ -564,13 +582,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
             const int rcg = bn_param_grads(h, k + 1, bucket_hi, cur_bucket, s);
             if (rcg != CUNET_OK) return rcg;
-            if (on_bucket) {
-                if (h->use_side && h->side) {      // ... including the weight gradients on the side stream
-                    HIPCHK(hipEventRecord(h->join_ev, h->side));
-                    HIPCHK(hipStreamWaitEvent(s, h->join_ev, 0));
-                }
-                on_bucket(cur_bucket, user);
-            }
+            if (on_bucket) on_bucket(cur_bucket, user);   // the consumer joins the side stream itself (cunet_side_stream_join)
             cur_bucket = n.bucket;
             bucket_hi = k + 1;
         }

@@ -90,6 +90,10 @@ class _BoundPlan:
             self._cb_keepalive = cb
             check(lib().cunet_backward_ex(self.handle.h, arr, _stream_ptr(dev), cb, None), 'cunet_backward_ex')
 
+    def side_stream_join(self, stream_ptr):
+        """Make the stream (raw hipStream_t as c_void_p) wait for the weight gradients enqueued so far."""
+        check(lib().cunet_side_stream_join(self.handle.h, stream_ptr), 'cunet_side_stream_join')
+
     def debug_poke(self, name: str, value: torch.Tensor, grad: bool = True):
         """Overwrite an internal NHWC tensor from an NCHW one (kernel unit tests only)."""
         d = self.handle.describe()

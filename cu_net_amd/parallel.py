@@ -35,8 +35,10 @@ class BucketAllReducer:
     def begin_step(self):
         self.reduced = []
 
-    def reduce_bucket(self, flat: torch.Tensor, b: int):
-        """Called when every kernel writing bucket b has been enqueued on the current stream."""
+    def reduce_bucket(self, flat: torch.Tensor, b: int, join_side=None):
+        """Called when every kernel writing bucket b has been enqueued.  `join_side(stream_ptr)` makes a raw
+        stream wait for the library's internal weight-gradient stream (cunet_side_stream_join)."""
+        import ctypes
         begin, count = self.buckets[b]
         self.reduced.append(b)
         if self.pg is None or count == 0:
@@ -49,9 +51,13 @@ class BucketAllReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             self._stream.wait_event(ev)
+            if join_side is not None:
+                join_side(ctypes.c_void_p(self._stream.cuda_stream))
             with torch.cuda.stream(self._stream):
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
         else:
+            if join_side is not None and flat.is_cuda:
+                join_side(ctypes.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream))
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self, flat: torch.Tensor):

@@ -62,7 +62,7 @@ class FusedTrainer:
             plan.backward(None)
         else:
             self.reducer.begin_step()
-            plan.backward(None, on_bucket=lambda b: self.reducer.reduce_bucket(net._grad_arena, b))
+            plan.backward(None, on_bucket=lambda b: self.reducer.reduce_bucket(net._grad_arena, b, plan.side_stream_join))
             self.reducer.finish(net._grad_arena)
         gscale = 1.0 / self.world
         if self.quan_op is not None:

@@ -105,14 +105,20 @@ int cunet_backward(cunet_plan_t* plan, const float* const* grad_heat, void* stre
 /* Gradient buckets for data parallelism.  The parameter/gradient arena is laid out bucket-major:
  * bucket i < layer_num holds every parameter used by U-Net index i, bucket layer_num the stem.
  * cunet_backward_ex calls on_bucket(b, user) on the calling thread right after the LAST kernel
- * writing bucket b has been enqueued on `stream` (order: layer_num-1, ..., 0, stem), so the host
- * can record an event and start that bucket's RCCL all-reduce on another stream while the rest
- * of backward runs.  (Replaces the grad reduce inside torch.nn.DataParallel, cu-net.py:59.) */
+ * writing bucket b has been enqueued (order: layer_num-1, ..., 0, stem), so the host can start that
+ * bucket's RCCL all-reduce on another stream while the rest of backward runs.  Weight gradients are
+ * enqueued on a library-internal side stream, the rest on `stream`: inside the callback the consumer
+ * stream must (1) wait for an event recorded on `stream` and (2) call cunet_side_stream_join(plan,
+ * consumer) -- `stream` itself is NOT made to wait for the weight gradients at a bucket boundary (that
+ * stalled the data-gradient chain for 2.6 ms per step).  After cunet_backward_ex returns, `stream` has
+ * joined the side stream.  (Replaces the grad reduce inside torch.nn.DataParallel, cu-net.py:59.) */
 typedef void (*cunet_bucket_cb)(int bucket, void* user);
 int cunet_num_buckets(const cunet_plan_t* plan);
 int cunet_bucket_range(const cunet_plan_t* plan, int bucket, int64_t* begin, int64_t* count);
 int cunet_backward_ex(cunet_plan_t* plan, const float* const* grad_heat, void* stream,
                       cunet_bucket_cb on_bucket, void* user);
+/* make `stream` wait for everything enqueued so far on the plan's internal side stream (no-op without one) */
+int cunet_side_stream_join(cunet_plan_t* plan, void* stream);
 /* the order in which cunet_backward_ex reports buckets (host only; returns the count) */
 int cunet_bucket_order(const cunet_plan_t* plan, int32_t* order, int capacity);
 
