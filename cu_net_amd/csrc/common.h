@@ -23,7 +23,7 @@ struct Seg {
     int C;                 // channels taken from this tensor (all of it)
     int ld;                // row pitch in floats
     int ups;               // 1: tensor is at half resolution, read through nearest-upsample (cu_net.py:250,265)
-    int gfirst;            // backward: 1 = first writer of gx (store), 0 = accumulate
+    int pad0_;
     int choff;             // channel offset inside the concat
     int pad_;
 };

@@ -345,7 +345,7 @@ bool Plan::build(const cunet_cfg& c) {
         }
     }
 
-    // ---- backward-order simulation: who writes a gradient buffer first
+    // ---- backward-order check: every node's output gradient exists when backward reaches the node
     {
         std::vector<char> written(tensors.size(), 0);
         for (int h : head_tensors) written[h] = 1;            // d(loss)/d(heat) is provided
@@ -353,10 +353,9 @@ bool Plan::build(const cunet_cfg& c) {
             Node& n = nodes[k];
             if (n.type == N_CONV) {
                 if (!written[n.out]) { error = "internal: gradient of " + tensors[n.out].name + " never produced"; return false; }
-                for (auto& s : n.segs) { s.gfirst = written[s.tensor] ? 0 : 1; written[s.tensor] = 1; }
+                for (auto& s : n.segs) written[s.tensor] = 1;
             } else if (n.type == N_POOL || n.type == N_STEM_BNPOOL) {
                 if (!written[n.out]) { error = "internal: gradient of " + tensors[n.out].name + " never produced"; return false; }
-                n.segs[0].gfirst = 1;
                 if (written[n.segs[0].tensor]) { error = "internal: pooled tensor has a second consumer"; return false; }
                 written[n.segs[0].tensor] = 1;
             }
@@ -453,7 +452,7 @@ void Plan::describe() {
         o << ",\"head\":" << n.head << ",\"segs\":[";
         for (size_t s = 0; s < n.segs.size(); ++s)
             o << (s ? "," : "") << "{\"t\":" << n.segs[s].tensor << ",\"ups\":" << n.segs[s].ups
-              << ",\"gfirst\":" << n.segs[s].gfirst << "}";
+              << "}";
         o << "]}";
     }
     o << "]}";

@@ -53,7 +53,6 @@ struct ConvInfo {
 struct SegRef {
     int tensor;
     int ups;
-    int gfirst = 0;           // filled by the backward-order simulation
 };
 
 enum NodeType { N_STEM_CONV = 0, N_STEM_BNPOOL = 1, N_CONV = 2, N_POOL = 3 };

@@ -250,7 +250,6 @@ struct Exec {
     Plan& P;
     float* wsf;        // float region
     double* zero;      // fp64 region
-    int force_first = 0;
     explicit Exec(cunet_plan* hh) : h(hh), P(hh->plan) {
         wsf = reinterpret_cast<float*>(h->ws + P.off_floats);
         zero = reinterpret_cast<double*>(h->ws + P.off_zero);
@@ -268,7 +267,7 @@ struct Exec {
             s.gx = h->bound_training ? grad(n.segs[i].tensor) : nullptr;
             s.stats = stats(n.segs[i].tensor);
             s.count = (double)t.rows();
-            s.C = t.C; s.ld = t.ld; s.ups = n.segs[i].ups; s.gfirst = force_first ? 1 : n.segs[i].gfirst; s.choff = choff; s.pad_ = 0;
+            s.C = t.C; s.ld = t.ld; s.ups = n.segs[i].ups; s.pad0_ = 0; s.choff = choff; s.pad_ = 0;
             choff += t.C;
         }
         return (int)n.segs.size();
@@ -334,7 +333,7 @@ static int bn_param_grads(cunet_plan* h, int k0, int k1, int bucket, hipStream_t
 }
 
 // Backward of one node: data gradient (+ReLU mask + BN reductions), weight gradient, BN apply.
-static int bwd_node(cunet_plan* h, const Node& n, int node_index, int force_first, hipStream_t s) {
+static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s) {
     Exec E(h);
     // weight gradients only read d(loss)/d(out) and activations and only write dW: they fork to the side stream
     hipStream_t ws = s;
@@ -345,7 +344,6 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, int force_firs
     }
     Plan& P = h->plan;
     const int cus = h->num_cus;
-    E.force_first = force_first;
     float* dz = n.dz >= 0 ? E.wsf + n.dz : nullptr;
     const TensorInfo& o = P.tensors[n.out];
     if (n.type == N_CONV) {
@@ -590,7 +588,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             const int rcg = gather_tensor_grad(h, n.out, -1, s);
             if (rcg != CUNET_OK) return rcg;
         }
-        const int rc = bwd_node(h, n, k, 0, s);
+        const int rc = bwd_node(h, n, k, s);
         if (rc != CUNET_OK) return rc;
     }
     {
@@ -693,7 +691,7 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (n.red >= 0)
         HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * n.red, 0, (size_t)16 * n.Ccat, s));
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
-    const int rc = bwd_node(h, n, node, 1, s);
+    const int rc = bwd_node(h, n, node, s);
     if (rc != CUNET_OK) return rc;
     if (n.type == N_CONV) {                // this node's contribution to each of its inputs, and its BN parameter gradients
         for (size_t j = 0; j < n.segs.size(); ++j) {
