@@ -202,12 +202,13 @@ struct Wg2Args {
     WgradArgs w;
     int dbg;                 // unused (timing experiments)
     int any_ups;             // some segment is read through the nearest-upsample map
+    int stem;                // X is the 7x7/2 im2col view of the NCHW image (w.img), no BatchNorm in front
     int ngroups;
     Wg2Group grp[12];
     int rows_per_chunk[12];
 };
 
-template <int NTW, int CT, bool UPS>
+template <int NTW, int CT, bool UPS, bool STEM = false>
 __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int chunk, int rpc, float* lds) {
     const WgradArgs& p = q.w;
     const int tid = threadIdx.x;
@@ -225,7 +226,19 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
     float xsc[CT], xsh[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) { xsc[t] = 0.f; xsh[t] = 0.f; }
-    if (cok) {
+    // STEM: channel c of the im2col view is (ci, ky, kx) = (c / 49, (c % 49) / 7, c % 7); per-lane element offsets
+    int soff[CT], sky[CT], skx[CT];
+    bool sokc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int c = cb + t;
+        sokc[t] = STEM && c < p.Ccat;
+        const int cc = sokc[t] ? c : 0;
+        const int ci = cc / 49, r = cc - ci * 49;
+        sky[t] = r / 7; skx[t] = r - sky[t] * 7;
+        soff[t] = (ci * p.IH + sky[t]) * p.IW + skx[t];
+    }
+    if (cok && !STEM) {
         int s = 0;
         for (int t = 1; t < p.nseg; ++t)
             if (cb >= p.seg[t].choff) s = t;
@@ -279,7 +292,20 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 for (int t = 0; t < NTW; ++t) a[t] = ldg1(src + t);
             }
         }
-        {
+        if constexpr (STEM) {      // gather of the image: output pixel (py, px) reads rows 2py-3+ky, columns 2px-3+kx
+            const int nimg = mc / HW;
+            const int rem = mc - nimg * HW;
+            const int py = rem / p.W;
+            const int px = rem - py * p.W;
+            const int iy0 = 2 * py - 3, ix0 = 2 * px - 3;
+            const int base = (nimg * 3 * p.IH + iy0) * p.IW + ix0;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const bool in = sokc[t] && (iy0 + sky[t] >= 0) && (iy0 + sky[t] < p.IH) && (ix0 + skx[t] >= 0) && (ix0 + skx[t] < p.IW);
+                const float v = ldg1(p.img + (in ? base + soff[t] : 0));     // always a valid address; zero padding by select
+                x[t] = in ? v : 0.f;
+            }
+        } else {
             int xrow = mc;
             if constexpr (UPS) {
                 const int nimg = mc / HW;
@@ -299,7 +325,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         ok = mok;
     };
 
-    if constexpr (NTW == 4 && (CT == 2 || CT == 1)) {
+    if constexpr (NTW == 4 && (CT == 2 || CT == 1) && !STEM) {
         // ---- counted-vmcnt pipeline.  hipcc drains vmcnt(0) at a loop back-edge, so with compiler-visible loads the
         // prefetch depth collapses to "whatever was issued in this iteration".  Here the loads are inline asm (invisible
         // to hipcc's wait bookkeeping) and every slot is awaited with an explicit, COUNTED s_waitcnt: when slot u is
@@ -382,7 +408,9 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             for (int t = 0; t < NTW; ++t) a[t] = (xok[u] && nok) ? av[u][t] : 0.f;
             // BN + ReLU at consumption time (rows outside the chunk contribute exactly 0)
 #pragma unroll
-            for (int t = 0; t < CT; ++t) x[t] = (xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f;
+            for (int t = 0; t < CT; ++t)
+                x[t] = STEM ? (xok[u] ? xv[u][t] : 0.f)          // raw image, validity already applied per element
+                            : ((xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f);
             issue(m0 + (uu + WG2_PD) * stride, av[u], xv[u], xok[u]);       // refill this slot PD pairs ahead
 #pragma unroll
             for (int ta = 0; ta < NTW; ++ta)
@@ -433,7 +461,12 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
     const Wg2Group g = q.grp[gi];
     const int chunk = blockIdx.x - g.chunk0;
     const int rpc = q.rows_per_chunk[gi];
-    if (q.any_ups) {
+    if (q.stem) {
+        if constexpr (NTW == 4) {
+            if (g.ct == 2) wg2_body<4, 2, false, true>(q, g, chunk, rpc, lds);
+            else wg2_body<4, 1, false, true>(q, g, chunk, rpc, lds);
+        }
+    } else if (q.any_ups) {
         if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), true>(q, g, chunk, rpc, lds);
         else if (g.ct == 2) wg2_body<NTW, 2, true>(q, g, chunk, rpc, lds);
         else wg2_body<NTW, 1, true>(q, g, chunk, rpc, lds);
@@ -453,6 +486,7 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     q.dbg = wdbg;
     q.any_ups = 0;
     for (int i = 0; i < a.nseg; ++i) q.any_ups |= a.seg[i].ups;
+    q.stem = (a.img != nullptr && a.nseg == 0) ? 1 : 0;
     // channel groups: as many CT=4 (128-channel) groups as fit, then one CT=2 and/or CT=1 remainder
     int c = 0, ng = 0, weight = 0;
     const int C32 = (a.Ccat + 31) / 32;          // 32-channel tiles
@@ -517,6 +551,7 @@ static hipError_t launch_acc(const WgradArgs& a, int nacc, dim3 grid, hipStream_
 
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
     if (load == WG_SEG && a.Cout <= 128 && a.lddy % 4 == 0 && !getenv("CUNET_WG_OLD")) return launch_wgrad2(a, num_cus, s);
+    if (load == WG_STEM && a.Cout <= 128 && a.lddy > 64 && a.lddy % 4 == 0 && !getenv("CUNET_WG_OLD_STEM")) return launch_wgrad2(a, num_cus, s);
     const int nct = (a.Ccat + 31) / 32;
     const int ntiles = (a.Cout + 31) / 32;
     int nacc, jobs;
@@ -533,7 +568,8 @@ hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
     static const int mult = getenv("CUNET_WG_CHUNK_MULT") ? atoi(getenv("CUNET_WG_CHUNK_MULT")) : 2;   // tuning knob
     static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;                                   // timing experiments only
     if (nocommit) a.ctw = -a.ctw;
-    int chunks = (mult * num_cus + jobs - 1) / jobs;
+    static const int stem_mult = getenv("CUNET_WG_STEM_MULT") ? atoi(getenv("CUNET_WG_STEM_MULT")) : 2;
+    int chunks = ((load == WG_STEM ? stem_mult : mult) * num_cus + jobs - 1) / jobs;
     if (chunks < 1) chunks = 1;
     int rpb = (a.M + chunks - 1) / chunks;
     rpb = (rpb + quantum - 1) / quantum * quantum;

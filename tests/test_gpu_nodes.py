@@ -6,7 +6,8 @@ differs from an fp64 evaluation by 1e-2 on these tiny nets), so the exact checks
 node of the plan the node's inputs are the activations the GPU itself produced, d(loss)/d(output) is
 a seeded random tensor, and the HIP kernels' input gradients / weight gradient / dgamma / dbeta are
 compared with torch's on the CPU.  fp32 tolerance: max|hip-ref| <= 2e-4 * max|ref| for all but a
-1e-3 fraction of elements (z == 0 +- rounding can still flip a mask), and relative L2 error <= 1e-3.
+1e-3 fraction of elements (z == 0 +- rounding can still flip a mask), and relative L2 error <= 1e-3
+over the remaining elements.
 """
 import pytest
 import torch
@@ -22,9 +23,14 @@ def _close(name, got, ref, bad, rtol=2e-4, frac=1e-3, l2=1e-3):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     mag = ref.abs().max().item()
     diff = (got - ref).abs()
+    allowed = max(2, int(frac * ref.numel()))      # elements whose ReLU mask may legitimately flip (z == 0 +- rounding)
     nbad = int((diff > rtol * mag + 1e-7).sum())
-    rel2 = (diff.double().norm() / (ref.double().norm() + 1e-30)).item()
-    if nbad > max(2, frac * ref.numel()) or rel2 > l2 or not bool(torch.isfinite(got).all()):
+    # relative L2 without the `allowed` worst elements: one flipped mask under a large dy would otherwise dominate it
+    d = diff.flatten().double()
+    if d.numel() > allowed:
+        d = d.sort().values[:d.numel() - allowed]
+    rel2 = (d.norm() / (ref.double().norm() + 1e-30)).item()
+    if nbad > allowed or rel2 > l2 or not bool(torch.isfinite(got).all()):
         bad.append(f'{name}: {nbad}/{ref.numel()} elements off, max err {diff.max().item():.3e} (mag {mag:.3e}), relL2 {rel2:.2e}')
 
 
@@ -33,7 +39,22 @@ def test_every_node_backward_matches_autograd(tag):
     g = Golden(tag)
     x = g.t('x')
     st = g.group('state0')
-    net = cu_net_amd.create_cu_net(**g.cfg)
+    _check_all_nodes(g.cfg, st, x)
+
+
+def test_every_node_backward_full_width():
+    """The production channel widths (4 / 32 / 128, K = 68), one 256x256 image: these are the shapes that select
+    the wide-tile, tap-split, multi-consumer-gather and vector-operand weight-gradient kernel variants."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=21)
+    x, _ = O.synthetic_batch(1, 68, 256, seed=22)
+    _check_all_nodes(cfg, st, x)
+
+
+def _check_all_nodes(cfg, st, x):
+    net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
     n, _, h, w = x.shape
