@@ -81,10 +81,9 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
 }
 
 constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
-constexpr int CONV_MAX_WAVES_NT1 = 16;   // one accumulator tile: 4 waves per SIMD (VGPR budget 128)
 
 template <int LD, int EP, int NT, bool FAST>
-__global__ __launch_bounds__((NT == 1 ? CONV_MAX_WAVES_NT1 : CONV_MAX_WAVES) * 64) void conv_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
     const int kq4 = p.Kpad >> 2;
@@ -676,9 +675,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     const int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
-    static const int w1 = getenv("CUNET_CONV_W1") ? atoi(getenv("CUNET_CONV_W1")) : 12;
-    static const int w1b = getenv("CUNET_CONV_W1_BWD") ? atoi(getenv("CUNET_CONV_W1_BWD")) : 12;
-    const int maxw = NT == 1 ? (epi == EP_BWD ? w1b : w1) : CONV_MAX_WAVES;
+    const int maxw = CONV_MAX_WAVES;      // 16 waves for one-tile blocks (VGPR budget 128) measured 2-3 % slower
     if (waves > maxw / blocks_per_cu) waves = maxw / blocks_per_cu;
     if (waves < 1) waves = 1;
     int gx = (ntiles + waves - 1) / waves;

@@ -482,8 +482,7 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     q.w = a;
     static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;
     q.w.ctw = nocommit ? -1 : 1;
-    static const int wdbg = getenv("CUNET_WG_DBG") ? atoi(getenv("CUNET_WG_DBG")) : 0;
-    q.dbg = wdbg;
+    q.dbg = 0;
     q.any_ups = 0;
     for (int i = 0; i < a.nseg; ++i) q.any_ups |= a.seg[i].ups;
     q.stem = (a.img != nullptr && a.nseg == 0) ? 1 : 0;
@@ -568,8 +567,7 @@ hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
     static const int mult = getenv("CUNET_WG_CHUNK_MULT") ? atoi(getenv("CUNET_WG_CHUNK_MULT")) : 2;   // tuning knob
     static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;                                   // timing experiments only
     if (nocommit) a.ctw = -a.ctw;
-    static const int stem_mult = getenv("CUNET_WG_STEM_MULT") ? atoi(getenv("CUNET_WG_STEM_MULT")) : 2;
-    int chunks = ((load == WG_STEM ? stem_mult : mult) * num_cus + jobs - 1) / jobs;
+    int chunks = (mult * num_cus + jobs - 1) / jobs;
     if (chunks < 1) chunks = 1;
     int rpb = (a.M + chunks - 1) / chunks;
     rpb = (rpb + quantum - 1) / quantum * quantum;
