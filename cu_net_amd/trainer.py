@@ -26,6 +26,7 @@ class FusedTrainer:
         self.net = net
         self.lr, self.alpha, self.eps = float(lr), float(alpha), float(eps)
         self.square_avg = None
+        self.steps_done = 0           # optimiser steps taken (the `step` entry of torch's RMSprop state)
         self.quan_op = quan_op        # cu_net_amd.quant.QuanOp / BinOp: quantised training (cu-net-prev-version-wig.py:163-190)
         self.pg = process_group
         self.world = 1
@@ -76,6 +77,7 @@ class FusedTrainer:
         check(lib().cunet_rmsprop_step(_ptr(net._param_arena), _ptr(net._grad_arena), _ptr(self.square_avg),
                                        net._n_params, self.lr, self.alpha, self.eps, gscale,
                                        _stream_ptr(img.device)), 'cunet_rmsprop_step')
+        self.steps_done += 1
         return loss
 
     def last_outputs(self, img_shape):

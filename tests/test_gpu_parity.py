@@ -284,3 +284,19 @@ def test_flip_merge_and_accuracy_bit_exact():
     ref[0] = avg / cnt
     got = cu_net_amd.accuracy_origin_res(hm.cuda(), center, scale, [64, 64], gt, normalizers)
     assert torch.equal(got, ref), (got, ref)
+
+
+def test_driver_trains_validates_and_resumes(tmp_path):
+    """train.py's loop on the GPU: two short synthetic epochs (loss must fall), flip-TTA validation, checkpoint in the
+    reference's layout, resume from it at the next epoch."""
+    from cu_net_amd import driver as D
+    args = ['--exp_id', 'gpu', '--exp_dir', str(tmp_path), '--layer_num', '2', '--order', '1', '--class_num', '16',
+            '--loss_num', '2', '--bs', '4', '--synthetic', '6', '--print_freq', '100', '--lr', '1e-3']
+    h = D.main(args + ['--nEpochs', '2'])
+    assert [e['epoch'] for e in h.epoch] == [0, 1]
+    assert h.loss[1]['train_loss'] < h.loss[0]['train_loss']
+    files = sorted(os.listdir(os.path.join(str(tmp_path), 'gpu')))
+    assert 'lr-0.001-1.pth.tar' in files and 'opt.txt' in files
+    h2 = D.main(args + ['--nEpochs', '3', '--resume_prefix', 'lr-0.001-1.pth.tar'])
+    assert [e['epoch'] for e in h2.epoch] == [0, 1, 2]
+    assert h2.loss[2]['train_loss'] < h.loss[0]['train_loss']
