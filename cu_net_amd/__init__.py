@@ -9,4 +9,4 @@ the validation-loop pieces (`get_preds`, `final_preds`, `flip_merge`, `accuracy`
 """
 from ._lib import CUNetError, LIB_PATH  # noqa: F401
 from .module import CUNet, create_cu_net  # noqa: F401
-from .trainer import FusedTrainer, accuracy, accuracy_origin_res, final_preds, flip_merge, get_preds  # noqa: F401
+from .trainer import FusedTrainer, accuracy, accuracy_origin_res, final_preds, flip_merge, get_preds, pts2heatmap  # noqa: F401

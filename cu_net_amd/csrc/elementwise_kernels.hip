@@ -754,4 +754,30 @@ hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, fl
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gaussian target maps (pylib/HumanPts.py:35-76).  One block per map: zero fill, then the cropped patch whose
+// centre is pixel (int(x), int(y)) -- int() truncates toward zero exactly as python's does on the float64 input.
+__global__ __launch_bounds__(256) void render_targets_kernel(const double* __restrict__ pts, const float* __restrict__ patch,
+                                                              int half, float* __restrict__ out, int H, int W) {
+    const int m = blockIdx.x;
+    float* o = out + (size_t)m * H * W;
+    const double px = pts[2 * m], py = pts[2 * m + 1];
+    const int ulx = (int)(px - (double)half), uly = (int)(py - (double)half);      // C conversion truncates toward zero
+    const int brx = (int)(px + (double)half), bry = (int)(py + (double)half);
+    const bool draw = px > 0.0 && py > 0.0 && !(ulx >= W || uly >= H || brx < 0 || bry < 0);
+    const int size = 2 * half + 1;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const int gx = x - ulx, gy = y - uly;
+        float v = 0.f;
+        if (draw && gx >= 0 && gx < size && gy >= 0 && gy < size && x <= brx && y <= bry) v = patch[gy * size + gx];
+        o[i] = v;
+    }
+}
+
+hipError_t launch_render_targets(const double* pts, const float* patch, int half, float* out, int NK, int H, int W, hipStream_t s) {
+    hipLaunchKernelGGL(render_targets_kernel, dim3(NK), dim3(256), 0, s, pts, patch, half, out, H, W);
+    return hipGetLastError();
+}
+
 }  // namespace cunet

@@ -22,6 +22,7 @@ hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* s
 hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, float* ws, hipStream_t s);
 hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
                           float gscale, hipStream_t s);
+hipError_t launch_render_targets(const double* pts, const float* patch, int half, float* out, int NK, int H, int W, hipStream_t s);
 hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, float* out, int N, int K, int H, int W, hipStream_t s);
 hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,
                               int H, int W, int res0, int res1, hipStream_t s);

@@ -630,6 +630,12 @@ int cunet_final_preds(const float* heat, const float* center, const float* scale
     return CUNET_OK;
 }
 
+int cunet_render_targets(const double* pts, const float* patch, int half, float* out, int nk, int hh, int w, void* stream) {
+    if (!pts || !patch || !out || half < 0 || nk < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_render_targets(pts, patch, half, out, nk, hh, w, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
 int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float* out, int n, int k, int hh, int w,
                      void* stream) {
     if (!a || !b || !perm || !out || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");

@@ -184,3 +184,25 @@ def accuracy_origin_res(output: torch.Tensor, center, scale, res, grnd_pts, norm
     dev = pred_pts.device
     dists = _calc_dists(pred_pts, torch.as_tensor(grnd_pts).to(dev), torch.as_tensor(normalizers).to(dev), True)
     return _acc_from_dists(dists, idxs, 0.5)
+
+
+def pts2heatmap(pts: torch.Tensor, heatmap_shape, sigma: float = 1) -> torch.Tensor:
+    """Training targets on the GPU (pylib/HumanPts.py:35-76): `pts` is N x K x 2 (or K x 2) of (x, y) heat-map
+    coordinates, the result N x K x H x W fp32 -- what `torch.from_numpy(pts2heatmap(...)[0]).float()` gives per sample.
+    The (2*ceil(3 sigma)+1)^2 Gaussian patch is tabulated on the host in float64 exactly as the reference does."""
+    import numpy as np
+    if not pts.is_cuda:
+        raise CUNetError('pts2heatmap: GPU tensor required (the CPU oracle is oracle/decode_ref.py)')
+    squeeze = pts.dim() == 2
+    p = (pts.unsqueeze(0) if squeeze else pts).contiguous().double()
+    n, k, _ = p.shape
+    h, w = int(heatmap_shape[0]), int(heatmap_shape[1])
+    tmp = np.ceil(3 * sigma)
+    size = 2 * tmp + 1
+    x = np.arange(0, size, 1, float)
+    g = np.exp(-((x - size // 2) ** 2 + (x[:, np.newaxis] - size // 2) ** 2) / (tmp ** 2))
+    patch = torch.from_numpy(g.astype(np.float32)).to(p.device).contiguous()
+    out = torch.empty((n, k, h, w), dtype=torch.float32, device=p.device)
+    check(lib().cunet_render_targets(_ptr(p), _ptr(patch), int(tmp), _ptr(out), n * k, h, w, _stream_ptr(p.device)),
+          'cunet_render_targets')
+    return out[0] if squeeze else out

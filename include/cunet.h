@@ -178,6 +178,14 @@ int cunet_final_preds(const float* heat, const float* center, const float* scale
 int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float* out, int n, int k, int hh, int w,
                      void* stream);
 
+/* training targets on the device: replaces pylib/HumanPts.py:35-76 (pts2heatmap / draw_gaussian), which the
+ * reference's data loader runs per sample on the CPU.
+ *   pts:   N*K x 2 float64 (x, y) heat-map coordinates; a point with x <= 0 or y <= 0 leaves its map zero
+ *   patch: (2*half+1)^2 fp32 Gaussian patch, row-major (the caller tabulates exp(-(dx^2+dy^2)/half^2) once on the
+ *          host, in float64 like the reference, so the maps are bit-identical to the reference's `.float()`)
+ *   out:   N*K x H x W fp32, fully written */
+int cunet_render_targets(const double* pts, const float* patch, int half, float* out, int nk, int hh, int w, void* stream);
+
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);
  * negative if unknown. Names are those listed by cunet_plan_describe. */

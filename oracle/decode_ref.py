@@ -134,3 +134,39 @@ def accuracy(output: torch.Tensor, target: torch.Tensor, idxs, thr: float = 0.5)
     if cnt != 0:
         acc[0] = avg_acc / cnt
     return acc
+
+
+# ---- target synthesis (training labels) -----------------------------------------------------------------
+def draw_gaussian(img, pt, sigma):
+    """pylib/HumanPts.py:49-76: paste an un-normalised (peak 1) Gaussian patch of half-width ceil(3 sigma) whose
+    centre is pixel (int(pt[0]), int(pt[1])) (x, y); the part outside the map is cropped; float64 numpy."""
+    import numpy as np
+    tmp_size = np.ceil(3 * sigma)
+    ul = [int(pt[0] - tmp_size), int(pt[1] - tmp_size)]
+    br = [int(pt[0] + tmp_size), int(pt[1] + tmp_size)]
+    if ul[0] >= img.shape[1] or ul[1] >= img.shape[0] or br[0] < 0 or br[1] < 0:
+        return img
+    size = 2 * tmp_size + 1
+    x = np.arange(0, size, 1, float)
+    y = x[:, np.newaxis]
+    x0 = y0 = size // 2
+    g = np.exp(- ((x - x0) ** 2 + (y - y0) ** 2) / (tmp_size ** 2))
+    g_x = max(0, -ul[0]), min(br[0] + 1, img.shape[1]) - max(0, ul[0]) + max(0, -ul[0])
+    g_y = max(0, -ul[1]), min(br[1] + 1, img.shape[0]) - max(0, ul[1]) + max(0, -ul[1])
+    img_x = max(0, ul[0]), min(br[0] + 1, img.shape[1])
+    img_y = max(0, ul[1]), min(br[1] + 1, img.shape[0])
+    img[img_y[0]:img_y[1], img_x[0]:img_x[1]] = g[g_y[0]:g_y[1], g_x[0]:g_x[1]]
+    return img
+
+
+def pts2heatmap(pts, heatmap_shape, sigma=1):
+    """pylib/HumanPts.py:35-47: K x H x W float64 maps and the K x 2 points that were drawn (x <= 0 or y <= 0: skipped)."""
+    import numpy as np
+    heatmap = np.zeros((pts.shape[0], heatmap_shape[0], heatmap_shape[1]))
+    valid_pts = np.zeros((pts.shape))
+    for i in range(0, pts.shape[0]):
+        if pts[i][0] <= 0 or pts[i][1] <= 0:
+            continue
+        heatmap[i] = draw_gaussian(heatmap[i], pts[i], sigma)
+        valid_pts[i] = pts[i]
+    return heatmap, valid_pts

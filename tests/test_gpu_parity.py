@@ -300,3 +300,19 @@ def test_driver_trains_validates_and_resumes(tmp_path):
     h2 = D.main(args + ['--nEpochs', '3', '--resume_prefix', 'lr-0.001-1.pth.tar'])
     assert [e['epoch'] for e in h2.epoch] == [0, 1, 2]
     assert h2.loss[2]['train_loss'] < h.loss[0]['train_loss']
+
+
+def test_target_synthesis_bit_exact():
+    """Gaussian target maps rendered on the GPU vs the oracle (== the reference, G11): bit-exact, sigma 1 and 2."""
+    import numpy as np
+    from oracle import decode_ref as DR
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G11_targets.npz'))
+    pts = torch.from_numpy(z['pts'])
+    for sigma in (1, 2):
+        got = cu_net_amd.pts2heatmap(pts.cuda(), (64, 64), sigma).cpu().numpy()
+        ref = DR.pts2heatmap(z['pts'].copy(), (64, 64), sigma)[0].astype(np.float32)
+        assert np.array_equal(got, ref), sigma
+        assert np.array_equal(got[:, ::2, ::2], z[f'heat_s{sigma}'])
+    batch = cu_net_amd.pts2heatmap(pts.view(2, 20, 2).cuda(), (64, 64))
+    ref1 = DR.pts2heatmap(z['pts'].copy(), (64, 64), 1)[0].astype(np.float32)
+    assert batch.shape == (2, 20, 64, 64) and torch.equal(batch.view(40, 64, 64).cpu(), torch.from_numpy(ref1))

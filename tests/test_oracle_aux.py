@@ -60,3 +60,17 @@ def test_flip_merge_and_accuracy_match_reference_vectors():
     acc = DR.accuracy(m, tgt, z['idxs'].tolist())
     assert torch.equal(acc, torch.from_numpy(z['accuracy']))
     assert float(acc[7]) == -1.0          # the joint without ground truth anywhere
+
+
+def test_target_synthesis_matches_reference_vectors():
+    """G11: pts2heatmap / draw_gaussian of the oracle against vectors from the reference's functions."""
+    import numpy as np
+    import os
+    from oracle import decode_ref as DR
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G11_targets.npz'))
+    for sigma in (1, 2):
+        h, v = DR.pts2heatmap(z['pts'].copy(), (64, 64), sigma)
+        assert np.array_equal(h.astype(np.float32)[:, ::2, ::2], z[f'heat_s{sigma}'])
+        assert np.array_equal(h.astype(np.float32).sum(axis=(1, 2)), z[f'sum_s{sigma}'])
+        assert np.array_equal(v, z[f'valid_s{sigma}'])
+    assert z['sum_s1'][0] == 0 and z['sum_s1'][1] == 0 and z['sum_s1'][5] == 0 and z['sum_s1'][4] > 0

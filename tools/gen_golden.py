@@ -351,11 +351,43 @@ def tta_accuracy_parity():
     print('G10: flip-TTA merge and PCK accuracy: oracle == reference')
 
 
+
+def target_synthesis_parity():
+    """G11: Gaussian target maps (pylib/HumanPts.py pts2heatmap / draw_gaussian).  The file mixes tabs and spaces
+    (python 2); it is tab-expanded in memory and only the two functions are compiled."""
+    import ast, re
+    from oracle import decode_ref as DR
+    src = open(os.path.join(REF, 'pylib', 'HumanPts.py')).read().expandtabs(8)
+    src = re.sub(r"(?m)^(\s*)print (.+)$", r"\1print(\2)", src)
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('pts2heatmap', 'draw_gaussian')]
+    assert len(keep) == 2
+    hp = types.ModuleType('ref_humanpts_subset')
+    hp.__dict__.update(np=np)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), '<reference pylib/HumanPts.py subset>', 'exec'), hp.__dict__)
+    rng = np.random.RandomState(4)
+    pts = rng.uniform(-6, 70, size=(40, 2))
+    pts[0] = [0.0, 10.0]; pts[1] = [10.0, -1.0]          # skipped
+    pts[2] = [0.5, 0.5]; pts[3] = [63.9, 63.9]            # corners: cropped patches
+    pts[4] = [66.0, 30.0]; pts[5] = [67.0, 30.0]          # ul = 63 (one column visible) / ul = 64 (nothing drawn)
+    pts[6] = [2.999, 3.0]; pts[7] = [31.0, 31.0]
+    outs = {}
+    for sigma in (1, 2):
+        ref_h, ref_v = hp.pts2heatmap(pts.copy(), (64, 64), sigma)
+        my_h, my_v = DR.pts2heatmap(pts.copy(), (64, 64), sigma)
+        assert np.array_equal(ref_h, my_h) and np.array_equal(ref_v, my_v), sigma
+        outs[f'heat_s{sigma}'] = ref_h.astype(np.float32)[:, ::2, ::2]      # what the dataset hands to torch (.float()), subsampled
+        outs[f'sum_s{sigma}'] = ref_h.astype(np.float32).sum(axis=(1, 2))
+        outs[f'valid_s{sigma}'] = ref_v
+    np.savez_compressed(os.path.join(OUT, 'G11_targets.npz'), pts=pts, **outs)
+    print('G11: pts2heatmap / draw_gaussian, sigma 1 and 2, 40 points: oracle == reference')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 2 and sys.argv[1] == '--only':       # regenerate one fixture
-        {'decode': decode_parity, 'tta': tta_accuracy_parity}[sys.argv[2]]()
+        {'decode': decode_parity, 'tta': tta_accuracy_parity, 'targets': target_synthesis_parity}[sys.argv[2]]()
         return
     ref = load_reference_models()
     tiny = dict(neck_size=2, growth_rate=4, init_chan_num=8)
@@ -373,6 +405,7 @@ def main():
     quant_parity(ref, load_reference_quantize())
     decode_parity()
     tta_accuracy_parity()
+    target_synthesis_parity()
 
 
 if __name__ == '__main__':
