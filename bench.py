@@ -32,6 +32,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, Peak
 PEAK_HBM_GBS = 8000.0
 # algorithmic train-step GFLOP per image, conv MACs x2 only, no credit for recompute
 TRAIN_GFLOP_PER_IMG = {(2, 68): 16.252, (8, 68): 65.731, (8, 16): 64.422, (16, 16): 129.086}
+FWD_GFLOP_PER_IMG = {(2, 68): 5.623, (8, 68): 22.116, (8, 16): 21.680, (16, 16): 43.234}
 
 
 def log(*a):
@@ -85,6 +86,7 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default='')
+    ap.add_argument('--forward-only', action='store_true', help='inference: eval-mode forward (running statistics), no loss / backward')
     ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
     args = ap.parse_args()
 
@@ -128,13 +130,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    plan = net._get_plan(bs, 256, 256, True)
+    if args.forward_only:
+        net.eval()
+
+        def one_step():
+            with torch.no_grad():
+                outs = net(x)                                  # the public path: loss_num NCHW heat maps
+            return outs[-1][0, 0, 0, 0]
+    else:
+        def one_step():
+            return tr.step(x, t)
+    plan = net._get_plan(bs, 256, 256, not args.forward_only)
     # ---- warm-up; one of the warm-up steps is profiled per kernel class to pick the dominant one
     for i in range(max(args.warmup, 1)):
         if i == max(args.warmup, 1) - 1:
             plan.handle.profile_reset()
             plan.handle.profile_begin(1)
-        loss = tr.step(x, t)
+        loss = one_step()
     torch.cuda.synchronize(dev)
     prof_all = plan.handle.profile_collect()
     plan.handle.profile_begin(0)
@@ -158,7 +170,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.step(x, t)
+        loss = one_step()
     barrier()
     dt = time.perf_counter() - t0
     prof = plan.handle.profile_collect()
@@ -199,23 +211,24 @@ def main():
         except Exception:
             pass
         out = {
-            'metric': 'images/sec train step, 256x256x3 -> 64x64xK heatmaps, CU-Net-%d' % L,
+            'metric': ('images/sec inference forward' if args.forward_only else 'images/sec train step')
+                      + ', 256x256x3 -> 64x64xK heatmaps, CU-Net-%d' % L,
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
                                    + (f'QuanOp bits_w={args.bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if args.bits_w > 0 else '')
-                                   + 'fp32 train step (fwd + MSE + bwd + RMSprop'
-                                   + (' + RCCL bucketed grad all-reduce)' if world > 1 else ')'),
+                                   + ('fp32 eval-mode forward only' if args.forward_only else 'fp32 train step (fwd + MSE + bwd + RMSprop')
+                                   + ('' if args.forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')),
                        'global_batch': world * bs, 'parallelism': f'dp{world}'},
             'roofline': roof,
             'final_loss': final_loss,
         }
-        g = TRAIN_GFLOP_PER_IMG.get((L, K))
+        g = (FWD_GFLOP_PER_IMG if args.forward_only else TRAIN_GFLOP_PER_IMG).get((L, K))
         if g:
             out['step_tflops'] = round(g * value / 1e3, 2)
             out['step_frac_of_f32_mfma_peak'] = round(g * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out['cpu_baseline'] = cpu_baseline(L, K, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:

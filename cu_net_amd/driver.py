@@ -207,18 +207,12 @@ class SyntheticLoader:
         return self.nbatches
 
     def __iter__(self):
+        from .trainer import pts2heatmap
         g = torch.Generator().manual_seed(self.seed)
-        ys, xs = torch.meshgrid(torch.arange(7.), torch.arange(7.), indexing='ij')
-        blob = torch.exp(-((xs - 3) ** 2 + (ys - 3) ** 2) / 9.0)       # pylib/HumanPts.py:49-76, sigma 1
         for _ in range(self.nbatches):
             img = torch.rand(self.batch, 3, 256, 256, generator=g)
-            hm = torch.zeros(self.batch, self.k, 64, 64)
-            cx = torch.randint(3, 61, (self.batch, self.k), generator=g)
-            cy = torch.randint(3, 61, (self.batch, self.k), generator=g)
-            for n in range(self.batch):
-                for c in range(self.k):
-                    hm[n, c, cy[n, c] - 3:cy[n, c] + 4, cx[n, c] - 3:cx[n, c] + 4] = blob
-            yield img.to(self.device), hm.to(self.device)
+            pts = torch.randint(3, 61, (self.batch, self.k, 2), generator=g).double()
+            yield img.to(self.device), pts2heatmap(pts.to(self.device), (64, 64), 1)     # targets rendered on the GPU
 
 
 # ---- loops ------------------------------------------------------------------------------------
