@@ -461,12 +461,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
     const Wg2Group g = q.grp[gi];
     const int chunk = blockIdx.x - g.chunk0;
     const int rpc = q.rows_per_chunk[gi];
-    if (q.stem) {
-        if constexpr (NTW == 4) {
-            if (g.ct == 2) wg2_body<4, 2, false, true>(q, g, chunk, rpc, lds);
-            else wg2_body<4, 1, false, true>(q, g, chunk, rpc, lds);
-        }
-    } else if (q.any_ups) {
+    if (q.any_ups) {
         if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), true>(q, g, chunk, rpc, lds);
         else if (g.ct == 2) wg2_body<NTW, 2, true>(q, g, chunk, rpc, lds);
         else wg2_body<NTW, 1, true>(q, g, chunk, rpc, lds);
@@ -475,6 +470,22 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
         else if (g.ct == 2) wg2_body<NTW, 2, false>(q, g, chunk, rpc, lds);
         else wg2_body<NTW, 1, false>(q, g, chunk, rpc, lds);
     }
+}
+
+// The stem's 7x7/2 weight gradient on the same design (its own symbol so that profiles separate it):
+// X is the im2col view of the NCHW image, gathered per lane; no BatchNorm in front of it.
+__global__ __launch_bounds__(256, 2) void wgrad2_stem_kernel(const Wg2Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    int gi = 0;
+    for (int t = 1; t < q.ngroups; ++t)
+        if ((int)blockIdx.x >= q.grp[t].chunk0) gi = t;
+    const Wg2Group g = q.grp[gi];
+    const int chunk = blockIdx.x - g.chunk0;
+    const int rpc = q.rows_per_chunk[gi];
+    if (g.ct == 3) wg2_body<4, 3, false, true>(q, g, chunk, rpc, lds);       // 147 input channels = 3 + 2 tiles: dY is read twice
+    else if (g.ct == 2) wg2_body<4, 2, false, true>(q, g, chunk, rpc, lds);
+    else wg2_body<4, 1, false, true>(q, g, chunk, rpc, lds);
 }
 
 static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) {
@@ -493,7 +504,8 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     const int ctmax = ntw == 4 ? 2 : 4;          // <= 8 accumulators: two waves per SIMD
     int left = C32;
     while (left > 0 && ng < 12) {
-        const int ct = (left >= 4 && ctmax >= 4) ? 4 : (left >= 2 ? 2 : 1);
+        int ct = (left >= 4 && ctmax >= 4) ? 4 : (left >= 2 ? 2 : 1);
+        if (q.stem && left >= 3 && ng == 0) ct = 3;          // scalar gathers: any tile count works (12 accumulators still fit)
         q.grp[ng].c0 = c; q.grp[ng].ct = ct;
         c += 32 * ct; left -= ct; weight += ct; ++ng;
     }
@@ -526,11 +538,13 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     if (!done) {
         hipError_t e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4>));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_stem_kernel));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1>));
         if (e != hipSuccess) return e;
         done = true;
     }
-    if (ntw == 4) hipLaunchKernelGGL(wgrad2_kernel<4>, grid, dim3(256), smem, s, q);
+    if (q.stem) hipLaunchKernelGGL(wgrad2_stem_kernel, grid, dim3(256), smem, s, q);
+    else if (ntw == 4) hipLaunchKernelGGL(wgrad2_kernel<4>, grid, dim3(256), smem, s, q);
     else if (ntw == 2) hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(256), smem, s, q);
     else hipLaunchKernelGGL(wgrad2_kernel<1>, grid, dim3(256), smem, s, q);
     return hipGetLastError();

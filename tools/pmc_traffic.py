@@ -14,6 +14,7 @@ import sys
 import pandas as pd
 
 CLASSES = [
+    (r'wgrad2_stem_kernel', 'stem_bwd_weight'),
     (r'wgrad2_kernel', 'conv1x1_bwd_weight'),
     (r'wgrad_kernel<\(?cunet::\)?1|wgrad_kernel<1,', 'conv3x3_bwd_weight'),
     (r'wgrad_kernel<2,', 'stem_bwd_weight'),
