@@ -316,3 +316,40 @@ def test_target_synthesis_bit_exact():
     batch = cu_net_amd.pts2heatmap(pts.view(2, 20, 2).cuda(), (64, 64))
     ref1 = DR.pts2heatmap(z['pts'].copy(), (64, 64), 1)[0].astype(np.float32)
     assert batch.shape == (2, 20, 64, 64) and torch.equal(batch.view(40, 64, 64).cpu(), torch.from_numpy(ref1))
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 128, 192), (3, 192, 128), (1, 256, 128)])
+def test_non_square_and_odd_batches_match_oracle(n, h, w):
+    """Rectangular inputs and odd batch sizes (ragged 32-row tiles at the coarse levels): forward outputs, loss,
+    running statistics and parameter gradients of one train step against the oracle evaluated on the spot."""
+    cfg = dict(neck_size=2, growth_rate=8, init_chan_num=16, class_num=5, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=31)
+    gen = torch.Generator().manual_seed(32)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    target = torch.rand(n, 5, h // 4, w // 4, generator=gen) * 0.2
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net.cuda().train()
+    tr = FusedTrainer(net)
+    loss = tr.step(x.cuda(), target.cuda())
+    outs = tr.last_outputs(x.shape)
+    st_ref = {k: v.clone() for k, v in st.items()}
+    ref_loss, ref_outs, ref_grads = O.train_step(spec, st_ref, x, target)
+    assert abs(float(loss) - float(ref_loss)) <= RTOL_TOY * abs(float(ref_loss))
+    for a, b in zip(outs, ref_outs):
+        assert a.shape == b.shape
+        assert (a.cpu() - b).abs().max().item() <= RTOL_TOY * b.abs().max().item() + ATOL
+    sd = net.state_dict()
+    for k, v in st_ref.items():
+        if 'running' in k:
+            assert (sd[k].cpu() - v).abs().max().item() <= 10 * RTOL_TOY * v.abs().max().item() + ATOL, k
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    num = den = 0.0
+    for k, gref in ref_grads.items():
+        if gref is None:
+            continue
+        o, nmel, shape = off[k]
+        got = net._grad_arena[o:o + nmel].view(shape).cpu().double()
+        num += float((got - gref.double()).pow(2).sum()); den += float(gref.double().pow(2).sum())
+    assert (num / den) ** 0.5 <= L2_GRAD, (num / den) ** 0.5
