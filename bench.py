@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default='')
     ap.add_argument('--forward-only', action='store_true', help='inference: eval-mode forward (running statistics), no loss / backward')
+    ap.add_argument('--bf16', action='store_true', help='with --forward-only: bf16-storage inference (cunet_forward_bf16)')
     ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
     args = ap.parse_args()
 
@@ -135,7 +136,7 @@ def main():
 
         def one_step():
             with torch.no_grad():
-                outs = net(x)                                  # the public path: loss_num NCHW heat maps
+                outs = net.forward_bf16(x) if args.bf16 else net(x)      # the public path: loss_num NCHW heat maps
             return outs[-1][0, 0, 0, 0]
     else:
         def one_step():
@@ -150,6 +151,9 @@ def main():
     torch.cuda.synchronize(dev)
     prof_all = plan.handle.profile_collect()
     plan.handle.profile_begin(0)
+    if args.bf16 and not args.forward_only:
+        raise SystemExit('--bf16 is an inference mode: use it with --forward-only')
+    have_classes = any(v[0] for v in prof_all.values())       # the bf16 path is not instrumented per class
     dominant = max(prof_all.items(), key=lambda kv: kv[1][1])[0]
     if rank == 0:
         tot = sum(v[1] for v in prof_all.values())
@@ -187,7 +191,10 @@ def main():
         value = imgs / dt
         cnt, ms, fl, by = prof[dominant]
         mfma_bound = fl > 0
-        if mfma_bound:
+        roof = None
+        if not have_classes:
+            pass
+        elif mfma_bound:
             achieved = fl / (ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
@@ -197,11 +204,16 @@ def main():
             roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS,
                     'unit': 'GB/s', 'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
                     'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
+        if not have_classes:      # bf16 inference: whole-forward algorithmic bytes (bf16 forward is HBM-bound) against HBM peak
+            fb = {(2, 68): 55.2e6, (8, 68): 221.7e6, (8, 16): 218.3e6, (16, 16): 437.0e6}.get((L, K))
+            ach = (fb * value / 1e9) if fb else 0.0
+            roof = {'bound': 'hbm', 'kernel': 'whole forward (conv inputs + outputs once, bf16)', 'achieved': round(ach, 1),
+                    'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
         # HBM bytes per launch of that kernel class from the committed PMC passes (rocprofv3 --pmc cannot run inside
         # this process): profiles/r01_traffic.json, produced by tools/profile_round.sh + tools/pmc_traffic.py on
         # this workload.  null when the file has no entry for the class or the workload is not the profiled one.
         try:
-            if (L, K, bs) == (2, 68, 24):
+            if (L, K, bs) == (2, 68, 24) and have_classes:
                 tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')))
                 ent = tj['classes'].get(dominant)
                 if ent:
@@ -215,10 +227,10 @@ def main():
                       + ', 256x256x3 -> 64x64xK heatmaps, CU-Net-%d' % L,
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
                                    + (f'QuanOp bits_w={args.bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if args.bits_w > 0 else '')
-                                   + ('fp32 eval-mode forward only' if args.forward_only else 'fp32 train step (fwd + MSE + bwd + RMSprop')
+                                   + (('bf16-storage' if args.bf16 else 'fp32') + ' eval-mode forward only' if args.forward_only else 'fp32 train step (fwd + MSE + bwd + RMSprop')
                                    + ('' if args.forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')),
                        'global_batch': world * bs, 'parallelism': f'dp{world}'},
             'roofline': roof,
@@ -227,7 +239,10 @@ def main():
         g = (FWD_GFLOP_PER_IMG if args.forward_only else TRAIN_GFLOP_PER_IMG).get((L, K))
         if g:
             out['step_tflops'] = round(g * value / 1e3, 2)
-            out['step_frac_of_f32_mfma_peak'] = round(g * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)
+            if args.bf16:
+                out['step_frac_of_bf16_mfma_peak'] = round(g * value / 1e3 / (2500.0 * world), 4)      # dense bf16 MFMA ~2.5 PFLOP/s
+            else:
+                out['step_frac_of_f32_mfma_peak'] = round(g * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out['cpu_baseline'] = cpu_baseline(L, K, args.cpu_steps)
         print(json.dumps(out), flush=True)

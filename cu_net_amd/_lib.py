@@ -65,6 +65,7 @@ def lib():
         'cunet_bucket_order': (i32, [vp, C.POINTER(C.c_int32), i32]),
         'cunet_backward_ex': (i32, [vp, C.POINTER(vp), vp, BUCKET_CB, vp]),
         'cunet_side_stream_join': (i32, [vp, vp]),
+        'cunet_forward_bf16': (i32, [vp, vp, C.POINTER(vp), vp]),
         'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
         'cunet_final_preds': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -96,7 +97,7 @@ def lib():
 EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_plan_destroy', 'cunet_state_count',
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind',
-            'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_bucket_order', 'cunet_num_buckets',
+            'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_flip_merge', 'cunet_render_targets',
             'cunet_debug_tensor_offset', 'cunet_quant_prepare', 'cunet_quant_restore', 'cunet_quant_grad',
             'cunet_ternary_pack', 'cunet_ternary_conv', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
@@ -154,8 +155,9 @@ class PlanHandle:
     def counter_numel(self):
         return int(lib().cunet_counter_numel(self.h))
 
-    def workspace_bytes(self, training: bool):
-        return int(lib().cunet_workspace_bytes(self.h, 1 if training else 0))
+    def workspace_bytes(self, training):
+        """training: False / True, or 2 for inference plus the bf16 arena."""
+        return int(lib().cunet_workspace_bytes(self.h, int(training)))
 
     @property
     def num_heads(self):

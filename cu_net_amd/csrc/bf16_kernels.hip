@@ -1,0 +1,322 @@
+// bf16-storage inference forward (BASELINE config 3 direction: "bf16 storage + fp32 accumulate").
+//
+// Activations live as bf16 NHWC, weights as bf16 MFMA operands, BatchNorm (running statistics) + ReLU are applied
+// in fp32 on load and re-rounded to bf16, the contraction is v_mfma_f32_32x32x16_bf16 with fp32 accumulators.
+// Same structure as conv_kernels.hip (weight-stationary B operand in LDS, independent waves over 32-row tiles, the
+// concat read in place segment by segment, nearest-upsample folded into the row index), at half the bytes per
+// element.  Eval mode only: no batch statistics, no gradients.  The stem (7x7/2 on the fp32 image, BN-ReLU-pool)
+// runs on the fp32 kernels and is converted once.
+//
+// Operand maps of v_mfma_f32_32x32x16_bf16: A lane l holds A[i = l&31][k = 8*(l>>5) .. +7], B lane l holds
+// B[k = 8*(l>>5) .. +7][j = l&31], C/D as the f32 form (col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace cunet {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {     // round to nearest even, (hi << 16) | lo
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1)))* gptr_u32x4;
+__device__ __forceinline__ uint4 ldg16(const u16* p) {       // explicit global address space: never a flat load
+    const u32x4 v = *(gptr_u32x4)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> bf16 (round to nearest even), n multiple of 8
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        reinterpret_cast<uint4*>(dst)[i] = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+    }
+}
+
+hipError_t launch_cvt_bf16(const float* src, void* dst, long n, hipStream_t s) {
+    const long n8 = n / 8;
+    long gx = (n8 + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)gx), dim3(256), 0, s, src, (u16*)dst, n8);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weights torch [Cout][Cin][taps] fp32 -> bf16 B operand [tap][Kpad/8][Npad][8] (K = Cin, N = Cout), one launch
+// for every conv (blockIdx.y); same element offsets (dstF) as the fp32 operand, in the bf16 arena.
+__global__ __launch_bounds__(256) void repack_bf16_kernel(const RepackEntry* tab, const float* params, u16* arena) {
+    const RepackEntry e = tab[blockIdx.y];
+    const float* w = params + e.src;
+    const long total = (long)e.taps * e.KpadF * e.NpadF;
+    u16* dst = arena + e.dstF;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total / 2; i += (long)gridDim.x * 256) {
+        const long j = 2 * i;
+        const int ee = (int)(j & 7);
+        long r = j >> 3;
+        const int n = (int)(r % e.NpadF); r /= e.NpadF;
+        const int kq = (int)(r % (e.KpadF >> 3));
+        const int t = (int)(r / (e.KpadF >> 3));
+        const int k = 8 * kq + ee;
+        const float a = (k < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k) * e.taps + t] : 0.f;
+        const float b = (k + 1 < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k + 1) * e.taps + t] : 0.f;
+        reinterpret_cast<unsigned*>(dst)[i] = pack_bf16(a, b);
+    }
+}
+
+hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(repack_bf16_kernel, dim3(16, n), dim3(256), 0, s, tab, params, (u16*)arena);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x2/2 max-pool over bf16 NHWC (max of bf16 values is exact in any precision)
+__global__ __launch_bounds__(256) void pool_bf16_kernel(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C) {
+    const int g8 = C >> 3;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * g8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / g8;
+        const int g = (int)(idx - row * g8);
+        const int ni = (int)(row / (Ho * Wo));
+        const int rm = (int)(row - (long)ni * Ho * Wo);
+        const int yo = rm / Wo, xo = rm - yo * Wo;
+        const size_t m00 = ((size_t)ni * H + 2 * yo) * W + 2 * xo;
+        const size_t off[4] = {m00, m00 + 1, m00 + W, m00 + W + 1};
+        float best[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 v = ldg16(x + off[k] * C + 8 * g);
+            const unsigned q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bf16_lo(q[e]), hi = bf16_hi(q[e]);
+                best[2 * e] = k == 0 ? lo : fmaxf(best[2 * e], lo);
+                best[2 * e + 1] = k == 0 ? hi : fmaxf(best[2 * e + 1], hi);
+            }
+        }
+        reinterpret_cast<uint4*>(y + (size_t)row * C + 8 * g)[0] =
+            make_uint4(pack_bf16(best[0], best[1]), pack_bf16(best[2], best[3]), pack_bf16(best[4], best[5]), pack_bf16(best[6], best[7]));
+    }
+}
+
+hipError_t launch_pool_bf16(const void* x, void* y, int N, int H, int W, int C, hipStream_t s) {
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
+    long gx = (total + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(pool_bf16_kernel, dim3((unsigned)gx), dim3(256), 0, s, (const u16*)x, (u16*)y, N, H, W, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// [concat -> BatchNorm(eval) -> ReLU] -> 1x1 / 3x3 convolution, bf16 in, bf16 (OUTF32 = 0) or fp32 (heads) out.
+// Seg::x / ConvArgs::y carry bf16 pointers here (typed float* in the shared argument struct); ld in elements.
+// Requirements (checked by the launcher): every segment and K a multiple of 32 channels, M a multiple of 32 rows.
+constexpr int B16_MAX_WAVES = 16;        // <= 128 VGPRs per lane (the widest variant uses 118)
+
+template <int TAPS, int NT, int OUTF32>
+__global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NB = NT * 32;
+    const int kq8 = p.Kpad >> 3;
+    const int brows = TAPS * kq8;                     // 16-byte rows of B
+    uint4* Bs = reinterpret_cast<uint4*>(smem);       // [TAPS * Kpad/8][NB]
+    float* sc = reinterpret_cast<float*>(Bs + (size_t)brows * NB);
+    float* sh = sc + p.Ccat;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const u16* wB = reinterpret_cast<const u16*>(p.wB);
+
+    {   // B operand -> LDS (8 loads in flight per thread)
+        const int total = brows * NB;
+        for (int base = tid; base < total; base += blockDim.x * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * blockDim.x;
+                const int ic = idx < total ? idx : 0;
+                const int row = ic / NB;
+                const int n = ic - row * NB;
+                const int nn = (n0 + n < p.Npad) ? n0 + n : 0;
+                v[u] = ldg16(wB + ((size_t)row * p.Npad + nn) * 8);
+                if (n0 + n >= p.Npad) v[u] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * blockDim.x;
+                if (idx < total) Bs[idx] = v[u];
+            }
+        }
+    }
+    for (int c = tid; c < p.Ccat; c += blockDim.x) {   // BatchNorm in eval mode: running statistics
+        const double istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - (double)p.rmean[c] * scale);
+    }
+    __syncthreads();
+
+    const int HW = p.H * p.W;
+    const int nck = p.Kpad >> 5;                      // 32-channel chunks per tap
+    const int ntiles = p.M >> 5;
+
+    for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+        const int m = tile * 32 + li;
+        const int nimg = m / HW;
+        const int rem = m - nimg * HW;
+        const int py = rem / p.W;
+        const int px = rem - py * p.W;
+        const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+        int sidx = 0, cl = 0, ncs = 0, tap = 0;
+        const u16* rowptr = nullptr;
+        bool tvalid = true;
+        auto enter = [&]() {
+            if (TAPS == 1) {
+                const Seg sg = p.seg[sidx];
+                rowptr = reinterpret_cast<const u16*>(sg.x) + (size_t)(sg.ups ? rowU : m) * sg.ld + 8 * hi;
+                ncs = sg.C >> 5;
+            } else {
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int yy = py + dy, xx = px + dx;
+                tvalid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+                rowptr = reinterpret_cast<const u16*>(p.seg[0].x) + (size_t)(tvalid ? m + dy * p.W + dx : m) * p.seg[0].ld + 8 * hi;
+                ncs = nck;
+            }
+            cl = 0;
+        };
+        const int nchunks = TAPS * nck;
+        enter();
+        uint4 anext[2];
+        bool vcur = tvalid;
+        anext[0] = ldg16(rowptr);
+        anext[1] = ldg16(rowptr + 16);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            uint4 acur[2] = {anext[0], anext[1]};
+            const bool vthis = vcur;
+            if (ch + 1 < nchunks) {
+                if (++cl == ncs) { ++sidx; ++tap; enter(); }
+                vcur = tvalid;
+                anext[0] = ldg16(rowptr + cl * 32);
+                anext[1] = ldg16(rowptr + cl * 32 + 16);
+            }
+            const int cc = (TAPS == 9) ? (ch % nck) : ch;                 // channel chunk inside the concat
+            const uint4* bb = Bs + (size_t)ch * 4 * NB;                      // rows (ch*4 + 2s + hi)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // BN + ReLU on the 8 channels cc*32 + 16s + 8hi .. +7, back to bf16
+                const float* scp = sc + cc * 32 + 16 * s + 8 * hi;
+                const float* shp = sh + cc * 32 + 16 * s + 8 * hi;
+                const float4 s0 = *reinterpret_cast<const float4*>(scp), s1 = *reinterpret_cast<const float4*>(scp + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(shp), h1 = *reinterpret_cast<const float4*>(shp + 4);
+                const uint4 v = acur[s];
+                uint4 a;
+                a.x = pack_bf16(fmaxf(fmaf(bf16_lo(v.x), s0.x, h0.x), 0.f), fmaxf(fmaf(bf16_hi(v.x), s0.y, h0.y), 0.f));
+                a.y = pack_bf16(fmaxf(fmaf(bf16_lo(v.y), s0.z, h0.z), 0.f), fmaxf(fmaf(bf16_hi(v.y), s0.w, h0.w), 0.f));
+                a.z = pack_bf16(fmaxf(fmaf(bf16_lo(v.z), s1.x, h1.x), 0.f), fmaxf(fmaf(bf16_hi(v.z), s1.y, h1.y), 0.f));
+                a.w = pack_bf16(fmaxf(fmaf(bf16_lo(v.w), s1.z, h1.z), 0.f), fmaxf(fmaf(bf16_hi(v.w), s1.w, h1.w), 0.f));
+                if (TAPS == 9 && !vthis) a = make_uint4(0, 0, 0, 0);        // zero padding is post-activation
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const int mrow0 = tile * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 32 + li;
+            if (col < p.Nout) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (OUTF32) p.y[(size_t)mm * p.ldy + col] = acc[nt][r];
+                    else reinterpret_cast<u16*>(p.y)[(size_t)mm * p.ldy + col] = (u16)(pack_bf16(acc[nt][r], 0.f) & 0xffffu);
+                }
+            }
+        }
+    }
+}
+
+static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
+    return (size_t)taps * (Kpad / 8) * NT * 32 * 16 + (size_t)Ccat * 8;
+}
+
+template <int TAPS, int NT, int OUTF32>
+static hipError_t launch_b16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TAPS, NT, OUTF32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_bf16_kernel<TAPS, NT, OUTF32>), grid, dim3(threads), smem, s, a);
+    return hipGetLastError();
+}
+
+// a.seg[*].x, a.wB: bf16 data behind float-typed pointers; a.y: bf16 (out_f32 = 0) or fp32 (out_f32 = 1)
+hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStream_t s) {
+    if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
+    const int ntiles = a.M / 32;
+    const int ncol32 = (a.Nout + 31) / 32;
+    const long target = 2L * 4 * num_cus;
+    int NT = 1;
+    float best = 1e30f;
+    for (int c = 4; c >= 1; c = (c == 4 ? 2 : c - 1)) {       // 4, 2, 1
+        if (conv_bf16_smem(c, a.taps, a.Kpad, a.Ccat) > 150 * 1024) continue;
+        const int slices = (ncol32 + c - 1) / c;
+        if (c > 1 && (long)ntiles * slices < target) continue;
+        const float cost = slices * ((float)c + 0.3f);
+        if (cost < best) { best = cost; NT = c; }
+    }
+    const size_t smem = conv_bf16_smem(NT, a.taps, a.Kpad, a.Ccat);
+    if (smem > 150 * 1024) return hipErrorInvalidValue;
+    const int gy = (ncol32 + NT - 1) / NT;
+    const int blocks_per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : 3);
+    const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
+    int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
+    if (waves > B16_MAX_WAVES / blocks_per_cu) waves = B16_MAX_WAVES / blocks_per_cu;
+    if (waves < 1) waves = 1;
+    int gx = (ntiles + waves - 1) / waves;
+    if (gx > max_blocks_x) gx = max_blocks_x;
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, gy);
+    const int threads = (waves < 4 ? 4 : waves) * 64;
+#define CUNET_B16(T, N) \
+    if (a.taps == T && NT == N) return out_f32 ? launch_b16_inst<T, N, 1>(a, grid, threads, smem, s) : launch_b16_inst<T, N, 0>(a, grid, threads, smem, s);
+    CUNET_B16(1, 1) CUNET_B16(1, 2) CUNET_B16(1, 4) CUNET_B16(9, 1) CUNET_B16(9, 2) CUNET_B16(9, 4)
+#undef CUNET_B16
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cunet

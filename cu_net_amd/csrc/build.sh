@@ -6,7 +6,7 @@ OUT=../libcunet_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
-for f in conv_kernels.hip wgrad_kernels.hip elementwise_kernels.hip quant_kernels.hip runtime.hip; do
+for f in conv_kernels.hip wgrad_kernels.hip elementwise_kernels.hip quant_kernels.hip bf16_kernels.hip runtime.hip; do
   hipcc $FLAGS -c $f -o build/${f%.hip}.o &
   pids+=($!)
 done

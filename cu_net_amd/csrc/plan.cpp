@@ -425,6 +425,8 @@ void Plan::layout_workspace() {
     n_floats_train = f;
     ws_bytes_infer = off_floats + n_floats_infer * 4;
     ws_bytes_train = off_floats + n_floats_train * 4;
+    off_bf16 = round_up64(ws_bytes_infer, 256);
+    ws_bytes_bf16 = off_bf16 + n_floats_infer * 2;
 }
 
 void Plan::describe() {

@@ -142,7 +142,9 @@ int64_t cunet_param_numel(const cunet_plan_t* p) { return p ? p->plan.n_params :
 int64_t cunet_buffer_numel(const cunet_plan_t* p) { return p ? p->plan.n_buffers : 0; }
 int64_t cunet_counter_numel(const cunet_plan_t* p) { return p ? p->plan.n_counters : 0; }
 int64_t cunet_workspace_bytes(const cunet_plan_t* p, int training) {
-    return p ? (training ? p->plan.ws_bytes_train : p->plan.ws_bytes_infer) : 0;
+    if (!p) return 0;
+    if (training == 2) return p->plan.ws_bytes_bf16;      // inference incl. the bf16 arena of cunet_forward_bf16
+    return training ? p->plan.ws_bytes_train : p->plan.ws_bytes_infer;
 }
 int cunet_num_heads(const cunet_plan_t* p) { return p ? (int)p->plan.head_tensors.size() : 0; }
 int cunet_loss_anchors(const cunet_plan_t* p, int32_t* anchors, int capacity) {
@@ -495,6 +497,78 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     h->fwd_training_done = training ? 1 : 0;
     h->loss_done = 0;
     h->last_x = x;
+    return CUNET_OK;
+}
+
+int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, void* stream) {
+    if (!h || !x || !heat) return fail(CUNET_ERR_INVALID, "null argument");
+    if (!h->ws) return fail(CUNET_ERR_STATE, "cunet_bind has not been called");
+    Plan& P = h->plan;
+    if (h->ws_bytes < P.ws_bytes_bf16) return fail(CUNET_ERR_STATE, "workspace smaller than cunet_workspace_bytes(plan, 2)");
+    hipStream_t s = (hipStream_t)stream;
+    Exec E(h);
+    const int cus = h->num_cus;
+    unsigned short* a16 = reinterpret_cast<unsigned short*>(h->ws + P.off_bf16);      // bf16 arena, element offsets as the fp32 layout
+    HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));   // (stem operand)
+    HIPCHK(launch_repack_bf16(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, a16, s));
+    for (size_t ni = 0; ni < P.nodes.size(); ++ni) {
+        const Node& n = P.nodes[ni];
+        const TensorInfo& o = P.tensors[n.out];
+        if (n.type == N_STEM_CONV) {               // fp32 kernels on the fp32 image
+            const ConvInfo& c = P.convs[n.conv];
+            ConvArgs a{};
+            a.nseg = 0; a.Ccat = 0; a.training = 0;
+            a.K = c.Cin; a.taps = 1; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
+            a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = nullptr;
+            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            a.img = x; a.IH = P.cfg.height; a.IW = P.cfg.width;
+            HIPCHK(launch_conv(a, LD_STEM, EP_FWD, cus, s));
+        } else if (n.type == N_STEM_BNPOOL) {
+            const int tin = n.segs[0].tensor;
+            const TensorInfo& ti = P.tensors[tin];
+            const BnInfo& b = P.bns[n.bn];
+            PoolArgs a{};
+            a.x = E.act(tin); a.y = E.act(n.out); a.ystats = nullptr;
+            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 0;
+            a.xstats = nullptr; a.count = (double)ti.rows();
+            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+            HIPCHK(launch_pool_fwd(a, 1, cus, s));
+            if (o.ld != o.C || (o.rows() * o.C) % 8) return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 8");
+            HIPCHK(launch_cvt_bf16(E.act(n.out), a16 + o.act, (long)o.rows() * o.ld, s));
+        } else if (n.type == N_POOL) {
+            const int tin = n.segs[0].tensor;
+            const TensorInfo& ti = P.tensors[tin];
+            if (ti.C % 8 || ti.ld != ti.C) return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 8");
+            HIPCHK(launch_pool_bf16(a16 + ti.act, a16 + o.act, ti.N, ti.H, ti.W, ti.C, s));
+        } else {  // N_CONV
+            const ConvInfo& c = P.convs[n.conv];
+            const BnInfo& b = P.bns[n.bn];
+            ConvArgs a{};
+            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+            for (int i = 0; i < a.nseg; ++i)       // the bf16 copies of the inputs
+                a.seg[i].x = reinterpret_cast<const float*>(a16 + P.tensors[n.segs[i].tensor].act);
+            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+            a.training = 0;
+            a.K = n.Ccat; a.taps = c.taps; a.wB = reinterpret_cast<const float*>(a16 + c.wF); a.Kpad = c.KpadF; a.Npad = c.NpadF;
+            const int is_head = n.head >= 0;
+            a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
+            a.ldy = o.ld; a.Nout = c.Cout; a.ystats = nullptr;
+            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            hipError_t e = launch_conv_bf16(a, is_head, cus, s);
+            if (e == hipErrorInvalidValue)
+                return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 32 and rows of 32 (node " + n.name + ")");
+            HIPCHK(e);
+        }
+    }
+    for (size_t i = 0; i < P.head_tensors.size(); ++i) {
+        if (!heat[i]) continue;
+        const TensorInfo& t = P.tensors[P.head_tensors[i]];
+        HIPCHK(launch_transpose(E.act(P.head_tensors[i]), heat[i], t.N, t.C, t.H * t.W, t.ld, 0, s));
+    }
+    h->fwd_training_done = 0;
+    h->loss_done = 0;
     return CUNET_OK;
 }
 

@@ -39,12 +39,12 @@ def _stream_ptr(device) -> C.c_void_p:
 class _BoundPlan:
     """A plan specialised for (batch, H, W) with its workspace, bound to the module's arenas."""
 
-    def __init__(self, net: 'CUNet', n: int, h: int, w: int, training_ws: bool):
+    def __init__(self, net: 'CUNet', n: int, h: int, w: int, training_ws: bool, bf16: bool = False):
         self.handle = PlanHandle(*net._hyper, batch=n, height=h, width=w)
         self.shape = (n, h, w)
         self.training_ws = training_ws
         dev = net._param_arena.device
-        nbytes = self.handle.workspace_bytes(training_ws)
+        nbytes = self.handle.workspace_bytes(2 if bf16 else training_ws)      # 2: inference + bf16 arena
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.hw_out = (h // 4, w // 4)
@@ -69,6 +69,14 @@ class _BoundPlan:
                                   _stream_ptr(x.device)), 'cunet_forward')
         self.generation += 1
         self._last_x = x          # the stem's weight gradient re-reads the image during backward
+        return outs
+
+    def forward_bf16(self, x: torch.Tensor) -> List[torch.Tensor]:
+        n, h, w = self.shape
+        k = self.handle.cfg.class_num
+        outs = [torch.empty((n, k, self.hw_out[0], self.hw_out[1]), dtype=torch.float32, device=x.device) for _ in range(self.num_heads)]
+        arr = (C.c_void_p * self.num_heads)(*[o.data_ptr() for o in outs])
+        check(lib().cunet_forward_bf16(self.handle.h, _ptr(x), arr, _stream_ptr(x.device)), 'cunet_forward_bf16')
         return outs
 
     def loss_mse(self, target: torch.Tensor) -> torch.Tensor:
@@ -302,6 +310,25 @@ class CUNet(nn.Module):
             plan = _BoundPlan(self, n, h, w, need_grad)
             self._plans[key] = plan
         return plan
+
+    def forward_bf16(self, x):
+        """Inference with bf16 storage: activations and weights are bf16 between the stem and the heads, contracted
+        with bf16 MFMA into fp32 accumulators; BatchNorm (running statistics) + ReLU in fp32.  Same inputs and outputs
+        as `forward` in eval mode (fp32 NCHW); heat maps agree with it to about 1e-2 of their range.  Not a reference
+        feature (the reference is fp32): BASELINE config 3's storage format, inference half."""
+        if self.training:
+            raise CUNetError('forward_bf16 is an inference path: call net.eval() first')
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3 or not x.is_cuda or x.dtype != torch.float32:
+            raise CUNetError('input must be an fp32 N x 3 x H x W GPU tensor')
+        self._check_aliasing()
+        x = x.contiguous()
+        n, _, h, w = x.shape
+        key = ('bf16', n, h, w)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _BoundPlan(self, n, h, w, False, bf16=True)
+            self._plans[key] = plan
+        return plan.forward_bf16(x)
 
     def forward(self, x):
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:

@@ -353,3 +353,40 @@ def test_non_square_and_odd_batches_match_oracle(n, h, w):
         got = net._grad_arena[o:o + nmel].view(shape).cpu().double()
         num += float((got - gref.double()).pow(2).sum()); den += float(gref.double().pow(2).sum())
     assert (num / den) ** 0.5 <= L2_GRAD, (num / den) ** 0.5
+
+
+def test_bf16_inference_forward_close_to_fp32():
+    """bf16-storage inference (cunet_forward_bf16) against the fp32 HIP eval forward and the fp32 oracle at production
+    widths.  Tolerance for bf16 storage (8 mantissa bits, re-rounded after every BatchNorm+ReLU and every conv):
+    max |diff| <= 3e-2 of the heat-map range; the arg-max landmarks of clear peaks must not move by more than a pixel."""
+    g = Golden('G5_full_L2K68')
+    spec = O.Spec(**g.cfg)
+    st = O.init_state(spec, seed=int(g.z['init_seed']))
+    x, target = O.synthetic_batch(2, spec.class_num, 256, seed=11)
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(st)
+    net.cuda().train()
+    tr = FusedTrainer(net, lr=1e-3)
+    for _ in range(3):                                   # move weights and running statistics off their initial values
+        tr.step(x.cuda(), target.cuda())
+    net.eval()
+    with torch.no_grad():
+        ref = net(x.cuda())
+        got = net.forward_bf16(x.cuda())
+    assert len(got) == len(ref)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a.shape == b.shape and a.dtype == torch.float32
+        rng = (b.max() - b.min()).item()
+        err = (a - b).abs().max().item()
+        assert err <= 3e-2 * rng, (i, err, rng)
+        rel2 = ((a - b).double().norm() / b.double().norm()).item()
+        assert rel2 <= 2e-2, (i, rel2)
+    st1 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    oref = O.forward(spec, st1, x, training=False)
+    assert (got[-1].cpu() - oref[-1]).abs().max().item() <= 3e-2 * (oref[-1].max() - oref[-1].min()).item()
+    try:
+        net.train()
+        net.forward_bf16(x.cuda())
+        assert False, 'forward_bf16 must refuse training mode'
+    except cu_net_amd.CUNetError:
+        pass
