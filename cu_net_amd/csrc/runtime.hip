@@ -635,7 +635,6 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     hipStream_t s = (hipStream_t)stream;
     Exec E(h);
     Plan& P = h->plan;
-    const int cus = h->num_cus;
     if (grad_heat) {
         for (size_t i = 0; i < P.head_tensors.size(); ++i) {
             const TensorInfo& t = P.tensors[P.head_tensors[i]];

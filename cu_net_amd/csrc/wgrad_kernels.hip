@@ -16,7 +16,6 @@
 
 namespace cunet {
 
-constexpr int WG_MAXACC = 9;     // accumulators per wave: up to 9 taps (3x3) or ctw<=9 c-tiles
 constexpr int WG_UNROLL = 4;     // row pairs in flight per wave
 
 enum WgLoad { WG_SEG = 0, WG_3X3 = 1, WG_STEM = 2 };
