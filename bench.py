@@ -87,7 +87,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default='')
     ap.add_argument('--forward-only', action='store_true', help='inference: eval-mode forward (running statistics), no loss / backward')
-    ap.add_argument('--bf16', action='store_true', help='with --forward-only: bf16-storage inference (cunet_forward_bf16)')
+    ap.add_argument('--bf16', action='store_true', help='bf16 activation storage + bf16 MFMA forward (train step: gradients, weights, optimiser stay fp32; '
+                    'with --forward-only: bf16-storage inference)')
     ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
     args = ap.parse_args()
 
@@ -120,7 +121,7 @@ def main():
     if args.bits_w > 0:
         from cu_net_amd.quant import QuanOp
         quan = QuanOp(net, bits_w=args.bits_w, bits_i=8, bits_g=8)
-    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan)
+    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=args.bf16)
     tr.broadcast_parameters(0)
     x, t = synthetic_batch(bs, K, 256, seed=1000 + rank, device=dev)
 
@@ -141,7 +142,7 @@ def main():
     else:
         def one_step():
             return tr.step(x, t)
-    plan = net._get_plan(bs, 256, 256, not args.forward_only)
+    plan = net._get_plan(bs, 256, 256, not args.forward_only, bf16=args.bf16)
     # ---- warm-up; one of the warm-up steps is profiled per kernel class to pick the dominant one
     for i in range(max(args.warmup, 1)):
         if i == max(args.warmup, 1) - 1:
@@ -151,8 +152,6 @@ def main():
     torch.cuda.synchronize(dev)
     prof_all = plan.handle.profile_collect()
     plan.handle.profile_begin(0)
-    if args.bf16 and not args.forward_only:
-        raise SystemExit('--bf16 is an inference mode: use it with --forward-only')
     have_classes = any(v[0] for v in prof_all.values())       # the bf16 path is not instrumented per class
     dominant = max(prof_all.items(), key=lambda kv: kv[1][1])[0]
     if rank == 0:
@@ -192,7 +191,7 @@ def main():
         cnt, ms, fl, by = prof[dominant]
         mfma_bound = fl > 0
         roof = None
-        if not have_classes:
+        if not have_classes or ms <= 0:
             pass
         elif mfma_bound:
             achieved = fl / (ms * 1e-3) / 1e12
@@ -204,7 +203,7 @@ def main():
             roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS,
                     'unit': 'GB/s', 'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
                     'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
-        if not have_classes:      # bf16 inference: whole-forward algorithmic bytes (bf16 forward is HBM-bound) against HBM peak
+        if not have_classes and args.forward_only:      # bf16 inference: whole-forward algorithmic bytes (bf16 forward is HBM-bound) against HBM peak
             fb = {(2, 68): 55.2e6, (8, 68): 221.7e6, (8, 16): 218.3e6, (16, 16): 437.0e6}.get((L, K))
             ach = (fb * value / 1e9) if fb else 0.0
             roof = {'bound': 'hbm', 'kernel': 'whole forward (conv inputs + outputs once, bf16)', 'achieved': round(ach, 1),
@@ -230,7 +229,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
                                    + (f'QuanOp bits_w={args.bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if args.bits_w > 0 else '')
-                                   + (('bf16-storage' if args.bf16 else 'fp32') + ' eval-mode forward only' if args.forward_only else 'fp32 train step (fwd + MSE + bwd + RMSprop')
+                                   + (('bf16-storage' if args.bf16 else 'fp32') + ' eval-mode forward only' if args.forward_only else
+                                      ('bf16-activation' if args.bf16 else 'fp32') + ' train step (fwd + MSE + bwd + RMSprop')
                                    + ('' if args.forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')),
                        'global_batch': world * bs, 'parallelism': f'dp{world}'},
             'roofline': roof,

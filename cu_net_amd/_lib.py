@@ -65,7 +65,7 @@ def lib():
         'cunet_bucket_order': (i32, [vp, C.POINTER(C.c_int32), i32]),
         'cunet_backward_ex': (i32, [vp, C.POINTER(vp), vp, BUCKET_CB, vp]),
         'cunet_side_stream_join': (i32, [vp, vp]),
-        'cunet_forward_bf16': (i32, [vp, vp, C.POINTER(vp), vp]),
+        'cunet_forward_bf16': (i32, [vp, vp, C.POINTER(vp), i32, vp]),
         'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
         'cunet_final_preds': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -26,6 +26,13 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {     // round
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
+__device__ __forceinline__ double shfl_xor_d16(double v) {     // value of lane ^ 32
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, 32, 64);
+    hi = __shfl_xor(hi, 32, 64);
+    return __hiloint2double(hi, lo);
+}
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1)))* gptr_u32x4;
 __device__ __forceinline__ uint4 ldg16(const u16* p) {       // explicit global address space: never a flat load
@@ -34,20 +41,57 @@ __device__ __forceinline__ uint4 ldg16(const u16* p) {       // explicit global 
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32 -> bf16 (round to nearest even), n multiple of 8
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, long n8) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-        reinterpret_cast<uint4*>(dst)[i] = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+// fp32 NHWC [rows][C] -> bf16 (round to nearest even) + fp64 batch statistics of the ROUNDED values when
+// ystats != null (they are what every consumer BatchNorm will normalise).  A thread owns 8 channels.
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, double* ystats,
+                                                        long rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);           // [rpi][C][2]
+    const int tid = threadIdx.x;
+    const int g8 = C >> 3;
+    const int rpi = 256 / g8;
+    const int g = tid % g8;
+    const int ry = tid / g8;
+    const bool active = ry < rpi;
+    double s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
+    if (active) {
+        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)row * C + 8 * g);
+            const float4 b = *reinterpret_cast<const float4*>(src + (size_t)row * C + 8 * g + 4);
+            const uint4 q = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+            *reinterpret_cast<uint4*>(dst + (size_t)row * C + 8 * g) = q;
+            const float v[8] = {bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y), bf16_lo(q.z), bf16_hi(q.z), bf16_lo(q.w), bf16_hi(q.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += (double)v[e] * v[e]; }
+        }
+    }
+    if (ystats == nullptr) return;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((size_t)ry * C + 8 * g + e) * 2 + 0] = s1[e];
+            red[((size_t)ry * C + 8 * g + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < rpi; ++r) { a += red[((size_t)r * C + c) * 2 + 0]; b += red[((size_t)r * C + c) * 2 + 1]; }
+        __hip_atomic_fetch_add(ystats + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ystats + C + c, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-hipError_t launch_cvt_bf16(const float* src, void* dst, long n, hipStream_t s) {
-    const long n8 = n / 8;
-    long gx = (n8 + 255) / 256;
-    if (gx > 4096) gx = 4096;
+hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long rows, int C, int num_cus, hipStream_t s) {
+    const int g8 = C / 8;
+    if (g8 < 1 || g8 > 256 || C % 8) return hipErrorInvalidValue;
+    const int rpi = 256 / g8;
+    long gx = (rows + rpi - 1) / rpi;
+    if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)gx), dim3(256), 0, s, src, (u16*)dst, n8);
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)gx), dim3(256), (size_t)rpi * C * 16, s, src, (u16*)dst, ystats, rows, C);
     return hipGetLastError();
 }
 
@@ -80,42 +124,74 @@ hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2x2/2 max-pool over bf16 NHWC (max of bf16 values is exact in any precision)
-__global__ __launch_bounds__(256) void pool_bf16_kernel(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C) {
+// 2x2/2 max-pool over bf16 NHWC (the max of bf16 values is exact) + fp64 batch statistics of the pooled tensor when
+// ystats != null (training).  A thread owns 8 channels; 256 / (C/8) rows per block iteration.
+__global__ __launch_bounds__(256) void pool_bf16_kernel(const u16* __restrict__ x, u16* __restrict__ y, double* ystats,
+                                                         int N, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);           // [rpi][C][2]
+    const int tid = threadIdx.x;
     const int g8 = C >> 3;
+    const int rpi = 256 / g8;
+    const int g = tid % g8;
+    const int ry = tid / g8;
+    const bool active = ry < rpi;
     const int Ho = H >> 1, Wo = W >> 1;
-    const long total = (long)N * Ho * Wo * g8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long row = idx / g8;
-        const int g = (int)(idx - row * g8);
-        const int ni = (int)(row / (Ho * Wo));
-        const int rm = (int)(row - (long)ni * Ho * Wo);
-        const int yo = rm / Wo, xo = rm - yo * Wo;
-        const size_t m00 = ((size_t)ni * H + 2 * yo) * W + 2 * xo;
-        const size_t off[4] = {m00, m00 + 1, m00 + W, m00 + W + 1};
-        float best[8];
+    const long rows = (long)N * Ho * Wo;
+    double s1[8], s2[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint4 v = ldg16(x + off[k] * C + 8 * g);
-            const unsigned q[4] = {v.x, v.y, v.z, v.w};
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
+    if (active) {
+        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
+            const int ni = (int)(row / (Ho * Wo));
+            const int rm = (int)(row - (long)ni * Ho * Wo);
+            const int yo = rm / Wo, xo = rm - yo * Wo;
+            const size_t m00 = ((size_t)ni * H + 2 * yo) * W + 2 * xo;
+            const size_t off[4] = {m00, m00 + 1, m00 + W, m00 + W + 1};
+            float best[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = bf16_lo(q[e]), hi = bf16_hi(q[e]);
-                best[2 * e] = k == 0 ? lo : fmaxf(best[2 * e], lo);
-                best[2 * e + 1] = k == 0 ? hi : fmaxf(best[2 * e + 1], hi);
+            for (int k = 0; k < 4; ++k) {
+                const uint4 v = ldg16(x + off[k] * C + 8 * g);
+                const unsigned q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bf16_lo(q[e]), hi = bf16_hi(q[e]);
+                    best[2 * e] = k == 0 ? lo : fmaxf(best[2 * e], lo);
+                    best[2 * e + 1] = k == 0 ? hi : fmaxf(best[2 * e + 1], hi);
+                }
             }
+            reinterpret_cast<uint4*>(y + (size_t)row * C + 8 * g)[0] =
+                make_uint4(pack_bf16(best[0], best[1]), pack_bf16(best[2], best[3]), pack_bf16(best[4], best[5]), pack_bf16(best[6], best[7]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += best[e]; s2[e] += (double)best[e] * best[e]; }
         }
-        reinterpret_cast<uint4*>(y + (size_t)row * C + 8 * g)[0] =
-            make_uint4(pack_bf16(best[0], best[1]), pack_bf16(best[2], best[3]), pack_bf16(best[4], best[5]), pack_bf16(best[6], best[7]));
+    }
+    if (ystats == nullptr) return;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((size_t)ry * C + 8 * g + e) * 2 + 0] = s1[e];
+            red[((size_t)ry * C + 8 * g + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < rpi; ++r) { a += red[((size_t)r * C + c) * 2 + 0]; b += red[((size_t)r * C + c) * 2 + 1]; }
+        __hip_atomic_fetch_add(ystats + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ystats + C + c, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-hipError_t launch_pool_bf16(const void* x, void* y, int N, int H, int W, int C, hipStream_t s) {
-    const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
-    long gx = (total + 255) / 256;
-    if (gx > 4096) gx = 4096;
+hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H, int W, int C, int num_cus, hipStream_t s) {
+    const int g8 = C / 8;
+    if (g8 < 1 || g8 > 256 || C % 8) return hipErrorInvalidValue;
+    const int rpi = 256 / g8;
+    const long rows = (long)N * (H / 2) * (W / 2);
+    long gx = (rows + rpi - 1) / rpi;
+    if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(pool_bf16_kernel, dim3((unsigned)gx), dim3(256), 0, s, (const u16*)x, (u16*)y, N, H, W, C);
+    hipLaunchKernelGGL(pool_bf16_kernel, dim3((unsigned)gx), dim3(256), (size_t)rpi * C * 16, s, (const u16*)x, (u16*)y, ystats, N, H, W, C);
     return hipGetLastError();
 }
 
@@ -134,6 +210,7 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
     uint4* Bs = reinterpret_cast<uint4*>(smem);       // [TAPS * Kpad/8][NB]
     float* sc = reinterpret_cast<float*>(Bs + (size_t)brows * NB);
     float* sh = sc + p.Ccat;
+    double* redbuf = reinterpret_cast<double*>(sh + p.Ccat + (p.Ccat & 1));      // [NB][2] output statistics (training)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,17 +242,35 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
             }
         }
     }
-    for (int c = tid; c < p.Ccat; c += blockDim.x) {   // BatchNorm in eval mode: running statistics
-        const double istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
-        const double scale = (double)p.gamma[c] * istd;
-        sc[c] = (float)scale;
-        sh[c] = (float)((double)p.beta[c] - (double)p.rmean[c] * scale);
+    if (p.training) {          // batch statistics of each segment (fp64 sums written by the producers' epilogues)
+        for (int sgi = 0; sgi < p.nseg; ++sgi) {
+            const Seg sg = p.seg[sgi];
+            for (int lc = tid; lc < sg.C; lc += blockDim.x) {
+                const int c = sg.choff + lc;
+                const double mean = sg.stats[lc] / sg.count;
+                double var = sg.stats[sg.C + lc] / sg.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const double scale = (double)p.gamma[c] / sqrt(var + (double)BN_EPS);
+                sc[c] = (float)scale;
+                sh[c] = (float)((double)p.beta[c] - mean * scale);
+            }
+        }
+    } else {
+        for (int c = tid; c < p.Ccat; c += blockDim.x) {   // running statistics
+            const double scale = (double)p.gamma[c] / sqrt((double)p.rvar[c] + (double)BN_EPS);
+            sc[c] = (float)scale;
+            sh[c] = (float)((double)p.beta[c] - (double)p.rmean[c] * scale);
+        }
     }
+    for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
     __syncthreads();
 
     const int HW = p.H * p.W;
     const int nck = p.Kpad >> 5;                      // 32-channel chunks per tap
     const int ntiles = p.M >> 5;
+    double dsum[NT], dsq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
     for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
         const int m = tile * 32 + li;
@@ -253,20 +348,55 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + nt * 32 + li;
+            float s1 = 0.f, s2 = 0.f;
             if (col < p.Nout) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (OUTF32) p.y[(size_t)mm * p.ldy + col] = acc[nt][r];
-                    else reinterpret_cast<u16*>(p.y)[(size_t)mm * p.ldy + col] = (u16)(pack_bf16(acc[nt][r], 0.f) & 0xffffu);
+                    if (OUTF32) {
+                        p.y[(size_t)mm * p.ldy + col] = acc[nt][r];
+                    } else {
+                        const unsigned q = pack_bf16(acc[nt][r], 0.f);
+                        reinterpret_cast<u16*>(p.y)[(size_t)mm * p.ldy + col] = (u16)(q & 0xffffu);
+                        const float v = bf16_lo(q);                  // statistics of what the consumers will read
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
                 }
+            }
+            dsum[nt] += (double)s1;
+            dsq[nt] += (double)s2;
+        }
+    }
+
+    // ---- batch statistics of the output (training): lanes (l, l+32) -> waves through LDS -> one fp64 atomic per channel per block
+    if (p.ystats != nullptr && !OUTF32) {
+        double a1[NT], a2[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {               // all lanes active here
+            a1[nt] = dsum[nt] + shfl_xor_d16(dsum[nt]);
+            a2[nt] = dsq[nt] + shfl_xor_d16(dsq[nt]);
+        }
+        if (hi == 0) {                                  // LDS fp64 atomics: one barrier instead of one per wave
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], a1[nt]);
+                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], a2[nt]);
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            const int col = n0 + tid;
+            if (col < p.Nout) {
+                __hip_atomic_fetch_add(p.ystats + col, redbuf[tid * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(p.ystats + p.Nout + col, redbuf[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
 }
 
 static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
-    return (size_t)taps * (Kpad / 8) * NT * 32 * 16 + (size_t)Ccat * 8;
+    return (size_t)taps * (Kpad / 8) * NT * 32 * 16 + (size_t)(Ccat + 1) * 8 + (size_t)NT * 32 * 16;
 }
 
 template <int TAPS, int NT, int OUTF32>

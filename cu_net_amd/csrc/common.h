@@ -61,6 +61,7 @@ struct ConvArgs {
     // ---- stem (LD_STEM): NCHW image
     const float* img;
     int IH, IW;
+    int xbf16;             // EP_BWD: the segments' x are stored as bf16 (a, y, wB stay fp32)
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)
@@ -82,6 +83,7 @@ struct WgradArgs {
     int ctw;               // c-tiles per job (1x1); 3x3 jobs take one c-tile x 9 taps
     const float* img;      // stem
     int IH, IW;
+    int xbf16;             // the segments' x are stored as bf16 (dy and dw stay fp32)
 };
 
 constexpr int MAXGSRC = 8;  // conv consumers gathered per launch (more: further launches with accumulate = 1)
@@ -97,6 +99,7 @@ struct GradSrc {           // one conv node that reads the tensor: its BN backwa
 };
 
 struct GradGatherArgs {    // dX = sum_consumers scale*(dz - mean(dz) - xhat*mean(dz*xhat)), written once per tensor
+    int xbf16;             // 1: x is stored as bf16 (gx, dz stay fp32)
     int nsrc;
     int accumulate;        // 0: store, 1: add to what is there
     GradSrc src[MAXGSRC];
@@ -148,6 +151,7 @@ struct PoolArgs {
     const float* gy;       // [lo][C]
     float* gx;             // [hi][C]
     double* red;           // stem backward reductions [2][C]
+    int xbf16;             // pool backward: x is stored as bf16
 };
 
 struct QuantEntry {      // one target conv: weight [O][I][KK] at float offset `off` of the arena
@@ -176,6 +180,34 @@ __device__ __forceinline__ float ldg1(const float* p) { return *(gptr_f32)(uintp
 __device__ __forceinline__ float4 ldg4(const float* p) {
     const f32x4 v = *(gptr_f32x4)(uintptr_t)p;
     return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// X-operand loaders for the two activation storages: XB = 0 fp32, XB = 1 bf16 (training with bf16 activations keeps
+// gradients in fp32).  The argument structs type every activation pointer `const float*`; for XB = 1 it addresses bf16
+// data and all offsets / leading dimensions count ELEMENTS of the storage type.
+typedef const unsigned short __attribute__((address_space(1)))* gptr_u16;
+typedef const unsigned __attribute__((address_space(1)))* gptr_u32;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef const u32x2_t __attribute__((address_space(1)))* gptr_u32x2;
+__device__ __forceinline__ float bf16_bits_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_bits_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+template <int XB> __device__ __forceinline__ float ldx1(const float* base, size_t off) {
+    if (XB) return bf16_bits_lo((unsigned)*(gptr_u16)(uintptr_t)(reinterpret_cast<const unsigned short*>(base) + off));
+    return ldg1(base + off);
+}
+template <int XB> __device__ __forceinline__ float2 ldx2(const float* base, size_t off) {      // 2 consecutive elements (even offset)
+    if (XB) {
+        const unsigned v = *(gptr_u32)(uintptr_t)(reinterpret_cast<const unsigned short*>(base) + off);
+        return make_float2(bf16_bits_lo(v), bf16_bits_hi(v));
+    }
+    return make_float2(ldg1(base + off), ldg1(base + off + 1));
+}
+template <int XB> __device__ __forceinline__ float4 ldx4(const float* base, size_t off) {      // 4 consecutive elements (offset % 4 == 0)
+    if (XB) {
+        const u32x2_t v = *(gptr_u32x2)(uintptr_t)(reinterpret_cast<const unsigned short*>(base) + off);
+        return make_float4(bf16_bits_lo(v.x), bf16_bits_hi(v.x), bf16_bits_lo(v.y), bf16_bits_hi(v.y));
+    }
+    return ldg4(base + off);
 }
 #endif
 

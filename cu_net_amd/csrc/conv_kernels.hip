@@ -43,7 +43,7 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 }
 
 // Fill sc/sh (and mu/is) for every channel of the concat, and the group table.
-template <bool NEED_MEAN>
+template <bool NEED_MEAN, int XB>
 __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, float* sc, float* sh,
                                              float* mu, float* is) {
     const int tid = threadIdx.x;
@@ -72,7 +72,8 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
         }
         for (int g = tid; g < (sg.C >> 2); g += blockDim.x) {
             GrpEnt e;
-            e.ptr = sg.x + 4 * g;
+            e.ptr = XB ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sg.x) + 4 * g)     // bf16 storage
+                       : sg.x + 4 * g;
             e.ld = sg.ld;
             e.ups = sg.ups;
             grp[(sg.choff >> 2) + g] = e;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
 
 constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
 
-template <int LD, int EP, int NT, bool FAST>
+template <int LD, int EP, int NT, bool FAST, int XB = 0>      // XB = 1 (EP_BWD only): x of the concat is bf16
 __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         }
     }
     constexpr bool HAS_CONCAT = (LD == LD_SEG || LD == LD_3X3 || EP == EP_BWD);
-    if (HAS_CONCAT && !(p.dbg & 64)) setup_concat<EP == EP_BWD>(p, grp, sc, sh, mu, is);
+    if (HAS_CONCAT && !(p.dbg & 64)) setup_concat<EP == EP_BWD, XB>(p, grp, sc, sh, mu, is);
     for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
     __syncthreads();
 
@@ -370,12 +371,12 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             GrpEnt g;
             g.ptr = p.a; g.ld = 0; g.ups = 0;                 // always a valid address: loads stay branch-free
             if (colok) g = grp[col >> 2];
-            const float* xcol = g.ptr + (colok ? (col & 3) : 0);
+            const size_t xoff0 = colok ? (col & 3) : 0;
             const bool up = g.ups != 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = up ? rowUp[r] : rowP[r];
-                xo[r] = ldg1(xcol + (size_t)row * g.ld);
+                xo[r] = ldx1<XB>(g.ptr, xoff0 + (size_t)row * g.ld);
             }
         };
 #pragma unroll
@@ -428,16 +429,14 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             a[nt] = dsum[nt] + shfl_xor_d(dsum[nt], 32);
             b[nt] = dsq[nt] + shfl_xor_d(dsq[nt], 32);
         }
-        for (int w = 0; w < nwaves; ++w) {
-            if (wave == w && hi == 0) {
+        if (hi == 0) {                                  // LDS fp64 atomics: one barrier instead of one per wave
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    redbuf[(nt * 32 + li) * 2 + 0] += a[nt];
-                    redbuf[(nt * 32 + li) * 2 + 1] += b[nt];
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], a[nt]);
+                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], b[nt]);
             }
-            __syncthreads();
         }
+        __syncthreads();
         if (tid < NB) {
             const int col = n0 + tid;
             if (col < p.Nout) {
@@ -601,21 +600,26 @@ static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
 
 constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 
-template <int LD, int EP, int NT, bool FAST>
+template <int LD, int EP, int NT, bool FAST, int XB = 0>
 static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {       // dynamic LDS above 64 KB has to be opted into, once per instantiation
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<LD, EP, NT, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<LD, EP, NT, FAST, XB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BUDGET);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<LD, EP, NT, FAST>), grid, dim3(threads), smem, s, a);
+    hipLaunchKernelGGL((conv_kernel<LD, EP, NT, FAST, XB>), grid, dim3(threads), smem, s, a);
     return hipGetLastError();
 }
 
 template <int LD, int EP>
 static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    if (EP == EP_BWD && a.xbf16) {            // bf16 activations: the one-tile fast variant only (channel counts are multiples of 32)
+        if (NT != 1) return hipErrorInvalidValue;
+        if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), (EP == EP_BWD ? 1 : 0)>(a, grid, threads, smem, s);
+        return launch_inst<LD, EP, 1, false, (EP == EP_BWD ? 1 : 0)>(a, grid, threads, smem, s);      // heads: K = class_num
+    }
     if (fast && LD != LD_STEM) {
         switch (NT) {
             case 1: return launch_inst<LD, EP, 1, (LD != LD_STEM)>(a, grid, threads, smem, s);
@@ -661,7 +665,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
         float best = 1e30f;
         static const int nt_max = getenv("CUNET_CONV_NT_MAX") ? atoi(getenv("CUNET_CONV_NT_MAX")) : 4;
         static const int nt_max_bwd = getenv("CUNET_CONV_NT_MAX_BWD") ? atoi(getenv("CUNET_CONV_NT_MAX_BWD")) : 1;
-        for (int c = (epi == EP_BWD ? nt_max_bwd : nt_max); c >= 1; --c) {
+        for (int c = (a.xbf16 ? 1 : (epi == EP_BWD ? nt_max_bwd : nt_max)); c >= 1; --c) {
             if (conv_smem_bytes(c, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET) continue;
             const int slices = (ncol32 + c - 1) / c;
             if (c > 1 && (long)ntiles * slices < target) continue;

@@ -22,7 +22,7 @@ __device__ __forceinline__ void atomic_add_f64e(double* p, double v) {
 // share x: A*sum(dz) + 4E - 4D*x, which IS the backward of the index map (y>>1, x>>1).
 // NSRC consumers, all plain (UPS = 0) or all through the upsample map (UPS = 1): compile-time source
 // indices keep every load of an element in flight together (a runtime loop would chain them).
-template <int NSRC, int UPS>
+template <int NSRC, int UPS, int XB>
 __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cE = reinterpret_cast<float*>(smem);       // [C]   sum of E (x4 for upsampled consumers)
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
                 d[e][3] = ldg4(b + (size_t)(2 * p.W + 1) * p.src[e].lddz);
             }
         }
-        const float4 x = ldg4(p.x + (size_t)row * p.ld + c);
+        const float4 x = ldx4<XB>(p.x, (size_t)row * p.ld + c);
         float4* dst = reinterpret_cast<float4*>(p.gx + (size_t)row * p.ld + c);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.accumulate) o = *dst;
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
     }
 }
 
-template <int UPS>
+template <int UPS, int XB>
 static hipError_t launch_gather_n(const GradGatherArgs& a, dim3 grid, size_t smem, hipStream_t s) {
     switch (a.nsrc) {
-#define CUNET_G(N) case N: hipLaunchKernelGGL((grad_gather_kernel<N, UPS>), grid, dim3(256), smem, s, a); break;
+#define CUNET_G(N) case N: hipLaunchKernelGGL((grad_gather_kernel<N, UPS, XB>), grid, dim3(256), smem, s, a); break;
         CUNET_G(1) CUNET_G(2) CUNET_G(3) CUNET_G(4) CUNET_G(5) CUNET_G(6) CUNET_G(7) CUNET_G(8)
 #undef CUNET_G
         default: return hipErrorInvalidValue;
@@ -119,7 +119,8 @@ hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t 
     if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
     const size_t smem = (size_t)a.C * 4 * (2 + a.nsrc);
-    return a.src[0].ups ? launch_gather_n<1>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0>(a, dim3((unsigned)gx), smem, s);
+    if (a.xbf16) return a.src[0].ups ? launch_gather_n<1, 1>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 1>(a, dim3((unsigned)gx), smem, s);
+    return a.src[0].ups ? launch_gather_n<1, 0>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 0>(a, dim3((unsigned)gx), smem, s);
 }
 
 // dgamma / dbeta of a batch of BatchNorms from their backward reductions (one block per BatchNorm)
@@ -252,6 +253,7 @@ hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t
 
 // max-pool backward: the gradient goes to the FIRST maximum in window order (0,0),(0,1),(1,0),(1,1)
 // (torch CPU max_pool2d tie-break), every other input position gets 0.
+template <int XB>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolArgs p) {
     const int g4 = p.C >> 2;
     const int Ho = p.H >> 1, Wo = p.W >> 1;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolArgs p) {
         float v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(p.x + off[k] * p.C + 4 * g);
+            const float4 t = ldx4<XB>(p.x, off[k] * p.C + 4 * g);
             v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
         }
         const float4 gq = *reinterpret_cast<const float4*>(p.gy + (size_t)row * p.C + 4 * g);
@@ -294,7 +296,8 @@ hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s) {
     long gx = (total + 255) / 256;
     if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, s, a);
+    if (a.xbf16) hipLaunchKernelGGL(pool_bwd_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pool_bwd_kernel<0>, dim3((unsigned)gx), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

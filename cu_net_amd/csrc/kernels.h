@@ -22,9 +22,9 @@ hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* s
 hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, float* ws, hipStream_t s);
 hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
                           float gscale, hipStream_t s);
-hipError_t launch_cvt_bf16(const float* src, void* dst, long n, hipStream_t s);
+hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long rows, int C, int num_cus, hipStream_t s);
 hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, hipStream_t s);
-hipError_t launch_pool_bf16(const void* x, void* y, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H, int W, int C, int num_cus, hipStream_t s);
 hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStream_t s);
 hipError_t launch_render_targets(const double* pts, const float* patch, int half, float* out, int NK, int H, int W, hipStream_t s);
 hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, float* out, int N, int K, int H, int W, hipStream_t s);

@@ -427,6 +427,8 @@ void Plan::layout_workspace() {
     ws_bytes_train = off_floats + n_floats_train * 4;
     off_bf16 = round_up64(ws_bytes_infer, 256);
     ws_bytes_bf16 = off_bf16 + n_floats_infer * 2;
+    off_bf16_train = round_up64(ws_bytes_train, 256);
+    ws_bytes_bf16_train = off_bf16_train + n_floats_infer * 2;
 }
 
 void Plan::describe() {

@@ -97,6 +97,7 @@ struct Plan {
     int64_t dz_off = -1, target_off = -1;     // float offsets (training)
     int64_t ws_bytes_infer = 0, ws_bytes_train = 0;
     int64_t off_bf16 = 0, ws_bytes_bf16 = 0;     // bf16 inference: a bf16 arena of n_floats_infer elements behind the fp32 inference layout
+    int64_t off_bf16_train = 0, ws_bytes_bf16_train = 0;   // the same arena behind the training layout (bf16 activations, fp32 gradients)
     int n_runstat = 0;
 
     std::string json;

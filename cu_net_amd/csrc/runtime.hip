@@ -144,6 +144,7 @@ int64_t cunet_counter_numel(const cunet_plan_t* p) { return p ? p->plan.n_counte
 int64_t cunet_workspace_bytes(const cunet_plan_t* p, int training) {
     if (!p) return 0;
     if (training == 2) return p->plan.ws_bytes_bf16;      // inference incl. the bf16 arena of cunet_forward_bf16
+    if (training == 3) return p->plan.ws_bytes_bf16_train; // training incl. the bf16 activation arena
     return training ? p->plan.ws_bytes_train : p->plan.ws_bytes_infer;
 }
 int cunet_num_heads(const cunet_plan_t* p) { return p ? (int)p->plan.head_tensors.size() : 0; }
@@ -252,10 +253,14 @@ struct Exec {
     Plan& P;
     float* wsf;        // float region
     double* zero;      // fp64 region
+    unsigned short* a16 = nullptr;   // bf16 activation arena when the last training forward was cunet_forward_bf16
     explicit Exec(cunet_plan* hh) : h(hh), P(hh->plan) {
         wsf = reinterpret_cast<float*>(h->ws + P.off_floats);
         zero = reinterpret_cast<double*>(h->ws + P.off_zero);
+        if (h->fwd_training_done == 2) a16 = reinterpret_cast<unsigned short*>(h->ws + P.off_bf16_train);
     }
+    // activations as the backward kernels read them: fp32, or bf16 behind a float-typed pointer (xbf16 = 1 in the args)
+    const float* xact(int t) const { return a16 ? reinterpret_cast<const float*>(a16 + P.tensors[t].act) : act(t); }
     float* act(int t) const { return wsf + P.tensors[t].act; }
     float* grad(int t) const { return wsf + P.tensors[t].grad; }
     double* stats(int t) const { return P.tensors[t].stats >= 0 ? zero + P.tensors[t].stats : nullptr; }
@@ -265,7 +270,7 @@ struct Exec {
         for (size_t i = 0; i < n.segs.size(); ++i) {
             const TensorInfo& t = P.tensors[n.segs[i].tensor];
             Seg& s = segs[i];
-            s.x = act(n.segs[i].tensor);
+            s.x = xact(n.segs[i].tensor);
             s.gx = h->bound_training ? grad(n.segs[i].tensor) : nullptr;
             s.stats = stats(n.segs[i].tensor);
             s.count = (double)t.rows();
@@ -291,7 +296,7 @@ static int gather_tensor_grad(cunet_plan* h, int t, int only_node, hipStream_t s
         auto flush = [&]() -> int {
             if (a.nsrc == 0) return CUNET_OK;
             a.accumulate = accumulate;
-            a.x = E.act(t); a.gx = E.grad(t); a.stats = E.stats(t); a.count = (double)ti.rows();
+            a.x = E.xact(t); a.xbf16 = E.a16 ? 1 : 0; a.gx = E.grad(t); a.stats = E.stats(t); a.count = (double)ti.rows();
             a.C = ti.C; a.ld = ti.ld; a.rows = (int)ti.rows(); a.H = ti.H; a.W = ti.W;
             PROF(PC_APPLY, 0.0, 4.0 * (double)ti.rows() * ti.C * (2.0 + accumulate + a.nsrc * (ups ? 4.0 : 1.0)),
                  launch_grad_gather(a, h->num_cus, s));
@@ -358,6 +363,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
             a.training = 1;
+            a.xbf16 = E.a16 ? 1 : 0;
             a.a = E.grad(n.out); a.lda = o.ld;
             a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
             a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
@@ -372,6 +378,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
             w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
             w.dw = h->grads + c.w;
+            w.xbf16 = E.a16 ? 1 : 0;
             PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
                     launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));
         }
@@ -379,7 +386,8 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         const int tin = n.segs[0].tensor;
         const TensorInfo& ti = P.tensors[tin];
         PoolArgs a{};
-        a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+        a.x = E.xact(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+        a.xbf16 = E.a16 ? 1 : 0;
         a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
         PROF(PC_POOLB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_pool_bwd(a, cus, s));
     } else if (n.type == N_STEM_BNPOOL) {
@@ -413,6 +421,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     if (!h || !x) return fail(CUNET_ERR_INVALID, "null argument");
     if (!h->ws) return fail(CUNET_ERR_STATE, "cunet_bind has not been called");
     hipStream_t s = (hipStream_t)stream;
+    h->fwd_training_done = 0;        // (an earlier bf16 forward must not redirect this pass's activation pointers)
     Exec E(h);
     Plan& P = h->plan;
     const int cus = h->num_cus;
@@ -500,16 +509,19 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     return CUNET_OK;
 }
 
-int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, void* stream) {
-    if (!h || !x || !heat) return fail(CUNET_ERR_INVALID, "null argument");
+int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int training, void* stream) {
+    if (!h || !x) return fail(CUNET_ERR_INVALID, "null argument");
     if (!h->ws) return fail(CUNET_ERR_STATE, "cunet_bind has not been called");
     Plan& P = h->plan;
-    if (h->ws_bytes < P.ws_bytes_bf16) return fail(CUNET_ERR_STATE, "workspace smaller than cunet_workspace_bytes(plan, 2)");
+    if (training && !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
+    const int64_t off16 = h->bound_training ? P.off_bf16_train : P.off_bf16;
+    if (h->ws_bytes < off16 + P.n_floats_infer * 2) return fail(CUNET_ERR_STATE, "workspace has no bf16 arena: size it with cunet_workspace_bytes(plan, 2 or 3)");
     hipStream_t s = (hipStream_t)stream;
     Exec E(h);
     const int cus = h->num_cus;
-    unsigned short* a16 = reinterpret_cast<unsigned short*>(h->ws + P.off_bf16);      // bf16 arena, element offsets as the fp32 layout
-    HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));   // (stem operand)
+    unsigned short* a16 = reinterpret_cast<unsigned short*>(h->ws + off16);      // bf16 arena, element offsets as the fp32 layout
+    HIPCHK(hipMemsetAsync(h->ws + P.off_zero, 0, (size_t)P.zero_bytes, s));
+    HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
     HIPCHK(launch_repack_bf16(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, a16, s));
     for (size_t ni = 0; ni < P.nodes.size(); ++ni) {
         const Node& n = P.nodes[ni];
@@ -517,9 +529,9 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, void
         if (n.type == N_STEM_CONV) {               // fp32 kernels on the fp32 image
             const ConvInfo& c = P.convs[n.conv];
             ConvArgs a{};
-            a.nseg = 0; a.Ccat = 0; a.training = 0;
+            a.nseg = 0; a.Ccat = 0; a.training = training;
             a.K = c.Cin; a.taps = 1; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
-            a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = nullptr;
+            a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             a.img = x; a.IH = P.cfg.height; a.IW = P.cfg.width;
             HIPCHK(launch_conv(a, LD_STEM, EP_FWD, cus, s));
@@ -528,19 +540,21 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, void
             const TensorInfo& ti = P.tensors[tin];
             const BnInfo& b = P.bns[n.bn];
             PoolArgs a{};
-            a.x = E.act(tin); a.y = E.act(n.out); a.ystats = nullptr;
-            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 0;
-            a.xstats = nullptr; a.count = (double)ti.rows();
+            a.x = E.act(tin); a.y = E.act(n.out); a.ystats = nullptr;       // statistics come from the bf16 copy below
+            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = training;
+            a.xstats = E.stats(tin); a.count = (double)ti.rows();
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
             HIPCHK(launch_pool_fwd(a, 1, cus, s));
             if (o.ld != o.C || (o.rows() * o.C) % 8) return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 8");
-            HIPCHK(launch_cvt_bf16(E.act(n.out), a16 + o.act, (long)o.rows() * o.ld, s));
+            HIPCHK(launch_cvt_bf16(E.act(n.out), a16 + o.act, training ? E.stats(n.out) : nullptr, (long)o.rows(), o.C, cus, s));
         } else if (n.type == N_POOL) {
             const int tin = n.segs[0].tensor;
             const TensorInfo& ti = P.tensors[tin];
             if (ti.C % 8 || ti.ld != ti.C) return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 8");
-            HIPCHK(launch_pool_bf16(a16 + ti.act, a16 + o.act, ti.N, ti.H, ti.W, ti.C, s));
+            hipError_t e = launch_pool_bf16(a16 + ti.act, a16 + o.act, training ? E.stats(n.out) : nullptr, ti.N, ti.H, ti.W, ti.C, cus, s);
+            if (e == hipErrorInvalidValue) return fail(CUNET_ERR_INVALID, "bf16 path: unsupported channel count in a pooled tensor");
+            HIPCHK(e);
         } else {  // N_CONV
             const ConvInfo& c = P.convs[n.conv];
             const BnInfo& b = P.bns[n.bn];
@@ -550,11 +564,11 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, void
                 a.seg[i].x = reinterpret_cast<const float*>(a16 + P.tensors[n.segs[i].tensor].act);
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-            a.training = 0;
+            a.training = training;
             a.K = n.Ccat; a.taps = c.taps; a.wB = reinterpret_cast<const float*>(a16 + c.wF); a.Kpad = c.KpadF; a.Npad = c.NpadF;
             const int is_head = n.head >= 0;
             a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
-            a.ldy = o.ld; a.Nout = c.Cout; a.ystats = nullptr;
+            a.ldy = o.ld; a.Nout = c.Cout; a.ystats = (training && !is_head) ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             hipError_t e = launch_conv_bf16(a, is_head, cus, s);
             if (e == hipErrorInvalidValue)
@@ -562,13 +576,19 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, void
             HIPCHK(e);
         }
     }
-    for (size_t i = 0; i < P.head_tensors.size(); ++i) {
-        if (!heat[i]) continue;
-        const TensorInfo& t = P.tensors[P.head_tensors[i]];
-        HIPCHK(launch_transpose(E.act(P.head_tensors[i]), heat[i], t.N, t.C, t.H * t.W, t.ld, 0, s));
+    if (training)
+        HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
+                                     E.zero, h->buffers, h->counters, 0, s));
+    if (heat) {
+        for (size_t i = 0; i < P.head_tensors.size(); ++i) {
+            if (!heat[i]) continue;
+            const TensorInfo& t = P.tensors[P.head_tensors[i]];
+            HIPCHK(launch_transpose(E.act(P.head_tensors[i]), heat[i], t.N, t.C, t.H * t.W, t.ld, 0, s));
+        }
     }
-    h->fwd_training_done = 0;
+    h->fwd_training_done = training ? 2 : 0;        // 2: activations are in the bf16 arena
     h->loss_done = 0;
+    h->last_x = x;
     return CUNET_OK;
 }
 

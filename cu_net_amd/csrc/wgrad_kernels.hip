@@ -20,7 +20,7 @@ constexpr int WG_UNROLL = 4;     // row pairs in flight per wave
 
 enum WgLoad { WG_SEG = 0, WG_3X3 = 1, WG_STEM = 2 };
 
-template <int LD, int NACC>
+template <int LD, int NACC, int XB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);     // [4 waves][1024]
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int HW = p.H * p.W;
 
     // ---- per-lane column state of the B operand (channel c0 + a*32 + li)
-    const float* xptr[NACC];
+    const float* xptr[NACC];                          // segment base (fp32 or bf16 storage, see ldx1) ...
+    int xlc[NACC];                                    // ... and this lane's element offset in a row
     int xld[NACC], xups[NACC];
     float xsc[NACC], xsh[NACC];
     int skoff[NACC];                                  // stem: k -> (ci,ky,kx) packed
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     for (int a = 0; a < NACC; ++a) {
         const int c = (LD == WG_3X3) ? (c0 + li) : (c0 + a * 32 + li);
         cok[a] = c < p.Ccat;
-        xptr[a] = nullptr; xld[a] = 0; xups[a] = 0; xsc[a] = 0.f; xsh[a] = 0.f; skoff[a] = 0;
+        xptr[a] = nullptr; xlc[a] = 0; xld[a] = 0; xups[a] = 0; xsc[a] = 0.f; xsh[a] = 0.f; skoff[a] = 0;
         if (LD == WG_STEM) {
             if (cok[a]) {
                 const int ci = c / 49, r = c - ci * 49, ky = r / 7, kx = r - ky * 7;
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const double scale = (double)p.gamma[c] * istd;
             xsc[a] = (float)scale;
             xsh[a] = (float)((double)p.beta[c] - mean * scale);
-            xptr[a] = sg.x + lc;
+            xptr[a] = sg.x;
+            xlc[a] = lc;
             xld[a] = sg.ld;
             xups[a] = sg.ups;
         }
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     // each wave takes row pairs  row_begin + 2*(wave + 4*j).  Loads are branch-free (clamped addresses; validity
     // and BN+ReLU are applied when the value is consumed): a branch around a load serialises it behind its wait.
     const float* xbase0 = (LD != WG_STEM && cok[0]) ? xptr[0] : p.dy;
+    const int xlc0 = (LD != WG_STEM && cok[0]) ? xlc[0] : 0;
     const int xld0 = (LD != WG_STEM && cok[0]) ? xld[0] : 0;
     for (int base = row_begin + 2 * wave * WG_UNROLL; base < row_end; base += 2 * 4 * WG_UNROLL) {
         float av[WG_UNROLL];
@@ -111,15 +114,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int a = 0; a < NACC; ++a) {
                 if (LD == WG_SEG) {
-                    const float* src = (cok[a] ? xptr[a] : p.dy) + (size_t)(xups[a] ? rowU : mc) * (cok[a] ? xld[a] : 0);
-                    bv[u][a] = ldg1(src);
+                    bv[u][a] = ldx1<XB>(cok[a] ? xptr[a] : p.dy, (size_t)(xups[a] ? rowU : mc) * (cok[a] ? xld[a] : 0) + (cok[a] ? xlc[a] : 0));
                     vm |= (unsigned)(cok[a] && mok) << a;
                 } else if (LD == WG_3X3) {
                     const int dy = a / 3 - 1, dx = a - (a / 3) * 3 - 1;
                     const int yy = py + dy, xx = px + dx;
                     const bool ok = cok[0] && mok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
                     const int row = ok ? mc + dy * p.W + dx : mc;
-                    bv[u][a] = ldg1(xbase0 + (size_t)row * xld0);
+                    bv[u][a] = ldx1<XB>(xbase0, (size_t)row * xld0 + xlc0);
                     vm |= (unsigned)ok << a;
                 } else {  // WG_STEM
                     const int ci = skoff[a] >> 16, ky = (skoff[a] >> 8) & 255, kx = skoff[a] & 255;
@@ -207,7 +209,7 @@ struct Wg2Args {
     int rows_per_chunk[12];
 };
 
-template <int NTW, int CT, bool UPS, bool STEM = false>
+template <int NTW, int CT, bool UPS, bool STEM = false, int XB = 0>      // XB = 1: the segments' x are stored as bf16
 __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int chunk, int rpc, float* lds) {
     const WgradArgs& p = q.w;
     const int tid = threadIdx.x;
@@ -243,7 +245,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             if (cb >= p.seg[t].choff) s = t;
         const Seg sg = p.seg[s];
         const int lc = cb - sg.choff;
-        xptr = sg.x + lc;
+        xptr = XB ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sg.x) + lc) : sg.x + lc;
         xld = sg.ld;
         xups = sg.ups;
 #pragma unroll
@@ -314,11 +316,12 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
                 xrow = xups ? rowU : mc;
             }
-            const float* src = xbase + (size_t)xrow * xldc;
-            if (CT == 4) { const float4 v = ldg4(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+            const size_t xo = (size_t)xrow * xldc;
+            if (CT == 4) { const float4 v = ldx4<XB>(xbase, xo); x[0] = v.x; x[1] = v.y; x[2 % CT] = v.z; x[3 % CT] = v.w; }
+            else if (CT == 2) { const float2 v = ldx2<XB>(xbase, xo); x[0] = v.x; x[1 % CT] = v.y; }
             else {
 #pragma unroll
-                for (int t = 0; t < CT; ++t) x[t] = ldg1(src + t);
+                for (int t = 0; t < CT; ++t) x[t] = ldx1<XB>(xbase, xo + t);
             }
         }
         ok = mok;
@@ -349,10 +352,16 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
                 xrow = xups ? rowU : mc;
             }
-            const float* xsrc = xbase + (size_t)xrow * xldc;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a4) : "v"(asrc) : "memory");
-            if constexpr (CT == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(x2) : "v"(xsrc) : "memory");
-            else asm volatile("global_load_dword %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
+            if constexpr (XB) {        // bf16 x: CT = 2 -> one dword (two bf16), CT = 1 -> one ushort; unpacked at consumption (x1 carries the bits)
+                const unsigned short* xsrc = reinterpret_cast<const unsigned short*>(xbase) + (size_t)xrow * xldc;
+                if constexpr (CT == 2) asm volatile("global_load_dword %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
+                else asm volatile("global_load_ushort %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
+            } else {
+                const float* xsrc = xbase + (size_t)xrow * xldc;
+                if constexpr (CT == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(x2) : "v"(xsrc) : "memory");
+                else asm volatile("global_load_dword %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
+            }
             ok = mok;
         };
         int mm = row_begin + 2 * wave;
@@ -361,7 +370,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         for (; mm < row_end; mm += PD * 8) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                if constexpr (CT == 2)
+                if constexpr (CT == 2 && !XB)
                     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A4[u]), "+v"(X2[u]) : "n"(2 * (PD - 1)) : "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A4[u]), "+v"(X1[u]) : "n"(2 * (PD - 1)) : "memory");
@@ -369,7 +378,11 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 const bool okk = OK[u];
                 a[0] = (okk && nok) ? A4[u].x : 0.f; a[1] = (okk && nok) ? A4[u].y : 0.f;
                 a[2] = (okk && nok) ? A4[u].z : 0.f; a[3] = (okk && nok) ? A4[u].w : 0.f;
-                if constexpr (CT == 2) {
+                if constexpr (XB) {
+                    const unsigned bits = __float_as_uint(X1[u]);
+                    x[0] = (okk && cok) ? fmaxf(fmaf(bf16_bits_lo(bits), xsc[0], xsh[0]), 0.f) : 0.f;
+                    if constexpr (CT == 2) x[1 % CT] = (okk && cok) ? fmaxf(fmaf(bf16_bits_hi(bits), xsc[1 % CT], xsh[1 % CT]), 0.f) : 0.f;
+                } else if constexpr (CT == 2) {
                     x[0] = (okk && cok) ? fmaxf(fmaf(X2[u].x, xsc[0], xsh[0]), 0.f) : 0.f;
                     x[1] = (okk && cok) ? fmaxf(fmaf(X2[u].y, xsc[1], xsh[1]), 0.f) : 0.f;
                 } else {
@@ -386,7 +399,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         // drain: the tail refills are still in flight and own their registers until they land
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-            if constexpr (CT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X2[u]) : : "memory");
+            if constexpr (CT == 2 && !XB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X2[u]) : : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X1[u]) : : "memory");
         }
     } else {
@@ -449,7 +462,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
     }
 }
 
-template <int NTW>
+template <int NTW, int XB>
 __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
@@ -461,13 +474,13 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wg2Args q) {
     const int chunk = blockIdx.x - g.chunk0;
     const int rpc = q.rows_per_chunk[gi];
     if (q.any_ups) {
-        if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), true>(q, g, chunk, rpc, lds);
-        else if (g.ct == 2) wg2_body<NTW, 2, true>(q, g, chunk, rpc, lds);
-        else wg2_body<NTW, 1, true>(q, g, chunk, rpc, lds);
+        if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), true, false, XB>(q, g, chunk, rpc, lds);
+        else if (g.ct == 2) wg2_body<NTW, 2, true, false, XB>(q, g, chunk, rpc, lds);
+        else wg2_body<NTW, 1, true, false, XB>(q, g, chunk, rpc, lds);
     } else {
-        if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), false>(q, g, chunk, rpc, lds);
-        else if (g.ct == 2) wg2_body<NTW, 2, false>(q, g, chunk, rpc, lds);
-        else wg2_body<NTW, 1, false>(q, g, chunk, rpc, lds);
+        if (g.ct == 4 && NTW < 4) wg2_body<NTW, (NTW < 4 ? 4 : 2), false, false, XB>(q, g, chunk, rpc, lds);
+        else if (g.ct == 2) wg2_body<NTW, 2, false, false, XB>(q, g, chunk, rpc, lds);
+        else wg2_body<NTW, 1, false, false, XB>(q, g, chunk, rpc, lds);
     }
 }
 
@@ -535,24 +548,29 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     auto set_attr = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); };
     static bool done = false;
     if (!done) {
-        hipError_t e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4>));
-        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2>));
+        hipError_t e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4, 0>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4, 1>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2, 0>));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_stem_kernel));
-        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1, 0>));
         if (e != hipSuccess) return e;
         done = true;
     }
     if (q.stem) hipLaunchKernelGGL(wgrad2_stem_kernel, grid, dim3(256), smem, s, q);
-    else if (ntw == 4) hipLaunchKernelGGL(wgrad2_kernel<4>, grid, dim3(256), smem, s, q);
-    else if (ntw == 2) hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(256), smem, s, q);
-    else hipLaunchKernelGGL(wgrad2_kernel<1>, grid, dim3(256), smem, s, q);
+    else if (a.xbf16) {
+        if (ntw != 4) return hipErrorInvalidValue;       // bf16 activations: heads and bottlenecks have > 64 output channels
+        hipLaunchKernelGGL((wgrad2_kernel<4, 1>), grid, dim3(256), smem, s, q);
+    } else if (ntw == 4) hipLaunchKernelGGL((wgrad2_kernel<4, 0>), grid, dim3(256), smem, s, q);
+    else if (ntw == 2) hipLaunchKernelGGL((wgrad2_kernel<2, 0>), grid, dim3(256), smem, s, q);
+    else hipLaunchKernelGGL((wgrad2_kernel<1, 0>), grid, dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
 template <int LD>
 static hipError_t launch_acc(const WgradArgs& a, int nacc, dim3 grid, hipStream_t s) {
     const size_t smem = (size_t)4 * 1024 * 4 + (LD == WG_3X3 ? (size_t)9 * 1024 * 4 : 0);
-#define CUNET_WG(N) case N: hipLaunchKernelGGL((wgrad_kernel<LD, N>), grid, dim3(256), smem, s, a); break;
+#define CUNET_WG(N) case N: if (a.xbf16) hipLaunchKernelGGL((wgrad_kernel<LD, N, 1>), grid, dim3(256), smem, s, a); \
+                    else hipLaunchKernelGGL((wgrad_kernel<LD, N, 0>), grid, dim3(256), smem, s, a); break;
     switch (nacc) {
         CUNET_WG(1) CUNET_WG(2) CUNET_WG(3) CUNET_WG(4) CUNET_WG(5) CUNET_WG(9)
         default: return hipErrorInvalidValue;

@@ -44,7 +44,8 @@ class _BoundPlan:
         self.shape = (n, h, w)
         self.training_ws = training_ws
         dev = net._param_arena.device
-        nbytes = self.handle.workspace_bytes(2 if bf16 else training_ws)      # 2: inference + bf16 arena
+        nbytes = self.handle.workspace_bytes((3 if training_ws else 2) if bf16 else training_ws)      # 2 / 3: + bf16 arena
+        self.bf16 = bf16
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.hw_out = (h // 4, w // 4)
@@ -71,12 +72,17 @@ class _BoundPlan:
         self._last_x = x          # the stem's weight gradient re-reads the image during backward
         return outs
 
-    def forward_bf16(self, x: torch.Tensor) -> List[torch.Tensor]:
+    def forward_bf16(self, x: torch.Tensor, training: bool = False, want_outputs: bool = True) -> List[torch.Tensor]:
         n, h, w = self.shape
         k = self.handle.cfg.class_num
-        outs = [torch.empty((n, k, self.hw_out[0], self.hw_out[1]), dtype=torch.float32, device=x.device) for _ in range(self.num_heads)]
-        arr = (C.c_void_p * self.num_heads)(*[o.data_ptr() for o in outs])
-        check(lib().cunet_forward_bf16(self.handle.h, _ptr(x), arr, _stream_ptr(x.device)), 'cunet_forward_bf16')
+        outs = []
+        arr = None
+        if want_outputs:
+            outs = [torch.empty((n, k, self.hw_out[0], self.hw_out[1]), dtype=torch.float32, device=x.device) for _ in range(self.num_heads)]
+            arr = (C.c_void_p * self.num_heads)(*[o.data_ptr() for o in outs])
+        check(lib().cunet_forward_bf16(self.handle.h, _ptr(x), arr, 1 if training else 0, _stream_ptr(x.device)), 'cunet_forward_bf16')
+        self.generation += 1
+        self._last_x = x
         return outs
 
     def loss_mse(self, target: torch.Tensor) -> torch.Tensor:
@@ -120,10 +126,20 @@ class _BoundPlan:
         """NCHW copy of an internal NHWC tensor (tests only)."""
         d = self.handle.describe()
         t = [t for t in d['tensors'] if t['name'] == name][0]
-        off = self.handle.tensor_offset(name, 1 if grad else 0)
         rows = t['N'] * t['H'] * t['W']
-        flat = self.workspace[off: off + rows * t['ld'] * 4].view(torch.float32)
+        if self.bf16 and not grad and self._in_bf16_arena(d, t):
+            base = (self.handle.workspace_bytes(self.training_ws) + 255) // 256 * 256      # where the bf16 arena starts
+            flat = self.workspace[base + 2 * t['act']: base + 2 * (t['act'] + rows * t['ld'])].view(torch.bfloat16).float()
+        else:
+            off = self.handle.tensor_offset(name, 1 if grad else 0)
+            flat = self.workspace[off: off + rows * t['ld'] * 4].view(torch.float32)
         return flat.view(t['N'], t['H'], t['W'], t['ld'])[..., :t['C']].permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def _in_bf16_arena(d, t) -> bool:
+        """With bf16 activations everything but the stem conv output and the heads lives in the bf16 arena."""
+        fp32 = {d['nodes'][0]['out']} | {n['out'] for n in d['nodes'] if n.get('head', -1) >= 0}
+        return t['id'] not in fp32
 
 
 class _CUNetFunction(torch.autograd.Function):
@@ -300,14 +316,14 @@ class CUNet(nn.Module):
         return out
 
     # ---- plans -----------------------------------------------------------------------------------
-    def _get_plan(self, n, h, w, need_grad) -> _BoundPlan:
-        key = (n, h, w)
+    def _get_plan(self, n, h, w, need_grad, bf16: bool = False) -> _BoundPlan:
+        key = ('bf16', n, h, w) if bf16 else (n, h, w)
         plan = self._plans.get(key)
         if plan is None or (need_grad and not plan.training_ws):
             if plan is None and len(self._plans) >= 4:      # bound the workspaces kept alive
                 self._plans.pop(next(iter(self._plans)))
             self._plans.pop(key, None)
-            plan = _BoundPlan(self, n, h, w, need_grad)
+            plan = _BoundPlan(self, n, h, w, need_grad, bf16=bf16)
             self._plans[key] = plan
         return plan
 
@@ -323,12 +339,7 @@ class CUNet(nn.Module):
         self._check_aliasing()
         x = x.contiguous()
         n, _, h, w = x.shape
-        key = ('bf16', n, h, w)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = _BoundPlan(self, n, h, w, False, bf16=True)
-            self._plans[key] = plan
-        return plan.forward_bf16(x)
+        return self._get_plan(n, h, w, False, bf16=True).forward_bf16(x)
 
     def forward(self, x):
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:

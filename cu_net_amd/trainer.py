@@ -18,7 +18,7 @@ from .module import CUNet, _ptr, _stream_ptr
 
 class FusedTrainer:
     def __init__(self, net: CUNet, lr: float = 2.5e-4, alpha: float = 0.99, eps: float = 1e-8,
-                 process_group=None, overlap: bool = True, quan_op=None):
+                 process_group=None, overlap: bool = True, quan_op=None, bf16: bool = False):
         """RMSprop hyper-parameters default to cu-net.py:60-61. `process_group`: a torch.distributed
         group (backend nccl == RCCL) for data parallelism, or None."""
         if not isinstance(net, CUNet):
@@ -26,6 +26,7 @@ class FusedTrainer:
         self.net = net
         self.lr, self.alpha, self.eps = float(lr), float(alpha), float(eps)
         self.square_avg = None
+        self.bf16 = bool(bf16)        # bf16 activation storage + bf16 MFMA forward; gradients, weights and the optimiser stay fp32
         self.steps_done = 0           # optimiser steps taken (the `step` entry of torch's RMSprop state)
         self.quan_op = quan_op        # cu_net_amd.quant.QuanOp / BinOp: quantised training (cu-net-prev-version-wig.py:163-190)
         self.pg = process_group
@@ -54,10 +55,13 @@ class FusedTrainer:
         n, _, h, w = img.shape
         if tuple(heatmap.shape) != (n, net._hyper[3], h // 4, w // 4):
             raise CUNetError(f'heatmap must be {n} x {net._hyper[3]} x {h // 4} x {w // 4}')
-        plan = net._get_plan(n, h, w, True)
+        plan = net._get_plan(n, h, w, True, bf16=self.bf16)
         if self.quan_op is not None:
             self.quan_op.quantization()
-        plan.forward(img, True, want_outputs=False)
+        if self.bf16:
+            plan.forward_bf16(img, True, want_outputs=False)
+        else:
+            plan.forward(img, True, want_outputs=False)
         loss = plan.loss_mse(heatmap)
         if self.pg is None:
             plan.backward(None)
@@ -83,7 +87,7 @@ class FusedTrainer:
     def last_outputs(self, img_shape):
         """Heat maps of the last step (NCHW copies), e.g. for the per-step accuracy of cu-net.py:191."""
         n, _, h, w = img_shape
-        plan = self.net._get_plan(n, h, w, True)
+        plan = self.net._get_plan(n, h, w, True, bf16=self.bf16)
         d = plan.handle.describe()
         heads = sorted((nd['head'], d['tensors'][nd['out']]['name']) for nd in d['nodes'] if nd.get('head', -1) >= 0)
         return [plan.debug_tensor(name) for _, name in heads]

@@ -68,7 +68,7 @@ int cunet_state_entry(const cunet_plan_t* plan, int index, cunet_state_desc* out
 int64_t cunet_param_numel(const cunet_plan_t* plan);     /* floats: parameter arena == gradient arena */
 int64_t cunet_buffer_numel(const cunet_plan_t* plan);    /* floats: running_mean / running_var arena */
 int64_t cunet_counter_numel(const cunet_plan_t* plan);   /* int64: num_batches_tracked arena */
-int64_t cunet_workspace_bytes(const cunet_plan_t* plan, int training);  /* 0 inference, 1 training, 2 inference + bf16 arena */
+int64_t cunet_workspace_bytes(const cunet_plan_t* plan, int training);  /* 0 inference, 1 training, 2 / 3: the same plus the bf16 activation arena */
 int cunet_num_heads(const cunet_plan_t* plan);           /* == loss_num */
 /* anchors[i] = 1-based U-Net index whose head produces output i (models/cu_net.py:275-283) */
 int cunet_loss_anchors(const cunet_plan_t* plan, int32_t* anchors, int capacity);
@@ -107,7 +107,7 @@ int cunet_backward(cunet_plan_t* plan, const float* const* grad_heat, void* stre
  * but activations and weights are held as bf16 between the stem and the heads and contracted with bf16 MFMA
  * (fp32 accumulation, BatchNorm + ReLU in fp32 on running statistics).  Needs a plan bound with training = 0 on a
  * workspace of cunet_workspace_bytes(plan, 2) bytes, and channel counts that are multiples of 32. */
-int cunet_forward_bf16(cunet_plan_t* plan, const float* x, float* const* heat, void* stream);
+int cunet_forward_bf16(cunet_plan_t* plan, const float* x, float* const* heat, int training, void* stream);
 
 /* Gradient buckets for data parallelism.  The parameter/gradient arena is laid out bucket-major:
  * bucket i < layer_num holds every parameter used by U-Net index i, bucket layer_num the stem.

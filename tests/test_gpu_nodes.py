@@ -53,14 +53,29 @@ def test_every_node_backward_full_width():
     _check_all_nodes(cfg, st, x)
 
 
-def _check_all_nodes(cfg, st, x):
+def test_every_node_backward_full_width_bf16_activations():
+    """The same node-by-node check with bf16 activation storage (FusedTrainer(bf16=True)): the backward kernels read x
+    as bf16 and compute in fp32, so against torch autograd fed with the SAME bf16-rounded activations the fp32 tolerance
+    holds unchanged (gradients, dz and weights stay fp32)."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=23)
+    x, _ = O.synthetic_batch(2, 68, 256, seed=24)       # the bf16 kernels need 32-row tiles at every level: N * 16 rows at the neck
+    _check_all_nodes(cfg, st, x, bf16=True)
+
+
+def _check_all_nodes(cfg, st, x, bf16=False):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
     n, _, h, w = x.shape
-    plan = net._get_plan(n, h, w, True)
+    plan = net._get_plan(n, h, w, True, bf16=bf16)
     xd = x.cuda()
-    plan.forward(xd, True, want_outputs=False)
+    if bf16:
+        plan.forward_bf16(xd, True, want_outputs=False)
+    else:
+        plan.forward(xd, True, want_outputs=False)
     torch.cuda.synchronize()
     desc = plan.handle.describe()
     T = desc['tensors']

@@ -390,3 +390,26 @@ def test_bf16_inference_forward_close_to_fp32():
         assert False, 'forward_bf16 must refuse training mode'
     except cu_net_amd.CUNetError:
         pass
+
+
+def test_bf16_activation_train_step_tracks_fp32():
+    """FusedTrainer(bf16=True): bf16 activation storage + bf16 MFMA forward, fp32 gradients / weights / RMSprop.  The
+    per-kernel exactness is in test_gpu_nodes.py; here the whole step: first loss within 2e-2 of the fp32 step's, and
+    ten steps bring the loss down by the same amount to within 10 %."""
+    g = Golden('G5_full_L2K68')
+    spec = O.Spec(**g.cfg)
+    st = O.init_state(spec, seed=int(g.z['init_seed']))
+    x, target = O.synthetic_batch(4, spec.class_num, 256, seed=13)
+    xd, td = x.cuda(), target.cuda()
+    hist = {}
+    for bf16 in (False, True):
+        net = cu_net_amd.create_cu_net(**g.cfg)
+        net.load_state_dict(st)
+        net.cuda().train()
+        tr = FusedTrainer(net, lr=2.5e-4, bf16=bf16)
+        hist[bf16] = [float(tr.step(xd, td)) for _ in range(10)]
+        assert all(torch.isfinite(torch.tensor(hist[bf16])))
+    a, b = hist[False], hist[True]
+    assert abs(b[0] - a[0]) <= 2e-2 * a[0], (a[0], b[0])
+    assert b[-1] < b[0]
+    assert abs((b[0] - b[-1]) - (a[0] - a[-1])) <= 0.1 * (a[0] - a[-1]), (a, b)
