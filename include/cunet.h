@@ -102,11 +102,13 @@ int cunet_loss_mse(cunet_plan_t* plan, const float* target, float* loss, void* s
  *   Fills the bound gradient arena (overwrites; parameters that received no gradient stay 0). */
 int cunet_backward(cunet_plan_t* plan, const float* const* grad_heat, void* stream);
 
-/* bf16-storage inference (BASELINE config 3 direction; nothing like it in the reference, which is fp32):
- * same inputs / outputs as cunet_forward(training = 0) -- fp32 NCHW image in, loss_num fp32 NCHW heat maps out --
- * but activations and weights are held as bf16 between the stem and the heads and contracted with bf16 MFMA
- * (fp32 accumulation, BatchNorm + ReLU in fp32 on running statistics).  Needs a plan bound with training = 0 on a
- * workspace of cunet_workspace_bytes(plan, 2) bytes, and channel counts that are multiples of 32. */
+/* bf16 activation storage (BASELINE config 3 direction; nothing like it in the reference, which is fp32):
+ * same inputs / outputs as cunet_forward -- fp32 NCHW image in, loss_num fp32 NCHW heat maps out -- but activations
+ * and the forward weight operands are held as bf16 between the stem and the heads and contracted with bf16 MFMA (fp32
+ * accumulation, BatchNorm + ReLU in fp32).  training = 0: running statistics; needs a plan bound with training = 0 on
+ * cunet_workspace_bytes(plan, 2) bytes.  training = 1: batch statistics of the bf16-rounded tensors; needs a training
+ * bind on cunet_workspace_bytes(plan, 3) bytes, and cunet_loss_mse / cunet_backward after it read x as bf16 while
+ * gradients, weights and the optimiser stay fp32.  Channel counts must be multiples of 32, rows of 32 at every level. */
 int cunet_forward_bf16(cunet_plan_t* plan, const float* x, float* const* heat, int training, void* stream);
 
 /* Gradient buckets for data parallelism.  The parameter/gradient arena is laid out bucket-major:
