@@ -89,6 +89,7 @@ def main():
     ap.add_argument('--forward-only', action='store_true', help='inference: eval-mode forward (running statistics), no loss / backward')
     ap.add_argument('--bf16', action='store_true', help='bf16 activation storage + bf16 MFMA forward (train step: gradients, weights, optimiser stay fp32; '
                     'with --forward-only: bf16-storage inference)')
+    ap.add_argument('--bf16-grads', action='store_true', help='with --bf16: the gradient tensors of backward (dY, dz, dX) stored as bf16 too')
     ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
     args = ap.parse_args()
 
@@ -121,7 +122,7 @@ def main():
     if args.bits_w > 0:
         from cu_net_amd.quant import QuanOp
         quan = QuanOp(net, bits_w=args.bits_w, bits_i=8, bits_g=8)
-    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=args.bf16)
+    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=args.bf16 or args.bf16_grads, bf16_grads=args.bf16_grads)
     tr.broadcast_parameters(0)
     x, t = synthetic_batch(bs, K, 256, seed=1000 + rank, device=dev)
 
@@ -142,6 +143,7 @@ def main():
     else:
         def one_step():
             return tr.step(x, t)
+    args.bf16 = args.bf16 or args.bf16_grads
     plan = net._get_plan(bs, 256, 256, not args.forward_only, bf16=args.bf16)
     # ---- warm-up; one of the warm-up steps is profiled per kernel class to pick the dominant one
     for i in range(max(args.warmup, 1)):
@@ -230,7 +232,7 @@ def main():
             'config': {'workload': f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
                                    + (f'QuanOp bits_w={args.bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if args.bits_w > 0 else '')
                                    + (('bf16-storage' if args.bf16 else 'fp32') + ' eval-mode forward only' if args.forward_only else
-                                      ('bf16-activation' if args.bf16 else 'fp32') + ' train step (fwd + MSE + bwd + RMSprop')
+                                      ('bf16 activation + gradient tensors' if args.bf16_grads else 'bf16-activation' if args.bf16 else 'fp32') + ' train step (fwd + MSE + bwd + RMSprop')
                                    + ('' if args.forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')),
                        'global_batch': world * bs, 'parallelism': f'dp{world}'},
             'roofline': roof,

@@ -61,7 +61,7 @@ struct ConvArgs {
     // ---- stem (LD_STEM): NCHW image
     const float* img;
     int IH, IW;
-    int xbf16;             // EP_BWD: the segments' x are stored as bf16 (a, y, wB stay fp32)
+    int xbf16;             // EP_BWD: 1 = the segments' x are bf16; 2 = x, the A operand (dY) and the dz output are bf16 (wB stays fp32)
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)
@@ -83,7 +83,7 @@ struct WgradArgs {
     int ctw;               // c-tiles per job (1x1); 3x3 jobs take one c-tile x 9 taps
     const float* img;      // stem
     int IH, IW;
-    int xbf16;             // the segments' x are stored as bf16 (dy and dw stay fp32)
+    int xbf16;             // 1 = the segments' x are bf16; 2 = x and dy are bf16 (dw stays fp32)
 };
 
 constexpr int MAXGSRC = 8;  // conv consumers gathered per launch (more: further launches with accumulate = 1)
@@ -99,7 +99,7 @@ struct GradSrc {           // one conv node that reads the tensor: its BN backwa
 };
 
 struct GradGatherArgs {    // dX = sum_consumers scale*(dz - mean(dz) - xhat*mean(dz*xhat)), written once per tensor
-    int xbf16;             // 1: x is stored as bf16 (gx, dz stay fp32)
+    int xbf16;             // 1: x is stored as bf16; 2: x, every dz and gx are bf16
     int nsrc;
     int accumulate;        // 0: store, 1: add to what is there
     GradSrc src[MAXGSRC];
@@ -151,7 +151,7 @@ struct PoolArgs {
     const float* gy;       // [lo][C]
     float* gx;             // [hi][C]
     double* red;           // stem backward reductions [2][C]
-    int xbf16;             // pool backward: x is stored as bf16
+    int xbf16;             // pool backward: 1 = x is bf16; 2 = x, gy and gx are bf16
 };
 
 struct QuantEntry {      // one target conv: weight [O][I][KK] at float offset `off` of the arena
@@ -191,6 +191,28 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef const u32x2_t __attribute__((address_space(1)))* gptr_u32x2;
 __device__ __forceinline__ float bf16_bits_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_bits_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+// pointer arithmetic in elements of the storage type
+template <int XB> __device__ __forceinline__ const float* xadv(const float* base, size_t off) {
+    return XB ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + off) : base + off;
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {      // round to nearest even (finite inputs)
+    const unsigned u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <int XB> __device__ __forceinline__ void stx1(float* base, size_t off, float v) {
+    if (XB) reinterpret_cast<unsigned short*>(base)[off] = f32_to_bf16_rne(v);
+    else base[off] = v;
+}
+template <int XB> __device__ __forceinline__ void stx4(float* base, size_t off, float4 v) {      // offset % 4 == 0
+    if (XB) {
+        uint2 q;
+        q.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
+        q.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = q;
+    } else {
+        *reinterpret_cast<float4*>(base + off) = v;
+    }
+}
 template <int XB> __device__ __forceinline__ float ldx1(const float* base, size_t off) {
     if (XB) return bf16_bits_lo((unsigned)*(gptr_u16)(uintptr_t)(reinterpret_cast<const unsigned short*>(base) + off));
     return ldg1(base + off);

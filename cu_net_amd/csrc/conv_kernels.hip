@@ -83,8 +83,10 @@ __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, flo
 
 constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
 
-template <int LD, int EP, int NT, bool FAST, int XB = 0>      // XB = 1 (EP_BWD only): x of the concat is bf16
+template <int LD, int EP, int NT, bool FAST, int XBG = 0>      // EP_BWD only: 1 = x of the concat is bf16, 2 = x, dY and dz are bf16
 __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
+    constexpr int XB = XBG != 0;                     // storage of x
+    constexpr int GB = (XBG == 2 && (LD == LD_PLAIN || LD == LD_PLAIN3)) ? 1 : 0;      // storage of the gradient tensors
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
     const int kq4 = p.Kpad >> 2;
@@ -182,11 +184,11 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                         const int row = tap_row(t, valid);
                         v = ldg4(p.seg[0].x + (size_t)row * p.seg[0].ld + kk);
                     } else if (LD == LD_PLAIN) {
-                        v = ldg4(p.a + (size_t)mc * p.lda + kk);
+                        v = ldx4<GB>(p.a, (size_t)mc * p.lda + kk);
                     } else if (LD == LD_PLAIN3) {
                         bool valid;
                         const int row = tap_row(t, valid);
-                        v = ldg4(p.a + (size_t)row * p.lda + kk);
+                        v = ldx4<GB>(p.a, (size_t)row * p.lda + kk);
                         if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {  // LD_STEM: im2col gather of the NCHW image, 7x7 stride 2 pad 3
                         float e4[4];
@@ -265,17 +267,17 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                     const int row = tap_row(tap, tvalid);
                     const float* base = (LD == LD_3X3) ? p.seg[0].x : p.a;
                     const int ld = (LD == LD_3X3) ? p.seg[0].ld : p.lda;
-                    rowptr = base + (size_t)row * ld + 4 * hi;
+                    rowptr = xadv<GB>(base, (size_t)row * ld + 4 * hi);
                     ncs = nck;
                 } else {
-                    rowptr = p.a + (size_t)mc * p.lda + 4 * hi;
+                    rowptr = xadv<GB>(p.a, (size_t)mc * p.lda + 4 * hi);
                     ncs = nck;
                 }
                 cl = 0;
             };
             auto fetch = [&](float4 (&a)[4]) {                // loads chunk (sidx|tap, cl) and advances
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = ldg4(rowptr + cl * 32 + q * 8);
+                for (int q = 0; q < 4; ++q) a[q] = ldx4<GB>(rowptr, cl * 32 + q * 8);
                 if (LD == LD_PLAIN3 && !tvalid) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                         const float xv = xq[nt & 1][r];
                         const float z = fmaf(xv, csc, csh);
                         const float dz = z > 0.f ? acc[nt][r] : 0.f;
-                        p.y[(size_t)mm * p.ldy + col] = dz;
+                        stx1<GB>(p.y, (size_t)mm * p.ldy + col, dz);
                         s1 += dz;
                         s2 = fmaf(dz, (xv - cmu) * cis, s2);
                     }
@@ -600,7 +602,7 @@ static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
 
 constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 
-template <int LD, int EP, int NT, bool FAST, int XB = 0>
+template <int LD, int EP, int NT, bool FAST, int XB = 0>      // XB: 0 / 1 / 2 as ConvArgs::xbf16
 static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {       // dynamic LDS above 64 KB has to be opted into, once per instantiation
@@ -615,10 +617,15 @@ static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t 
 
 template <int LD, int EP>
 static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int threads, size_t smem, hipStream_t s) {
-    if (EP == EP_BWD && a.xbf16) {            // bf16 activations: the one-tile fast variant only (channel counts are multiples of 32)
+    if (EP == EP_BWD && a.xbf16) {            // bf16 activations (and gradients): the one-tile variants only
         if (NT != 1) return hipErrorInvalidValue;
-        if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), (EP == EP_BWD ? 1 : 0)>(a, grid, threads, smem, s);
-        return launch_inst<LD, EP, 1, false, (EP == EP_BWD ? 1 : 0)>(a, grid, threads, smem, s);      // heads: K = class_num
+        constexpr int B = (EP == EP_BWD) ? 1 : 0;
+        if (a.xbf16 == 2) {
+            if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), 2 * B>(a, grid, threads, smem, s);
+            return launch_inst<LD, EP, 1, false, 2 * B>(a, grid, threads, smem, s);
+        }
+        if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), B>(a, grid, threads, smem, s);
+        return launch_inst<LD, EP, 1, false, B>(a, grid, threads, smem, s);      // heads: K = class_num
     }
     if (fast && LD != LD_STEM) {
         switch (NT) {

@@ -22,8 +22,9 @@ __device__ __forceinline__ void atomic_add_f64e(double* p, double v) {
 // share x: A*sum(dz) + 4E - 4D*x, which IS the backward of the index map (y>>1, x>>1).
 // NSRC consumers, all plain (UPS = 0) or all through the upsample map (UPS = 1): compile-time source
 // indices keep every load of an element in flight together (a runtime loop would chain them).
-template <int NSRC, int UPS, int XB>
+template <int NSRC, int UPS, int XBG>      // XBG: 0 fp32, 1 x bf16, 2 x / dz / gx bf16
 __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p) {
+    constexpr int XB = XBG != 0, GB = XBG == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cE = reinterpret_cast<float*>(smem);       // [C]   sum of E (x4 for upsampled consumers)
     float* cD = cE + p.C;                             // [C]   sum of D
@@ -69,18 +70,17 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
         float4 d[NSRC][UPS ? 4 : 1];
 #pragma unroll
         for (int e = 0; e < NSRC; ++e) {
-            const float* b = p.src[e].dz + drow * p.src[e].lddz + p.src[e].choff + c;
-            d[e][0] = ldg4(b);
+            const size_t b = drow * p.src[e].lddz + p.src[e].choff + c;
+            d[e][0] = ldx4<GB>(p.src[e].dz, b);
             if (UPS) {
-                d[e][1] = ldg4(b + p.src[e].lddz);
-                d[e][2] = ldg4(b + (size_t)2 * p.W * p.src[e].lddz);
-                d[e][3] = ldg4(b + (size_t)(2 * p.W + 1) * p.src[e].lddz);
+                d[e][1 % (UPS ? 4 : 1)] = ldx4<GB>(p.src[e].dz, b + p.src[e].lddz);
+                d[e][2 % (UPS ? 4 : 1)] = ldx4<GB>(p.src[e].dz, b + (size_t)2 * p.W * p.src[e].lddz);
+                d[e][3 % (UPS ? 4 : 1)] = ldx4<GB>(p.src[e].dz, b + (size_t)(2 * p.W + 1) * p.src[e].lddz);
             }
         }
         const float4 x = ldx4<XB>(p.x, (size_t)row * p.ld + c);
-        float4* dst = reinterpret_cast<float4*>(p.gx + (size_t)row * p.ld + c);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.accumulate) o = *dst;
+        if (p.accumulate) o = ldx4<GB>(p.gx, (size_t)row * p.ld + c);
         const float4 E = *reinterpret_cast<const float4*>(cE + c);
         const float4 D = *reinterpret_cast<const float4*>(cD + c);
         float4 r = make_float4(E.x - D.x * x.x, E.y - D.y * x.y, E.z - D.z * x.z, E.w - D.w * x.w);
@@ -89,15 +89,16 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
             const float4 A = *reinterpret_cast<const float4*>(cA + e * p.C + c);
             float4 v = d[e][0];
             if (UPS) {
-                v.x = (d[e][0].x + d[e][1].x) + (d[e][2].x + d[e][3].x);
-                v.y = (d[e][0].y + d[e][1].y) + (d[e][2].y + d[e][3].y);
-                v.z = (d[e][0].z + d[e][1].z) + (d[e][2].z + d[e][3].z);
-                v.w = (d[e][0].w + d[e][1].w) + (d[e][2].w + d[e][3].w);
+                constexpr int U = UPS ? 4 : 1;
+                v.x = (d[e][0].x + d[e][1 % U].x) + (d[e][2 % U].x + d[e][3 % U].x);
+                v.y = (d[e][0].y + d[e][1 % U].y) + (d[e][2 % U].y + d[e][3 % U].y);
+                v.z = (d[e][0].z + d[e][1 % U].z) + (d[e][2 % U].z + d[e][3 % U].z);
+                v.w = (d[e][0].w + d[e][1 % U].w) + (d[e][2 % U].w + d[e][3 % U].w);
             }
             r.x = fmaf(A.x, v.x, r.x); r.y = fmaf(A.y, v.y, r.y); r.z = fmaf(A.z, v.z, r.z); r.w = fmaf(A.w, v.w, r.w);
         }
         r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
-        *dst = r;
+        stx4<GB>(p.gx, (size_t)row * p.ld + c, r);
     }
 }
 
@@ -119,6 +120,7 @@ hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t 
     if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
     const size_t smem = (size_t)a.C * 4 * (2 + a.nsrc);
+    if (a.xbf16 == 2) return a.src[0].ups ? launch_gather_n<1, 2>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 2>(a, dim3((unsigned)gx), smem, s);
     if (a.xbf16) return a.src[0].ups ? launch_gather_n<1, 1>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 1>(a, dim3((unsigned)gx), smem, s);
     return a.src[0].ups ? launch_gather_n<1, 0>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 0>(a, dim3((unsigned)gx), smem, s);
 }
@@ -253,8 +255,9 @@ hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t
 
 // max-pool backward: the gradient goes to the FIRST maximum in window order (0,0),(0,1),(1,0),(1,1)
 // (torch CPU max_pool2d tie-break), every other input position gets 0.
-template <int XB>
+template <int XBG>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolArgs p) {
+    constexpr int XB = XBG != 0, GB = XBG == 2;
     const int g4 = p.C >> 2;
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const long total = (long)p.N * Ho * Wo * g4;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolArgs p) {
             const float4 t = ldx4<XB>(p.x, off[k] * p.C + 4 * g);
             v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
         }
-        const float4 gq = *reinterpret_cast<const float4*>(p.gy + (size_t)row * p.C + 4 * g);
+        const float4 gq = ldx4<GB>(p.gy, (size_t)row * p.C + 4 * g);
         const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
         float o[4][4];
 #pragma unroll
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolArgs p) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            *reinterpret_cast<float4*>(p.gx + off[k] * p.C + 4 * g) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+            stx4<GB>(p.gx, off[k] * p.C + 4 * g, make_float4(o[k][0], o[k][1], o[k][2], o[k][3]));
     }
 }
 
@@ -296,7 +299,8 @@ hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s) {
     long gx = (total + 255) / 256;
     if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
-    if (a.xbf16) hipLaunchKernelGGL(pool_bwd_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, a);
+    if (a.xbf16 == 2) hipLaunchKernelGGL(pool_bwd_kernel<2>, dim3((unsigned)gx), dim3(256), 0, s, a);
+    else if (a.xbf16) hipLaunchKernelGGL(pool_bwd_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pool_bwd_kernel<0>, dim3((unsigned)gx), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -304,7 +308,7 @@ hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s) {
 // Stem backward (pool -> ReLU -> BN), two streaming passes because BN backward needs full-batch
 // reductions.  PASS 0: reductions sum(dz), sum(dz*xhat) -> p.red.  PASS 1: dC = A*dz + E - D*x.
 // dz is non-zero only at the window's first arg-max, and only where the BN output was > 0.
-template <int PASS>
+template <int PASS, int GB>      // GB = 1: gy (gradient of the pooled features) is stored as bf16
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const PoolArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const PoolArgs p) {
                 const float4 t = *reinterpret_cast<const float4*>(p.x + off[k] * p.C + 4 * g);
                 v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
             }
-            const float4 gq = *reinterpret_cast<const float4*>(p.gy + (size_t)row * p.C + 4 * g);
+            const float4 gq = ldx4<GB>(p.gy, (size_t)row * p.C + 4 * g);
             const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
             float o[4][4];
 #pragma unroll
@@ -433,9 +437,11 @@ hipError_t launch_stem_bwd(const PoolArgs& a, int pass, float* dgamma, float* db
     if (gx < 1) gx = 1;
     const size_t smem = (size_t)6 * a.C * 4 + (size_t)rpi * a.C * 2 * 8;
     if (pass == 0) {
-        hipLaunchKernelGGL(stem_bwd_kernel<0>, dim3((unsigned)gx), dim3(256), smem, s, a);
+        if (a.xbf16 == 2) hipLaunchKernelGGL((stem_bwd_kernel<0, 1>), dim3((unsigned)gx), dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((stem_bwd_kernel<0, 0>), dim3((unsigned)gx), dim3(256), smem, s, a);
     } else {
-        hipLaunchKernelGGL(stem_bwd_kernel<1>, dim3((unsigned)gx), dim3(256), smem, s, a);
+        if (a.xbf16 == 2) hipLaunchKernelGGL((stem_bwd_kernel<1, 1>), dim3((unsigned)gx), dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((stem_bwd_kernel<1, 0>), dim3((unsigned)gx), dim3(256), smem, s, a);
         hipLaunchKernelGGL(stem_bn_param_grad_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s,
                            (const double*)a.red, dgamma, dbeta, a.C);
     }
@@ -486,6 +492,7 @@ hipError_t launch_transpose(const float* src, float* dst, int N, int C, int HW, 
 
 // ---------------------------------------------------------------------------------------------
 // Pixelwise MSE of one head (cu-net.py:175-178): loss += sum((o-t)^2)/numel, dO = 2(o-t)/numel.
+template <int GB>      // GB = 1: d(loss)/d(out) is stored as bf16
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                   float* __restrict__ dout, double* loss_acc,
                                                   long rows, int C, int ld) {
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out,
         const int c = (int)(i % ld);
         float d = 0.f;
         if (c < C) d = out[i] - tgt[i];
-        dout[i] = d * ginv;
+        stx1<GB>(dout, (size_t)i, d * ginv);
         acc += (double)d * d;
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -514,10 +521,11 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out,
 __global__ void loss_finalize_kernel(const double* acc, float* loss) { *loss = (float)(*acc); }
 
 hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld,
-                      int num_cus, hipStream_t s) {
+                      int grad_bf16, int num_cus, hipStream_t s) {
     long gx = (rows * ld + 255) / 256;
     if (gx > 4L * num_cus) gx = 4L * num_cus;
-    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld);
+    if (grad_bf16) hipLaunchKernelGGL(mse_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld);
+    else hipLaunchKernelGGL(mse_kernel<0>, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld);
     return hipGetLastError();
 }
 

@@ -254,10 +254,15 @@ struct Exec {
     float* wsf;        // float region
     double* zero;      // fp64 region
     unsigned short* a16 = nullptr;   // bf16 activation arena when the last training forward was cunet_forward_bf16
+    int xmode = 0;                   // the xbf16 value for kernel arguments: 0 fp32, 1 bf16 x, 2 bf16 x and bf16 gradient tensors
+                                     // (a bf16 gradient tensor occupies the first half of its fp32 slot: same pointer)
     explicit Exec(cunet_plan* hh) : h(hh), P(hh->plan) {
         wsf = reinterpret_cast<float*>(h->ws + P.off_floats);
         zero = reinterpret_cast<double*>(h->ws + P.off_zero);
-        if (h->fwd_training_done == 2) a16 = reinterpret_cast<unsigned short*>(h->ws + P.off_bf16_train);
+        if (h->fwd_training_done >= 2) {
+            a16 = reinterpret_cast<unsigned short*>(h->ws + P.off_bf16_train);
+            xmode = h->fwd_training_done == 3 ? 2 : 1;
+        }
     }
     // activations as the backward kernels read them: fp32, or bf16 behind a float-typed pointer (xbf16 = 1 in the args)
     const float* xact(int t) const { return a16 ? reinterpret_cast<const float*>(a16 + P.tensors[t].act) : act(t); }
@@ -296,7 +301,7 @@ static int gather_tensor_grad(cunet_plan* h, int t, int only_node, hipStream_t s
         auto flush = [&]() -> int {
             if (a.nsrc == 0) return CUNET_OK;
             a.accumulate = accumulate;
-            a.x = E.xact(t); a.xbf16 = E.a16 ? 1 : 0; a.gx = E.grad(t); a.stats = E.stats(t); a.count = (double)ti.rows();
+            a.x = E.xact(t); a.xbf16 = E.xmode; a.gx = E.grad(t); a.stats = E.stats(t); a.count = (double)ti.rows();
             a.C = ti.C; a.ld = ti.ld; a.rows = (int)ti.rows(); a.H = ti.H; a.W = ti.W;
             PROF(PC_APPLY, 0.0, 4.0 * (double)ti.rows() * ti.C * (2.0 + accumulate + a.nsrc * (ups ? 4.0 : 1.0)),
                  launch_grad_gather(a, h->num_cus, s));
@@ -363,7 +368,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
             a.training = 1;
-            a.xbf16 = E.a16 ? 1 : 0;
+            a.xbf16 = E.xmode;
             a.a = E.grad(n.out); a.lda = o.ld;
             a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
             a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
@@ -378,7 +383,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
             w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
             w.dw = h->grads + c.w;
-            w.xbf16 = E.a16 ? 1 : 0;
+            w.xbf16 = E.xmode;
             PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
                     launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));
         }
@@ -387,7 +392,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         const TensorInfo& ti = P.tensors[tin];
         PoolArgs a{};
         a.x = E.xact(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
-        a.xbf16 = E.a16 ? 1 : 0;
+        a.xbf16 = E.xmode;
         a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
         PROF(PC_POOLB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_pool_bwd(a, cus, s));
     } else if (n.type == N_STEM_BNPOOL) {
@@ -400,6 +405,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
         a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 1;
         a.red = E.zero + n.red;
+        a.xbf16 = E.xmode == 2 ? 2 : 0;          // x (the stem conv output) is fp32 in every mode; gy follows the gradient storage
         PROF(PC_STEMBPB, 0.0, 4.0 * 1.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 0, nullptr, nullptr, cus, s));
         PROF(PC_STEMBPB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
     } else {  // N_STEM_CONV: weight gradient only (the image needs no gradient)
@@ -450,7 +456,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
         if (n.type == N_STEM_CONV) {
             const ConvInfo& c = P.convs[n.conv];
             ConvArgs a{};
-            a.nseg = 0; a.Ccat = 0; a.training = training;
+            a.nseg = 0; a.Ccat = 0; a.training = training ? 1 : 0;
             a.K = c.Cin; a.taps = 1; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
@@ -529,7 +535,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
         if (n.type == N_STEM_CONV) {               // fp32 kernels on the fp32 image
             const ConvInfo& c = P.convs[n.conv];
             ConvArgs a{};
-            a.nseg = 0; a.Ccat = 0; a.training = training;
+            a.nseg = 0; a.Ccat = 0; a.training = training ? 1 : 0;
             a.K = c.Cin; a.taps = 1; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
@@ -541,7 +547,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             const BnInfo& b = P.bns[n.bn];
             PoolArgs a{};
             a.x = E.act(tin); a.y = E.act(n.out); a.ystats = nullptr;       // statistics come from the bf16 copy below
-            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = training;
+            a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = training ? 1 : 0;
             a.xstats = E.stats(tin); a.count = (double)ti.rows();
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
@@ -564,7 +570,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
                 a.seg[i].x = reinterpret_cast<const float*>(a16 + P.tensors[n.segs[i].tensor].act);
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-            a.training = training;
+            a.training = training ? 1 : 0;
             a.K = n.Ccat; a.taps = c.taps; a.wB = reinterpret_cast<const float*>(a16 + c.wF); a.Kpad = c.KpadF; a.Npad = c.NpadF;
             const int is_head = n.head >= 0;
             a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
@@ -586,7 +592,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             HIPCHK(launch_transpose(E.act(P.head_tensors[i]), heat[i], t.N, t.C, t.H * t.W, t.ld, 0, s));
         }
     }
-    h->fwd_training_done = training ? 2 : 0;        // 2: activations are in the bf16 arena
+    h->fwd_training_done = training ? (training == 2 ? 3 : 2) : 0;        // 2: activations are in the bf16 arena; 3: gradient tensors bf16 too
     h->loss_done = 0;
     h->last_x = x;
     return CUNET_OK;
@@ -605,7 +611,7 @@ int cunet_loss_mse(cunet_plan_t* h, const float* target, float* loss, void* stre
     HIPCHK(hipMemsetAsync(acc, 0, 8, s));
     for (int ht : P.head_tensors) {
         const TensorInfo& t = P.tensors[ht];
-        HIPCHK(launch_mse(E.act(ht), tgt, E.grad(ht), acc, (long)t.rows(), t.C, t.ld, h->num_cus, s));
+        HIPCHK(launch_mse(E.act(ht), tgt, E.grad(ht), acc, (long)t.rows(), t.C, t.ld, E.xmode == 2, h->num_cus, s));
     }
     HIPCHK(launch_loss_finalize(acc, loss, s));
     h->loss_done = 1;
@@ -652,6 +658,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
     if (!h->fwd_training_done) return fail(CUNET_ERR_STATE, "cunet_backward needs a preceding training-mode cunet_forward");
     if (!grad_heat && !h->loss_done) return fail(CUNET_ERR_STATE, "no staged loss gradient: call cunet_loss_mse or pass grad_heat");
+    if (grad_heat && h->fwd_training_done == 3) return fail(CUNET_ERR_STATE, "bf16 gradient storage takes its loss gradient from cunet_loss_mse only");
     hipStream_t s = (hipStream_t)stream;
     Exec E(h);
     Plan& P = h->plan;

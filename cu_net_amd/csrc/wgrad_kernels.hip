@@ -20,8 +20,9 @@ constexpr int WG_UNROLL = 4;     // row pairs in flight per wave
 
 enum WgLoad { WG_SEG = 0, WG_3X3 = 1, WG_STEM = 2 };
 
-template <int LD, int NACC, int XB>
+template <int LD, int NACC, int XBG>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    constexpr int XB = XBG != 0, GB = XBG == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);     // [4 waves][1024]
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const int m = base + 2 * u + hi;
             const bool mok = m < row_end;
             const int mc = mok ? m : row_begin;
-            av[u] = ldg1(p.dy + (size_t)mc * p.lddy + (nok ? n0 + li : 0));
+            av[u] = ldx1<GB>(p.dy, (size_t)mc * p.lddy + (nok ? n0 + li : 0));
             const int nimg = mc / HW;
             const int rem = mc - nimg * HW;
             const int py = rem / p.W;
@@ -209,8 +210,9 @@ struct Wg2Args {
     int rows_per_chunk[12];
 };
 
-template <int NTW, int CT, bool UPS, bool STEM = false, int XB = 0>      // XB = 1: the segments' x are stored as bf16
+template <int NTW, int CT, bool UPS, bool STEM = false, int XBG = 0>      // XBG: 1 = x is bf16, 2 = x and dY are bf16
 __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int chunk, int rpc, float* lds) {
+    constexpr int XB = XBG != 0, GB = XBG == 2;
     const WgradArgs& p = q.w;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -286,11 +288,11 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         const bool mok = m < row_end;
         const int mc = mok ? m : row_begin;
         {
-            const float* src = p.dy + (size_t)mc * p.lddy + acol;
-            if (NTW == 4) { const float4 v = ldg4(src); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+            const size_t ao = (size_t)mc * p.lddy + acol;
+            if (NTW == 4) { const float4 v = ldx4<GB>(p.dy, ao); a[0] = v.x; a[1 % NTW] = v.y; a[2 % NTW] = v.z; a[3 % NTW] = v.w; }
             else {
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) a[t] = ldg1(src + t);
+                for (int t = 0; t < NTW; ++t) a[t] = ldx1<GB>(p.dy, ao + t);
             }
         }
         if constexpr (STEM) {      // gather of the image: output pixel (py, px) reads rows 2py-3+ky, columns 2px-3+kx
@@ -335,10 +337,11 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         // statement names the slot's registers as read-write operands, which pins every consumer behind it.
         constexpr int PD = 6;
         f32x4 A4[PD];
+        f32x2 A2[GB ? PD : 1];                  // bf16 dY: four values in two registers
         f32x2 X2[PD];
         float X1[PD];
         bool OK[PD];
-        auto issue_asm = [&](int mm0, f32x4& a4, f32x2& x2, float& x1, bool& ok) {
+        auto issue_asm = [&](int mm0, f32x4& a4, f32x2& a2, f32x2& x2, float& x1, bool& ok) {
             const int m = mm0 + hi;
             const bool mok = m < row_end;
             const int mc = mok ? m : row_begin;
@@ -352,7 +355,12 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
                 xrow = xups ? rowU : mc;
             }
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a4) : "v"(asrc) : "memory");
+            if constexpr (GB) {
+                const unsigned short* asrc16 = reinterpret_cast<const unsigned short*>(p.dy) + (size_t)mc * p.lddy + acol;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(a2) : "v"(asrc16) : "memory");
+            } else {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a4) : "v"(asrc) : "memory");
+            }
             if constexpr (XB) {        // bf16 x: CT = 2 -> one dword (two bf16), CT = 1 -> one ushort; unpacked at consumption (x1 carries the bits)
                 const unsigned short* xsrc = reinterpret_cast<const unsigned short*>(xbase) + (size_t)xrow * xldc;
                 if constexpr (CT == 2) asm volatile("global_load_dword %0, %1, off" : "=v"(x1) : "v"(xsrc) : "memory");
@@ -366,18 +374,26 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         };
         int mm = row_begin + 2 * wave;
 #pragma unroll
-        for (int u = 0; u < PD; ++u) issue_asm(mm + u * 8, A4[u], X2[u], X1[u], OK[u]);
+        for (int u = 0; u < PD; ++u) issue_asm(mm + u * 8, A4[u], A2[GB ? u : 0], X2[u], X1[u], OK[u]);
         for (; mm < row_end; mm += PD * 8) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                if constexpr (CT == 2 && !XB)
+                if constexpr (GB)
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A2[GB ? u : 0]), "+v"(X1[u]) : "n"(2 * (PD - 1)) : "memory");
+                else if constexpr (CT == 2 && !XB)
                     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A4[u]), "+v"(X2[u]) : "n"(2 * (PD - 1)) : "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A4[u]), "+v"(X1[u]) : "n"(2 * (PD - 1)) : "memory");
                 float a[4], x[CT];
                 const bool okk = OK[u];
-                a[0] = (okk && nok) ? A4[u].x : 0.f; a[1] = (okk && nok) ? A4[u].y : 0.f;
-                a[2] = (okk && nok) ? A4[u].z : 0.f; a[3] = (okk && nok) ? A4[u].w : 0.f;
+                if constexpr (GB) {
+                    const unsigned b0 = __float_as_uint(A2[GB ? u : 0].x), b1 = __float_as_uint(A2[GB ? u : 0].y);
+                    a[0] = (okk && nok) ? bf16_bits_lo(b0) : 0.f; a[1] = (okk && nok) ? bf16_bits_hi(b0) : 0.f;
+                    a[2] = (okk && nok) ? bf16_bits_lo(b1) : 0.f; a[3] = (okk && nok) ? bf16_bits_hi(b1) : 0.f;
+                } else {
+                    a[0] = (okk && nok) ? A4[u].x : 0.f; a[1] = (okk && nok) ? A4[u].y : 0.f;
+                    a[2] = (okk && nok) ? A4[u].z : 0.f; a[3] = (okk && nok) ? A4[u].w : 0.f;
+                }
                 if constexpr (XB) {
                     const unsigned bits = __float_as_uint(X1[u]);
                     x[0] = (okk && cok) ? fmaxf(fmaf(bf16_bits_lo(bits), xsc[0], xsh[0]), 0.f) : 0.f;
@@ -388,7 +404,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 } else {
                     x[0] = (okk && cok) ? fmaxf(fmaf(X1[u], xsc[0], xsh[0]), 0.f) : 0.f;
                 }
-                issue_asm(mm + (u + PD) * 8, A4[u], X2[u], X1[u], OK[u]);        // refill this slot PD pairs ahead
+                issue_asm(mm + (u + PD) * 8, A4[u], A2[GB ? u : 0], X2[u], X1[u], OK[u]);        // refill this slot PD pairs ahead
 #pragma unroll
                 for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
@@ -399,7 +415,8 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
         // drain: the tail refills are still in flight and own their registers until they land
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-            if constexpr (CT == 2 && !XB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X2[u]) : : "memory");
+            if constexpr (GB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A2[GB ? u : 0]), "+v"(X1[u]) : : "memory");
+            else if constexpr (CT == 2 && !XB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X2[u]) : : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(A4[u]), "+v"(X1[u]) : : "memory");
         }
     } else {
@@ -550,6 +567,7 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     if (!done) {
         hipError_t e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4, 0>));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4, 1>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<4, 2>));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2, 0>));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_stem_kernel));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1, 0>));
@@ -559,7 +577,8 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     if (q.stem) hipLaunchKernelGGL(wgrad2_stem_kernel, grid, dim3(256), smem, s, q);
     else if (a.xbf16) {
         if (ntw != 4) return hipErrorInvalidValue;       // bf16 activations: heads and bottlenecks have > 64 output channels
-        hipLaunchKernelGGL((wgrad2_kernel<4, 1>), grid, dim3(256), smem, s, q);
+        if (a.xbf16 == 2) hipLaunchKernelGGL((wgrad2_kernel<4, 2>), grid, dim3(256), smem, s, q);
+        else hipLaunchKernelGGL((wgrad2_kernel<4, 1>), grid, dim3(256), smem, s, q);
     } else if (ntw == 4) hipLaunchKernelGGL((wgrad2_kernel<4, 0>), grid, dim3(256), smem, s, q);
     else if (ntw == 2) hipLaunchKernelGGL((wgrad2_kernel<2, 0>), grid, dim3(256), smem, s, q);
     else hipLaunchKernelGGL((wgrad2_kernel<1, 0>), grid, dim3(256), smem, s, q);
@@ -569,7 +588,8 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
 template <int LD>
 static hipError_t launch_acc(const WgradArgs& a, int nacc, dim3 grid, hipStream_t s) {
     const size_t smem = (size_t)4 * 1024 * 4 + (LD == WG_3X3 ? (size_t)9 * 1024 * 4 : 0);
-#define CUNET_WG(N) case N: if (a.xbf16) hipLaunchKernelGGL((wgrad_kernel<LD, N, 1>), grid, dim3(256), smem, s, a); \
+#define CUNET_WG(N) case N: if (a.xbf16 == 2) hipLaunchKernelGGL((wgrad_kernel<LD, N, 2>), grid, dim3(256), smem, s, a); \
+                    else if (a.xbf16) hipLaunchKernelGGL((wgrad_kernel<LD, N, 1>), grid, dim3(256), smem, s, a); \
                     else hipLaunchKernelGGL((wgrad_kernel<LD, N, 0>), grid, dim3(256), smem, s, a); break;
     switch (nacc) {
         CUNET_WG(1) CUNET_WG(2) CUNET_WG(3) CUNET_WG(4) CUNET_WG(5) CUNET_WG(9)

@@ -67,6 +67,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--bits_g', type=int, default=8)
     # not in the reference: there is no dataset in this repository
     p.add_argument('--bf16', type=_str2bool, default=False, help='bf16 activation storage + bf16 MFMA forward (gradients, weights, RMSprop fp32)')
+    p.add_argument('--bf16_grads', type=_str2bool, default=False, help='with --bf16: gradient tensors of backward stored as bf16 too')
     p.add_argument('--synthetic', type=int, default=0, help='>0: that many synthetic batches per epoch instead of MPII')
     return p
 
@@ -280,7 +281,7 @@ def main(argv=None, train_loader: Optional[Iterable] = None, val_loader: Optiona
     if opt.bits_w > 0:
         from .quant import QuanOp
         quan = QuanOp(net, bits_w=opt.bits_w, bits_i=opt.bits_i, bits_g=opt.bits_g)
-    trainer = FusedTrainer(net, lr=opt.lr, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=opt.bf16)
+    trainer = FusedTrainer(net, lr=opt.lr, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=opt.bf16, bf16_grads=opt.bf16_grads)
     history = TrainHistory()
     save_prefix = exp_dir + '/'
     start_epoch = 0

@@ -46,6 +46,7 @@ class _BoundPlan:
         dev = net._param_arena.device
         nbytes = self.handle.workspace_bytes((3 if training_ws else 2) if bf16 else training_ws)      # 2 / 3: + bf16 arena
         self.bf16 = bf16
+        self.grad_bf16 = False
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.hw_out = (h // 4, w // 4)
@@ -80,7 +81,8 @@ class _BoundPlan:
         if want_outputs:
             outs = [torch.empty((n, k, self.hw_out[0], self.hw_out[1]), dtype=torch.float32, device=x.device) for _ in range(self.num_heads)]
             arr = (C.c_void_p * self.num_heads)(*[o.data_ptr() for o in outs])
-        check(lib().cunet_forward_bf16(self.handle.h, _ptr(x), arr, 1 if training else 0, _stream_ptr(x.device)), 'cunet_forward_bf16')
+        self.grad_bf16 = int(training) == 2               # True/1: bf16 activations; 2: bf16 gradient tensors as well
+        check(lib().cunet_forward_bf16(self.handle.h, _ptr(x), arr, int(training), _stream_ptr(x.device)), 'cunet_forward_bf16')
         self.generation += 1
         self._last_x = x
         return outs
@@ -114,9 +116,17 @@ class _BoundPlan:
         t = [t for t in d['tensors'] if t['name'] == name][0]
         off = self.handle.tensor_offset(name, 1 if grad else 0)
         rows = t['N'] * t['H'] * t['W']
-        flat = self.workspace[off: off + rows * t['ld'] * 4].view(torch.float32).view(t['N'], t['H'], t['W'], t['ld'])
+        if grad and self.grad_bf16 and self._grad_is_bf16(d, t):       # a bf16 gradient tensor sits in the first half of its slot
+            flat = self.workspace[off: off + rows * t['ld'] * 2].view(torch.bfloat16).view(t['N'], t['H'], t['W'], t['ld'])
+        else:
+            flat = self.workspace[off: off + rows * t['ld'] * 4].view(torch.float32).view(t['N'], t['H'], t['W'], t['ld'])
         flat.zero_()
-        flat[..., :t['C']] = value.to(flat.device).permute(0, 2, 3, 1)
+        flat[..., :t['C']] = value.to(flat.device).permute(0, 2, 3, 1).to(flat.dtype)
+
+    @staticmethod
+    def _grad_is_bf16(d, t) -> bool:
+        """With bf16 gradient storage every gradient tensor is bf16 except d(loss)/d(stem conv output)."""
+        return t['id'] != d['nodes'][0]['out']
 
     def debug_run_node_backward(self, node_index: int):
         check(lib().cunet_debug_run_node_backward(self.handle.h, node_index, _stream_ptr(self.workspace.device)),
@@ -127,7 +137,10 @@ class _BoundPlan:
         d = self.handle.describe()
         t = [t for t in d['tensors'] if t['name'] == name][0]
         rows = t['N'] * t['H'] * t['W']
-        if self.bf16 and not grad and self._in_bf16_arena(d, t):
+        if grad and self.grad_bf16 and self._grad_is_bf16(d, t):
+            off = self.handle.tensor_offset(name, 1)
+            flat = self.workspace[off: off + rows * t['ld'] * 2].view(torch.bfloat16).float()
+        elif self.bf16 and not grad and self._in_bf16_arena(d, t):
             base = (self.handle.workspace_bytes(self.training_ws) + 255) // 256 * 256      # where the bf16 arena starts
             flat = self.workspace[base + 2 * t['act']: base + 2 * (t['act'] + rows * t['ld'])].view(torch.bfloat16).float()
         else:

@@ -18,7 +18,7 @@ from .module import CUNet, _ptr, _stream_ptr
 
 class FusedTrainer:
     def __init__(self, net: CUNet, lr: float = 2.5e-4, alpha: float = 0.99, eps: float = 1e-8,
-                 process_group=None, overlap: bool = True, quan_op=None, bf16: bool = False):
+                 process_group=None, overlap: bool = True, quan_op=None, bf16: bool = False, bf16_grads: bool = False):
         """RMSprop hyper-parameters default to cu-net.py:60-61. `process_group`: a torch.distributed
         group (backend nccl == RCCL) for data parallelism, or None."""
         if not isinstance(net, CUNet):
@@ -26,7 +26,8 @@ class FusedTrainer:
         self.net = net
         self.lr, self.alpha, self.eps = float(lr), float(alpha), float(eps)
         self.square_avg = None
-        self.bf16 = bool(bf16)        # bf16 activation storage + bf16 MFMA forward; gradients, weights and the optimiser stay fp32
+        self.bf16 = bool(bf16) or bool(bf16_grads)   # bf16 activation storage + bf16 MFMA forward; weights and the optimiser stay fp32
+        self.bf16_grads = bool(bf16_grads)           # ... and the gradient tensors of backward (dY, dz, dX) stored as bf16 too
         self.steps_done = 0           # optimiser steps taken (the `step` entry of torch's RMSprop state)
         self.quan_op = quan_op        # cu_net_amd.quant.QuanOp / BinOp: quantised training (cu-net-prev-version-wig.py:163-190)
         self.pg = process_group
@@ -59,7 +60,7 @@ class FusedTrainer:
         if self.quan_op is not None:
             self.quan_op.quantization()
         if self.bf16:
-            plan.forward_bf16(img, True, want_outputs=False)
+            plan.forward_bf16(img, 2 if self.bf16_grads else 1, want_outputs=False)
         else:
             plan.forward(img, True, want_outputs=False)
         loss = plan.loss_mse(heatmap)

@@ -108,7 +108,9 @@ int cunet_backward(cunet_plan_t* plan, const float* const* grad_heat, void* stre
  * accumulation, BatchNorm + ReLU in fp32).  training = 0: running statistics; needs a plan bound with training = 0 on
  * cunet_workspace_bytes(plan, 2) bytes.  training = 1: batch statistics of the bf16-rounded tensors; needs a training
  * bind on cunet_workspace_bytes(plan, 3) bytes, and cunet_loss_mse / cunet_backward after it read x as bf16 while
- * gradients, weights and the optimiser stay fp32.  Channel counts must be multiples of 32, rows of 32 at every level. */
+ * gradients, weights and the optimiser stay fp32.  training = 2: as 1, and the gradient TENSORS of backward (dY, dz, dX
+ * of every node) are stored as bf16 too (parameter gradients, weights and the optimiser stay fp32; the loss gradient
+ * must come from cunet_loss_mse).  Channel counts must be multiples of 32, rows of 32 at every level. */
 int cunet_forward_bf16(cunet_plan_t* plan, const float* x, float* const* heat, int training, void* stream);
 
 /* Gradient buckets for data parallelism.  The parameter/gradient arena is laid out bucket-major:

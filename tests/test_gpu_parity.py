@@ -402,14 +402,16 @@ def test_bf16_activation_train_step_tracks_fp32():
     x, target = O.synthetic_batch(4, spec.class_num, 256, seed=13)
     xd, td = x.cuda(), target.cuda()
     hist = {}
-    for bf16 in (False, True):
+    for mode in ('fp32', 'bf16', 'bf16_grads'):
         net = cu_net_amd.create_cu_net(**g.cfg)
         net.load_state_dict(st)
         net.cuda().train()
-        tr = FusedTrainer(net, lr=2.5e-4, bf16=bf16)
-        hist[bf16] = [float(tr.step(xd, td)) for _ in range(10)]
-        assert all(torch.isfinite(torch.tensor(hist[bf16])))
-    a, b = hist[False], hist[True]
-    assert abs(b[0] - a[0]) <= 2e-2 * a[0], (a[0], b[0])
-    assert b[-1] < b[0]
-    assert abs((b[0] - b[-1]) - (a[0] - a[-1])) <= 0.1 * (a[0] - a[-1]), (a, b)
+        tr = FusedTrainer(net, lr=2.5e-4, bf16=mode != 'fp32', bf16_grads=mode == 'bf16_grads')
+        hist[mode] = [float(tr.step(xd, td)) for _ in range(10)]
+        assert all(torch.isfinite(torch.tensor(hist[mode])))
+    a = hist['fp32']
+    for mode in ('bf16', 'bf16_grads'):          # (bf16_grads: dY, dz, dX of every node stored as bf16 as well)
+        b = hist[mode]
+        assert abs(b[0] - a[0]) <= 2e-2 * a[0], (mode, a[0], b[0])
+        assert b[-1] < b[0]
+        assert abs((b[0] - b[-1]) - (a[0] - a[-1])) <= 0.1 * (a[0] - a[-1]), (mode, a, b)
