@@ -98,28 +98,46 @@ hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long row
 // ---------------------------------------------------------------------------------------------
 // Weights torch [Cout][Cin][taps] fp32 -> bf16 B operand [tap][Kpad/8][Npad][8] (K = Cin, N = Cout), one launch
 // for every conv (blockIdx.y); same element offsets (dstF) as the fp32 operand, in the bf16 arena.
-__global__ __launch_bounds__(256) void repack_bf16_kernel(const RepackEntry* tab, const float* params, u16* arena) {
+__global__ __launch_bounds__(256) void repack_bf16_kernel(const RepackEntry* tab, const float* params, u16* arena, int with_backward) {
     const RepackEntry e = tab[blockIdx.y];
     const float* w = params + e.src;
-    const long total = (long)e.taps * e.KpadF * e.NpadF;
-    u16* dst = arena + e.dstF;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total / 2; i += (long)gridDim.x * 256) {
-        const long j = 2 * i;
-        const int ee = (int)(j & 7);
-        long r = j >> 3;
-        const int n = (int)(r % e.NpadF); r /= e.NpadF;
-        const int kq = (int)(r % (e.KpadF >> 3));
-        const int t = (int)(r / (e.KpadF >> 3));
-        const int k = 8 * kq + ee;
-        const float a = (k < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k) * e.taps + t] : 0.f;
-        const float b = (k + 1 < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k + 1) * e.taps + t] : 0.f;
-        reinterpret_cast<unsigned*>(dst)[i] = pack_bf16(a, b);
+    {
+        const long total = (long)e.taps * e.KpadF * e.NpadF;
+        u16* dst = arena + e.dstF;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total / 2; i += (long)gridDim.x * 256) {
+            const long j = 2 * i;
+            const int ee = (int)(j & 7);
+            long r = j >> 3;
+            const int n = (int)(r % e.NpadF); r /= e.NpadF;
+            const int kq = (int)(r % (e.KpadF >> 3));
+            const int t = (int)(r / (e.KpadF >> 3));
+            const int k = 8 * kq + ee;
+            const float a = (k < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k) * e.taps + t] : 0.f;
+            const float b = (k + 1 < e.Cin && n < e.Cout) ? w[((size_t)n * e.Cin + k + 1) * e.taps + t] : 0.f;
+            reinterpret_cast<unsigned*>(dst)[i] = pack_bf16(a, b);
+        }
+    }
+    if (with_backward && e.dstB >= 0 && (e.KpadB & 7) == 0) {      // K = Cout, N = Cin, taps flipped (data gradient)
+        const long total = (long)e.taps * e.KpadB * e.NpadB;
+        u16* dst = arena + e.dstB;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total / 2; i += (long)gridDim.x * 256) {
+            const long j = 2 * i;
+            const int ee = (int)(j & 7);
+            long r = j >> 3;
+            const int n = (int)(r % e.NpadB); r /= e.NpadB;
+            const int kq = (int)(r % (e.KpadB >> 3));
+            const int t = (int)(r / (e.KpadB >> 3));
+            const int k = 8 * kq + ee;                             // output channel of the forward conv
+            const float a = (k < e.Cout && n < e.Cin) ? w[((size_t)k * e.Cin + n) * e.taps + (e.taps - 1 - t)] : 0.f;
+            const float b = (k + 1 < e.Cout && n < e.Cin) ? w[((size_t)(k + 1) * e.Cin + n) * e.taps + (e.taps - 1 - t)] : 0.f;
+            reinterpret_cast<unsigned*>(dst)[i] = pack_bf16(a, b);
+        }
     }
 }
 
-hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, hipStream_t s) {
+hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, int with_backward, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(repack_bf16_kernel, dim3(16, n), dim3(256), 0, s, tab, params, (u16*)arena);
+    hipLaunchKernelGGL(repack_bf16_kernel, dim3(16, n), dim3(256), 0, s, tab, params, (u16*)arena, with_backward);
     return hipGetLastError();
 }
 
@@ -393,6 +411,270 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data gradient with bf16 MFMA (bf16 gradient-tensor storage, FusedTrainer(bf16_grads=True)):
+//   dz[m][c] = relu'(BN(x)[m][c]) * sum_{tap, n} dY[m + tap][n] * W[n][c][flip(tap)]
+// A = dY (bf16, no activation in front of it), B = the backward weight operand (bf16, [tap][Cout/8][Cin][8], taps
+// flipped), accumulators fp32.  Epilogue as EP_BWD of conv_kernel: x (bf16, read through the node's segment table,
+// up-sample map included) gives the ReLU mask and x-hat, dz is stored bf16, sum(dz) and sum(dz * xhat) go to `ystats`
+// (= d beta, d gamma) in fp64.  Requirements: K (= Cout) and every segment multiples of 32, M of 32, W of 4.
+struct Grp16 { const u16* ptr; int ld; int ups; };
+
+template <int TAPS, int NT>
+__global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NB = NT * 32;
+    const int kq8 = p.Kpad >> 3;
+    const int brows = TAPS * kq8;
+    uint4* Bs = reinterpret_cast<uint4*>(smem);                      // [TAPS * K/8][NB]
+    float* sc = reinterpret_cast<float*>(Bs + (size_t)brows * NB);    // [Ccat] each
+    float* sh = sc + p.Ccat;
+    float* mu = sh + p.Ccat;
+    float* is = mu + p.Ccat;
+    Grp16* grp = reinterpret_cast<Grp16*>(is + p.Ccat);               // [Ccat / 4]
+    double* redbuf = reinterpret_cast<double*>(grp + (p.Ccat >> 2));  // [NB][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const u16* wB = reinterpret_cast<const u16*>(p.wB);
+    const u16* dY = reinterpret_cast<const u16*>(p.a);
+
+    {   // B operand -> LDS
+        const int total = brows * NB;
+        for (int base = tid; base < total; base += blockDim.x * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * blockDim.x;
+                const int ic = idx < total ? idx : 0;
+                const int row = ic / NB;
+                const int n = ic - row * NB;
+                const int nn = (n0 + n < p.Npad) ? n0 + n : 0;
+                v[u] = ldg16(wB + ((size_t)row * p.Npad + nn) * 8);
+                if (n0 + n >= p.Npad) v[u] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * blockDim.x;
+                if (idx < total) Bs[idx] = v[u];
+            }
+        }
+    }
+    for (int sgi = 0; sgi < p.nseg; ++sgi) {           // BN tables of the concat (batch statistics) and the segment table
+        const Seg sg = p.seg[sgi];
+        for (int lc = tid; lc < sg.C; lc += blockDim.x) {
+            const int c = sg.choff + lc;
+            const double mean = sg.stats[lc] / sg.count;
+            double var = sg.stats[sg.C + lc] / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+            const double scale = (double)p.gamma[c] * istd;
+            sc[c] = (float)scale;
+            sh[c] = (float)((double)p.beta[c] - mean * scale);
+            mu[c] = (float)mean;
+            is[c] = (float)istd;
+        }
+        for (int g = tid; g < (sg.C >> 2); g += blockDim.x) {
+            Grp16 e;
+            e.ptr = reinterpret_cast<const u16*>(sg.x) + 4 * g;
+            e.ld = sg.ld;
+            e.ups = sg.ups;
+            grp[(sg.choff >> 2) + g] = e;
+        }
+    }
+    for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
+    __syncthreads();
+
+    const int HW = p.H * p.W;
+    const int nck = p.Kpad >> 5;
+    const int nchunks = TAPS * nck;
+    const int ntiles = p.M >> 5;
+    double dsum[NT], dsq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
+
+    for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+        const int m = tile * 32 + li;
+        const int nimg = m / HW;
+        const int rem = m - nimg * HW;
+        const int py = rem / p.W;
+        const int px = rem - py * p.W;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+        int cl = 0, tap = 0;
+        const u16* rowptr = nullptr;
+        bool tvalid = true;
+        auto enter = [&]() {
+            if (TAPS == 1) {
+                rowptr = dY + (size_t)m * p.lda + 8 * hi;
+            } else {
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int yy = py + dy, xx = px + dx;
+                tvalid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+                rowptr = dY + (size_t)(tvalid ? m + dy * p.W + dx : m) * p.lda + 8 * hi;
+            }
+            cl = 0;
+        };
+        enter();
+        uint4 anext[2];
+        bool vcur = tvalid;
+        anext[0] = ldg16(rowptr);
+        anext[1] = ldg16(rowptr + 16);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            uint4 acur[2] = {anext[0], anext[1]};
+            const bool vthis = vcur;
+            if (ch + 1 < nchunks) {
+                if (++cl == nck) { ++tap; enter(); }
+                vcur = tvalid;
+                anext[0] = ldg16(rowptr + cl * 32);
+                anext[1] = ldg16(rowptr + cl * 32 + 16);
+            }
+            const uint4* bb = Bs + (size_t)ch * 4 * NB;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 a = acur[s];
+                if (TAPS == 9 && !vthis) a = make_uint4(0, 0, 0, 0);
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue.  Rows of this lane's 16 accumulator registers, plain and through the up-sample map (W % 4 == 0:
+        //      registers 4k..4k+3 lie in one image row, one division per group)
+        const int mrow0 = tile * 32;
+        int rowP[16], rowUp[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m4 = mrow0 + 8 * k + 4 * hi;
+            const int ni = m4 / HW;
+            const int rm = m4 - ni * HW;
+            const int yy = rm / p.W;
+            const int xx = rm - yy * p.W;
+            const int base = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rowP[4 * k + j] = m4 + j; rowUp[4 * k + j] = base + (j >> 1); }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 32 + li;
+            const bool colok = col < p.Nout;
+            Grp16 g;
+            g.ptr = dY; g.ld = 0; g.ups = 0;                     // always a valid address: the loads stay branch-free
+            if (colok) g = grp[col >> 2];
+            const u16* xcol = g.ptr + (colok ? (col & 3) : 0);
+            const bool up = g.ups != 0;
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                xv[r] = bf16_lo((unsigned)*(gptr_u16)(uintptr_t)(xcol + (size_t)(up ? rowUp[r] : rowP[r]) * g.ld));
+            float csc = 0.f, csh = 0.f, cmu = 0.f, cis = 0.f;
+            if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
+            float s1 = 0.f, s2 = 0.f;
+            if (colok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float z = fmaf(xv[r], csc, csh);
+                    const float dz = z > 0.f ? acc[nt][r] : 0.f;
+                    reinterpret_cast<u16*>(p.y)[(size_t)rowP[r] * p.ldy + col] = (u16)(pack_bf16(dz, 0.f) & 0xffffu);
+                    s1 += dz;
+                    s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
+                }
+            }
+            dsum[nt] += (double)s1;
+            dsq[nt] += (double)s2;
+        }
+    }
+
+    if (p.ystats != nullptr) {
+        double a1[NT], a2[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            a1[nt] = dsum[nt] + shfl_xor_d16(dsum[nt]);
+            a2[nt] = dsq[nt] + shfl_xor_d16(dsq[nt]);
+        }
+        if (hi == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], a1[nt]);
+                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], a2[nt]);
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            const int col = n0 + tid;
+            if (col < p.Nout) {
+                __hip_atomic_fetch_add(p.ystats + col, redbuf[tid * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(p.ystats + p.Nout + col, redbuf[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+static size_t dgrad_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
+    return (size_t)taps * (Kpad / 8) * NT * 32 * 16 + (size_t)Ccat * 16 + (size_t)(Ccat / 4) * sizeof(Grp16) + (size_t)NT * 32 * 16 + 16;
+}
+
+template <int TAPS, int NT>
+static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_kernel<TAPS, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((dgrad_bf16_kernel<TAPS, NT>), grid, dim3(threads), smem, s, a);
+    return hipGetLastError();
+}
+
+// a.a (dY), a.seg[*].x, a.wB (backward operand), a.y (dz): bf16 behind float-typed pointers.  hipErrorInvalidValue when
+// the shape is outside the kernel's requirements (the caller then uses conv_kernel's XB = 2 variant).
+hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
+    if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9) || (a.W & 3) || a.lda % 8 || a.Nout % 4) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % 32) return hipErrorInvalidValue;
+    const int ntiles = a.M / 32;
+    const int ncol32 = (a.Nout + 31) / 32;
+    static const int ntmax = getenv("CUNET_DG16_NT") ? atoi(getenv("CUNET_DG16_NT")) : 2;
+    int NT = 1;
+    float best = 1e30f;
+    for (int c = ntmax >= 2 ? 2 : 1; c >= 1; --c) {
+        if (dgrad_bf16_smem(c, a.taps, a.Kpad, a.Ccat) > 150 * 1024) continue;
+        const int slices = (ncol32 + c - 1) / c;
+        const float cost = slices * ((float)c + 0.3f);
+        if (cost < best) { best = cost; NT = c; }
+    }
+    const size_t smem = dgrad_bf16_smem(NT, a.taps, a.Kpad, a.Ccat);
+    if (smem > 150 * 1024) return hipErrorInvalidValue;
+    const int gy = (ncol32 + NT - 1) / NT;
+    const int blocks_per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : 3);
+    const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
+    int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
+    if (waves > B16_MAX_WAVES / blocks_per_cu) waves = B16_MAX_WAVES / blocks_per_cu;
+    if (waves < 1) waves = 1;
+    int gx = (ntiles + waves - 1) / waves;
+    if (gx > max_blocks_x) gx = max_blocks_x;
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, gy);
+    const int threads = (waves < 4 ? 4 : waves) * 64;
+    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(a, grid, threads, smem, s) : launch_dg16_inst<1, 1>(a, grid, threads, smem, s);
+    return NT == 2 ? launch_dg16_inst<9, 2>(a, grid, threads, smem, s) : launch_dg16_inst<9, 1>(a, grid, threads, smem, s);
 }
 
 static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {

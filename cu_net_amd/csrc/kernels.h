@@ -23,7 +23,8 @@ hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, flo
 hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
                           float gscale, hipStream_t s);
 hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long rows, int C, int num_cus, hipStream_t s);
-hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, hipStream_t s);
+hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, int with_backward, hipStream_t s);
+hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H, int W, int C, int num_cus, hipStream_t s);
 hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStream_t s);
 hipError_t launch_render_targets(const double* pts, const float* patch, int half, float* out, int NK, int H, int W, hipStream_t s);

@@ -373,8 +373,26 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
             a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
-                 launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
+            static const int dg16 = getenv("CUNET_NO_DGRAD_BF16") ? 0 : 1;
+            bool done = false;
+            if (E.xmode == 2 && dg16 && n.head < 0) {      // bf16 gradient tensors: bf16 MFMA data gradient where the shape allows
+                ConvArgs b16 = a;
+                b16.wB = reinterpret_cast<const float*>(E.a16 + c.wB);
+                int slot_;
+                HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3D : PC_C1D, s, slot_));
+                const hipError_t e = launch_dgrad_bf16(b16, cus, s);
+                if (e == hipSuccess) {
+                    HIPCHK(prof_end(h, slot_, 2.0 * a.M * a.K * a.Nout * a.taps, 2.0 * (double)a.M * (a.K + 2.0 * a.Nout), s));
+                    done = true;
+                } else if (e != hipErrorInvalidValue) {
+                    HIPCHK(e);
+                } else {
+                    HIPCHK(prof_end(h, slot_, 0.0, 0.0, s));
+                }
+            }
+            if (!done)
+                PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
+                     launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
         }
         {   // weight gradient
             WgradArgs w{};
@@ -528,7 +546,8 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
     unsigned short* a16 = reinterpret_cast<unsigned short*>(h->ws + off16);      // bf16 arena, element offsets as the fp32 layout
     HIPCHK(hipMemsetAsync(h->ws + P.off_zero, 0, (size_t)P.zero_bytes, s));
     HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
-    HIPCHK(launch_repack_bf16(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, a16, s));
+    HIPCHK(launch_repack_bf16(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, a16,
+                              training == 2, s));
     for (size_t ni = 0; ni < P.nodes.size(); ++ni) {
         const Node& n = P.nodes[ni];
         const TensorInfo& o = P.tensors[n.out];

@@ -115,7 +115,10 @@ def _check_all_nodes(cfg, st, x, bf16=False):
             cat = torch.cat(parts, 1) if len(parts) > 1 else parts[0]
             gamma = st[nd['bn'] + '.weight'].clone().requires_grad_(True)
             beta = st[nd['bn'] + '.bias'].clone().requires_grad_(True)
-            wt = st[nd['conv'] + '.weight'].clone().requires_grad_(True)
+            wt = st[nd['conv'] + '.weight'].clone()
+            if gb and nd.get('head', -1) < 0:
+                wt = wt.bfloat16().float()              # the bf16-MFMA data gradient contracts with bf16-rounded weights
+            wt.requires_grad_(True)
             y = F.conv2d(F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5)), wt, None, 1,
                          1 if nd['taps'] == 9 else 0)
             y.backward(dy)
