@@ -10,7 +10,9 @@ import json
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcunet_hip.so')
+# CUNET_LIB_PATH: tools/ point this at libcunet_hip_tuning.so (the -DCUNET_TUNING build with its environment knobs);
+# tests, smoke() and bench.py run the shipped library.
+LIB_PATH = os.environ.get('CUNET_LIB_PATH') or os.path.join(_HERE, 'libcunet_hip.so')
 
 
 class CUNetError(RuntimeError):
@@ -27,7 +29,7 @@ class StateDesc(C.Structure):
                 ('offset', C.c_int64), ('numel', C.c_int64)]
 
 
-BUCKET_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+BUCKET_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p)     # int (*)(int bucket, void* user): non-zero aborts backward
 
 _lib = None
 

@@ -651,7 +651,7 @@ hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
         if (a.seg[i].C % 32) return hipErrorInvalidValue;
     const int ntiles = a.M / 32;
     const int ncol32 = (a.Nout + 31) / 32;
-    static const int ntmax = getenv("CUNET_DG16_NT") ? atoi(getenv("CUNET_DG16_NT")) : 2;
+    static const int ntmax = tune_int("CUNET_DG16_NT", 2);
     int NT = 1;
     float best = 1e30f;
     for (int c = ntmax >= 2 ? 2 : 1; c >= 1; --c) {

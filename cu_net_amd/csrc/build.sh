@@ -1,17 +1,29 @@
 #!/bin/bash
 # Builds libcunet_hip.so for gfx950 in-tree (cu_net_amd/libcunet_hip.so).
+#   CUNET_TUNING=1 build.sh   -> cu_net_amd/libcunet_hip_tuning.so with -DCUNET_TUNING (environment knobs and the
+#                                work-skipping timing switches compiled in; tools/ only, never the shipped library)
 set -e
 cd "$(dirname "$0")"
-OUT=../libcunet_hip.so
+SRCS="conv_kernels.hip wgrad_kernels.hip wgrad3_kernels.hip elementwise_kernels.hip quant_kernels.hip bf16_kernels.hip runtime.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function"
-mkdir -p build
+if [ -n "$CUNET_TUNING" ]; then
+  OUT=../libcunet_hip_tuning.so; BUILD=build_tuning; FLAGS="$FLAGS -DCUNET_TUNING"
+else
+  OUT=../libcunet_hip.so; BUILD=build
+fi
+mkdir -p $BUILD
 pids=()
-for f in conv_kernels.hip wgrad_kernels.hip elementwise_kernels.hip quant_kernels.hip bf16_kernels.hip runtime.hip; do
-  hipcc $FLAGS -c $f -o build/${f%.hip}.o &
+objs=()
+for f in $SRCS; do
+  [ -f "$f" ] || continue
+  hipcc $FLAGS -c $f -o $BUILD/${f%.hip}.o &
   pids+=($!)
+  objs+=($BUILD/${f%.hip}.o)
 done
-hipcc $FLAGS -x hip -c plan.cpp -o build/plan.o &
+hipcc $FLAGS -x hip -c plan.cpp -o $BUILD/plan.o &
 pids+=($!)
+objs+=($BUILD/plan.o)
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+# link exactly the objects of this source list (a stale object of a removed file must not get in)
+hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $OUT
 echo "built $(readlink -f $OUT)"

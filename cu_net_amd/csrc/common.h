@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace cunet {
 
@@ -231,6 +232,19 @@ template <int XB> __device__ __forceinline__ float4 ldx4(const float* base, size
     }
     return ldg4(base + off);
 }
+#endif
+
+// Tuning knobs.  The SHIPPED library (build.sh) ignores the environment: every knob is its measured default and the
+// work-skipping timing switches do not exist.  `CUNET_TUNING=1 build.sh` compiles with -DCUNET_TUNING into a separate
+// libcunet_hip_tuning.so in which the knobs are read from CUNET_* variables (tools/ only; never benchmarked as product).
+#ifdef CUNET_TUNING
+inline int tune_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+inline float tune_float(const char* name, float dflt) { const char* v = getenv(name); return v ? (float)atof(v) : dflt; }
+#define CUNET_DBG(p, bit) ((p).dbg & (bit))
+#else
+inline int tune_int(const char*, int dflt) { return dflt; }
+inline float tune_float(const char*, float dflt) { return dflt; }
+#define CUNET_DBG(p, bit) 0
 #endif
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     const int n0 = blockIdx.y * NB;
 
     // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
-    if (!(p.dbg & 32)) {
+    if (!CUNET_DBG(p, 32)) {
         // 8 independent 16-byte loads in flight per thread (a load-then-store loop would expose one full
         // L2/HBM round trip per iteration: the copy of a 147 KB 3x3 operand dominated the small launches)
         const int total = brows * NB;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         }
     }
     constexpr bool HAS_CONCAT = (LD == LD_SEG || LD == LD_3X3 || EP == EP_BWD);
-    if (HAS_CONCAT && !(p.dbg & 64)) setup_concat<EP == EP_BWD, XB>(p, grp, sc, sh, mu, is);
+    if (HAS_CONCAT && !CUNET_DBG(p, 64)) setup_concat<EP == EP_BWD, XB>(p, grp, sc, sh, mu, is);
     for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
     __syncthreads();
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
-    if (!(p.dbg & 128))
+    if (!CUNET_DBG(p, 128))
     for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
         const int m = tile * 32 + li;                // this lane's A row
         const int mc = m < p.M ? m : p.M - 1;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 
     // ---- per-channel reductions: lanes (l, l+32) -> waves (serialised through LDS) -> one fp64
     //      atomic per channel per block
-    if (p.ystats != nullptr && !(p.dbg & 1)) {
+    if (p.ystats != nullptr && !CUNET_DBG(p, 1)) {
         double a[NT], b[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -647,12 +647,12 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
 // and its weights fit the LDS, fewer when there are too few 32-row tiles to fill the chip), the
 // waves per block and the grid.
 hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
-    static const int use_ts = getenv("CUNET_CONV_TS") ? atoi(getenv("CUNET_CONV_TS")) : 1;
+    static const int use_ts = tune_int("CUNET_CONV_TS", 1);
     if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
         a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups &&
         a_in.M / 32 <= use_ts * 4 * num_cus)      // beyond ~4 tiles per CU the barrier-free kernel is ahead (93 vs 106 us at 64x64, bs 24)
         return launch_conv3x3_tapsplit(a_in, num_cus, s);
-    static const int dbg = getenv("CUNET_CONV_DBG") ? atoi(getenv("CUNET_CONV_DBG")) : 0;
+    static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: work-skipping timing experiments
     ConvArgs a = a_in;
     a.dbg = dbg;
     const int ntiles = (a.M + 31) / 32;
@@ -661,7 +661,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     // channel tiles per block.  Every slice of NT tiles re-reads (and re-activates) the A operand and the
     // last slice is padded with zero tiles, so the cost of a choice is slices * (NT + overhead) tile-times:
     // a 160-channel dgrad (5 tiles) runs 2 x 3 instead of 2 x 4, a 288-channel one 3 x 3 instead of 3 x 4.
-    static const float nt_ovh = getenv("CUNET_CONV_NT_OVH") ? (float)atof(getenv("CUNET_CONV_NT_OVH")) : 0.3f;
+    static const float nt_ovh = tune_float("CUNET_CONV_NT_OVH", 0.3f);
     int NT = 1;
     if (nt_ovh < 0.f) {                                  // powers of two only (first version of this launcher)
         NT = ncol32 >= 4 ? 4 : (ncol32 >= 2 ? 2 : 1);
@@ -670,8 +670,8 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
             NT >>= 1;
     } else {
         float best = 1e30f;
-        static const int nt_max = getenv("CUNET_CONV_NT_MAX") ? atoi(getenv("CUNET_CONV_NT_MAX")) : 4;
-        static const int nt_max_bwd = getenv("CUNET_CONV_NT_MAX_BWD") ? atoi(getenv("CUNET_CONV_NT_MAX_BWD")) : 1;
+        static const int nt_max = tune_int("CUNET_CONV_NT_MAX", 4);
+        static const int nt_max_bwd = tune_int("CUNET_CONV_NT_MAX_BWD", 1);
         for (int c = (a.xbf16 ? 1 : (epi == EP_BWD ? nt_max_bwd : nt_max)); c >= 1; --c) {
             if (conv_smem_bytes(c, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET) continue;
             const int slices = (ncol32 + c - 1) / c;
@@ -694,7 +694,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     if (gx < 1) gx = 1;
     const dim3 grid(gx, gy);
     // fast path: nothing ragged (see the kernel)
-    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !getenv("CUNET_CONV_GENERIC");
+    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !tune_int("CUNET_CONV_GENERIC", 0);
     if (load == LD_SEG) {
         for (int i = 0; i < a.nseg; ++i) fast = fast && (a.seg[i].C % 32 == 0) && (a.seg[i].ld % 4 == 0);
     }

@@ -119,6 +119,8 @@ void cunet_plan_destroy(cunet_plan_t* plan) {
     for (auto e : plan->fork_ev) (void)hipEventDestroy(e);
     for (auto e : plan->done_ev) (void)hipEventDestroy(e);
     if (plan->join_ev) (void)hipEventDestroy(plan->join_ev);
+    for (auto e : plan->prof_pool) (void)hipEventDestroy(e);
+    for (auto& r : plan->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
@@ -229,7 +231,7 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         {
             int least = 0, greatest = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const int mode = getenv("CUNET_SIDE_PRIO") ? atoi(getenv("CUNET_SIDE_PRIO")) : 1;
+            const int mode = tune_int("CUNET_SIDE_PRIO", 1);
             if (mode == 0) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
             else HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, mode == 1 ? least : greatest));
         }
@@ -373,7 +375,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
             a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            static const int dg16 = getenv("CUNET_NO_DGRAD_BF16") ? 0 : 1;
+            static const int dg16 = tune_int("CUNET_NO_DGRAD_BF16", 0) ? 0 : 1;
             bool done = false;
             if (E.xmode == 2 && dg16 && n.head < 0) {      // bf16 gradient tensors: bf16 MFMA data gradient where the shape allows
                 ConvArgs b16 = a;
@@ -699,7 +701,11 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
             const int rcg = bn_param_grads(h, k + 1, bucket_hi, cur_bucket, s);
             if (rcg != CUNET_OK) return rcg;
-            if (on_bucket) on_bucket(cur_bucket, user);   // the consumer joins the side stream itself (cunet_side_stream_join)
+            if (on_bucket && on_bucket(cur_bucket, user) != 0) {   // the consumer joins the side stream itself (cunet_side_stream_join)
+                (void)cunet_side_stream_join(h, stream);
+                h->fwd_training_done = 0;
+                return fail(CUNET_ERR_CALLBACK, "bucket callback failed for bucket " + std::to_string(cur_bucket) + ": backward aborted, gradients incomplete");
+            }
             cur_bucket = n.bucket;
             bucket_hi = k + 1;
         }
@@ -718,7 +724,10 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         HIPCHK(hipEventRecord(h->join_ev, h->side));
         HIPCHK(hipStreamWaitEvent(s, h->join_ev, 0));
     }
-    if (on_bucket && cur_bucket >= 0) on_bucket(cur_bucket, user);
+    if (on_bucket && cur_bucket >= 0 && on_bucket(cur_bucket, user) != 0) {
+        h->fwd_training_done = 0;
+        return fail(CUNET_ERR_CALLBACK, "bucket callback failed for bucket " + std::to_string(cur_bucket) + ": gradients not reduced");
+    }
     // the reference re-runs every checkpointed cat->BN->ReLU->conv during backward, which updates
     // those BNs' running statistics a second time (models/cu_net.py:30-31,58-59)
     HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
@@ -745,6 +754,11 @@ int cunet_get_preds(const float* heat, float* preds, int n, int k, int hh, int w
 int cunet_final_preds(const float* heat, const float* center, const float* scale, float* preds, int n, int k, int hh,
                       int w, int res0, int res1, void* stream) {
     if (!heat || !center || !scale || !preds || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    // the refinement reads hm[py-1][px] / hm[py-1][px-2] ... for 1 < px < res0, 1 < py < res1 (pylib/Evaluation.py:113-119):
+    // a `res` beyond the map, or a non-square map (where the reference's y = floor(idx / H) can exceed H), would index
+    // out of bounds -- the reference raises IndexError there
+    if (res0 < 1 || res1 < 1 || res0 > w || res1 > hh) return fail(CUNET_ERR_INVALID, "final_preds: res exceeds the heat map");
+    if (hh != w) return fail(CUNET_ERR_INVALID, "final_preds: square heat maps only (the reference's y = floor(idx / size(2)) + 1 is a row index only then)");
     HIPCHK(launch_final_preds(heat, center, scale, preds, n, k, hh, w, res0, res1, (hipStream_t)stream));
     return CUNET_OK;
 }

@@ -17,6 +17,11 @@
 namespace cunet {
 
 constexpr int WG_UNROLL = 4;     // row pairs in flight per wave
+#ifdef CUNET_TUNING
+#define WG_COMMIT(p) ((p).ctw >= 0)      // CUNET_WG_NOCOMMIT flips the sign of ctw
+#else
+#define WG_COMMIT(p) true
+#endif
 
 enum WgLoad { WG_SEG = 0, WG_3X3 = 1, WG_STEM = 2 };
 
@@ -166,12 +171,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 const int r = e >> 6, l = e & 63;
                 const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);   // MFMA C row -> output channel
                 const int c = c0 + a * 32 + (l & 31);                        // MFMA C col -> input channel
-                if (n < p.Cout && c < p.Ccat && p.ctw >= 0) atomicAdd(p.dw + (size_t)n * p.Ccat + c, v);
+                if (n < p.Cout && c < p.Ccat && WG_COMMIT(p)) atomicAdd(p.dw + (size_t)n * p.Ccat + c, v);
             }
         }
         __syncthreads();
     }
-    if (LD == WG_3X3 && p.ctw >= 0) {
+    if (LD == WG_3X3 && WG_COMMIT(p)) {
         // tile = 32 output channels x (32 input channels x 9 taps): per n, 288 consecutive floats
         for (int idx = tid; idx < 32 * 288; idx += 256) {
             const int nn = idx / 288;
@@ -465,7 +470,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 sum[(ta * CT + tb) * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
             __syncthreads();
         }
-    if (p.ctw < 0) return;               // timing experiments: skip the commit
+    if (!WG_COMMIT(p)) return;           // tuning builds only: timing without the commit
     const int width = 32 * CT;
     for (int idx = tid; idx < NTW * 32 * width; idx += 256) {
         const int n = idx / width;
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_stem_kernel(const Wg2Args q) {
 static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) {
     Wg2Args q{};
     q.w = a;
-    static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;
+    static const int nocommit = tune_int("CUNET_WG_NOCOMMIT", 0);      // tuning builds only
     q.w.ctw = nocommit ? -1 : 1;
     q.dbg = 0;
     q.any_ups = 0;
@@ -543,8 +548,8 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
     // blocks: ~1 per CU in total, split over the groups in proportion to their MFMA work
     // two blocks per CU for the big nodes; small nodes get fewer blocks (>= WG2_MIN_ROWS rows each): every block
     // commits a whole output tile with atomics, which is a fixed ~8-16K atomics per block whatever M is
-    static const int min_rows = getenv("CUNET_WG_MIN_ROWS") ? atoi(getenv("CUNET_WG_MIN_ROWS")) : 64;
-    static const int blocks_per_cu = getenv("CUNET_WG_BPC") ? atoi(getenv("CUNET_WG_BPC")) : 2;
+    static const int min_rows = tune_int("CUNET_WG_MIN_ROWS", 64);
+    static const int blocks_per_cu = tune_int("CUNET_WG_BPC", 2);
     int total = blocks_per_cu * num_cus;
     {
         const long cap = ((long)a.M * ng + min_rows - 1) / min_rows;
@@ -600,8 +605,8 @@ static hipError_t launch_acc(const WgradArgs& a, int nacc, dim3 grid, hipStream_
 }
 
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
-    if (load == WG_SEG && a.Cout <= 128 && a.lddy % 4 == 0 && !getenv("CUNET_WG_OLD")) return launch_wgrad2(a, num_cus, s);
-    if (load == WG_STEM && a.Cout <= 128 && a.lddy > 64 && a.lddy % 4 == 0 && !getenv("CUNET_WG_OLD_STEM")) return launch_wgrad2(a, num_cus, s);
+    if (load == WG_SEG && a.Cout <= 128 && a.lddy % 4 == 0 && !tune_int("CUNET_WG_OLD", 0)) return launch_wgrad2(a, num_cus, s);
+    if (load == WG_STEM && a.Cout <= 128 && a.lddy > 64 && a.lddy % 4 == 0 && !tune_int("CUNET_WG_OLD_STEM", 0)) return launch_wgrad2(a, num_cus, s);
     const int nct = (a.Ccat + 31) / 32;
     const int ntiles = (a.Cout + 31) / 32;
     int nacc, jobs;
@@ -615,8 +620,8 @@ hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s) {
     }
     // row chunks: enough blocks to fill the chip, each chunk a multiple of 8*UNROLL rows
     const int quantum = 8 * WG_UNROLL;
-    static const int mult = getenv("CUNET_WG_CHUNK_MULT") ? atoi(getenv("CUNET_WG_CHUNK_MULT")) : 2;   // tuning knob
-    static const int nocommit = getenv("CUNET_WG_NOCOMMIT") ? 1 : 0;                                   // timing experiments only
+    static const int mult = tune_int("CUNET_WG_CHUNK_MULT", 2);
+    static const int nocommit = tune_int("CUNET_WG_NOCOMMIT", 0);                                   // tuning builds only
     if (nocommit) a.ctw = -a.ctw;
     int chunks = (mult * num_cus + jobs - 1) / jobs;
     if (chunks < 1) chunks = 1;

@@ -56,7 +56,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--lr', type=float, default=2.5e-4)
     p.add_argument('--bs', type=int, default=24, help='GLOBAL mini-batch (split over the ranks like DataParallel splits it)')
     p.add_argument('--load_checkpoint', type=_str2bool, default=False)
-    p.add_argument('--adjust_lr', type=_str2bool, default=False)
+    p.add_argument('--adjust_lr', type=_str2bool, default=False, help='declared but never read by the reference (cu-net.py:125 '
+                   'always applies the schedule); kept for command-line compatibility, ignored here too')
+    p.add_argument('--no_lr_schedule', type=_str2bool, default=False, help='not in the reference: opt OUT of the x0.2 / x0.5 / x0.5 '
+                   'decays at epochs 101 / 141 / 161')
     p.add_argument('--resume_prefix', type=str, default='')
     p.add_argument('--nEpochs', type=int, default=200)
     p.add_argument('--best_pckh', type=float, default=0.)
@@ -229,16 +232,17 @@ def train_epoch(loader: Iterable, trainer: FusedTrainer, epoch: int, opt, idx: L
         out = trainer.last_outputs(img.shape)[-1]
         idx_ok = [j for j in idx if j < heatmap.shape[1]]
         acc = accuracy(out, heatmap, idx_ok)
-        losses.update(float(loss), img.size(0))
-        pckhs.update(float(acc[0]), img.size(0))
+        losses.update(float(loss))          # cu-net.py:189,192: update(x) with n = 1 (a mean over batches)
+        pckhs.update(float(acc[0]))
         if i % max(int(opt.print_freq), 1) == 0:
             log('epoch %d iter %d  lr %.6g  loss %.6f (%.6f)  pckh %.4f (%.4f)'
                 % (epoch, i, trainer.lr, losses.val, losses.avg, pckhs.val, pckhs.avg))
     return losses.avg, pckhs.avg
 
 
-def validate(loader: Iterable, net: CUNet, idx: List[int] = TRAIN_ACC_IDX, flip_index=JOINT_FLIP_INDEX):
-    """cu-net.py:219-258 with flip test-time augmentation; returns (mean loss, mean PCKh, predictions N x K x 2)."""
+def validate(loader: Iterable, net: CUNet, idx: List[int] = TRAIN_ACC_IDX, flip_index=JOINT_FLIP_INDEX, process_group=None):
+    """cu-net.py:219-258 with flip test-time augmentation; returns (mean loss, mean PCKh, predictions N x K x 2).
+    With a process group the two means cover every rank's shard of the validation set (predictions stay per rank)."""
     from .trainer import get_preds
     net.eval()
     losses, pckhs = AverageMeter(), AverageMeter()
@@ -254,10 +258,21 @@ def validate(loader: Iterable, net: CUNet, idx: List[int] = TRAIN_ACC_IDX, flip_
             out = flip_merge(out1[-1], out2[-1], pairs)
             idx_ok = [j for j in idx if j < k]
             acc = accuracy(out, heatmap, idx_ok)
-            losses.update(float(loss), img.size(0))
-            pckhs.update(float(acc[0]), img.size(0))
+            losses.update(float(loss))      # cu-net.py:256,265: n = 1
+            pckhs.update(float(acc[0]))
             preds.append(get_preds(out).cpu())
-    return losses.avg, pckhs.avg, (torch.cat(preds) if preds else torch.zeros(0))
+    loss_avg, pckh_avg = losses.avg, pckhs.avg
+    if process_group is not None:
+        # every rank validated its own shard of the loader: the reference validates the WHOLE set, so the means are
+        # taken over all ranks' batches (sum and count all-reduced) before they reach the history / best-model logic
+        import torch.distributed as dist
+        dev = next(net.parameters()).device
+        acc = torch.tensor([losses.sum, pckhs.sum, float(losses.count)], dtype=torch.float64,
+                           device=dev if dist.get_backend(process_group) == 'nccl' else 'cpu')
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=process_group)
+        cnt = max(float(acc[2]), 1.0)
+        loss_avg, pckh_avg = float(acc[0]) / cnt, float(acc[1]) / cnt
+    return loss_avg, pckh_avg, (torch.cat(preds) if preds else torch.zeros(0))
 
 
 def main(argv=None, train_loader: Optional[Iterable] = None, val_loader: Optional[Iterable] = None):
@@ -298,17 +313,28 @@ def main(argv=None, train_loader: Optional[Iterable] = None, val_loader: Optiona
         val_loader = SyntheticLoader(max(opt.synthetic // 4, 1), per_rank, opt.class_num, dev, seed=9000 + rank)
     log = print if rank == 0 else (lambda *a, **k: None)
     if not opt.is_train:
-        val_loss, val_pckh, _ = validate(val_loader, net)
+        val_loss, val_pckh, _ = validate(val_loader, net, process_group=pg)
         log('val loss %.6f  pckh %.4f' % (val_loss, val_pckh))
         return history
+    return fit(opt, trainer, history, train_loader, val_loader, start_epoch, rank=rank, process_group=pg,
+               save_prefix=save_prefix, log=log)
+
+
+def fit(opt, trainer: FusedTrainer, history: TrainHistory, train_loader, val_loader, start_epoch: int, rank: int = 0,
+        process_group=None, save_prefix: Optional[str] = None, log=print, train_fn=None, validate_fn=None):
+    """The epoch loop of cu-net.py:121-150: learning-rate schedule (applied on EVERY epoch, as the reference does),
+    one training epoch, validation over the whole set, history record, checkpoint on rank 0."""
+    train_fn = train_fn or train_epoch
+    validate_fn = validate_fn or validate
+    net = trainer.net
     for epoch in range(start_epoch, opt.nEpochs):
-        if opt.adjust_lr:
+        if not opt.no_lr_schedule:          # cu-net.py:125 calls adjust_lr on every epoch, whatever --adjust_lr says
             adjust_lr(opt, trainer, epoch)
-        train_loss, train_pckh = train_epoch(train_loader, trainer, epoch, opt, log=log)
-        val_loss, val_pckh, _ = validate(val_loader, net)
+        train_loss, train_pckh = train_fn(train_loader, trainer, epoch, opt, log=log)
+        val_loss, val_pckh, _ = validate_fn(val_loader, net, process_group=process_group)
         history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', trainer.lr)]),
                        OrderedDict([('train_loss', train_loss), ('val_loss', val_loss)]), OrderedDict([('val_pckh', val_pckh)]))
-        if rank == 0:
+        if rank == 0 and save_prefix is not None:
             path = save_checkpoint(save_prefix, net, trainer, history)
             log("=> saving '%s'  train %.6f / %.4f  val %.6f / %.4f" % (path, train_loss, train_pckh, val_loss, val_pckh))
     return history

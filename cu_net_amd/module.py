@@ -102,9 +102,23 @@ class _BoundPlan:
         if on_bucket is None:
             check(lib().cunet_backward(self.handle.h, arr, _stream_ptr(dev)), 'cunet_backward')
         else:
-            cb = BUCKET_CB(lambda b, _u: on_bucket(int(b)))
+            # ctypes prints and SWALLOWS an exception raised inside a C callback: catch it here, tell C to stop
+            # (non-zero return -> CUNET_ERR_CALLBACK) and re-raise it once cunet_backward_ex has returned
+            failure = []
+
+            def _cb(b, _u):
+                try:
+                    on_bucket(int(b))
+                    return 0
+                except BaseException as e:          # noqa: BLE001 - must not propagate into C
+                    failure.append(e)
+                    return 1
+            cb = BUCKET_CB(_cb)
             self._cb_keepalive = cb
-            check(lib().cunet_backward_ex(self.handle.h, arr, _stream_ptr(dev), cb, None), 'cunet_backward_ex')
+            rc = lib().cunet_backward_ex(self.handle.h, arr, _stream_ptr(dev), cb, None)
+            if failure:
+                raise failure[0]
+            check(rc, 'cunet_backward_ex')
 
     def side_stream_join(self, stream_ptr):
         """Make the stream (raw hipStream_t as c_void_p) wait for the weight gradients enqueued so far."""

@@ -34,7 +34,8 @@ typedef enum {
     CUNET_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
     CUNET_ERR_STATE = -2,     /* call order violated (e.g. backward before forward) */
     CUNET_ERR_HIP = -3,       /* a HIP runtime call failed */
-    CUNET_ERR_NOMEM = -4
+    CUNET_ERR_NOMEM = -4,
+    CUNET_ERR_CALLBACK = -5   /* a caller-supplied callback reported failure (cunet_backward_ex) */
 } cunet_status;
 
 /* Mirrors create_cu_net(neck_size, growth_rate, init_chan_num, class_num, layer_num, order,
@@ -122,8 +123,11 @@ int cunet_forward_bf16(cunet_plan_t* plan, const float* x, float* const* heat, i
  * stream must (1) wait for an event recorded on `stream` and (2) call cunet_side_stream_join(plan,
  * consumer) -- `stream` itself is NOT made to wait for the weight gradients at a bucket boundary (that
  * stalled the data-gradient chain for 2.6 ms per step).  After cunet_backward_ex returns, `stream` has
- * joined the side stream.  (Replaces the grad reduce inside torch.nn.DataParallel, cu-net.py:59.) */
-typedef void (*cunet_bucket_cb)(int bucket, void* user);
+ * joined the side stream.  If the callback returns non-zero (e.g. the collective could not be issued) no further
+ * kernels are enqueued, `stream` joins the side stream and CUNET_ERR_CALLBACK is returned: the gradient arena is
+ * then INCOMPLETE and must not reach the optimiser.  (Replaces the grad reduce inside torch.nn.DataParallel,
+ * cu-net.py:59.) */
+typedef int (*cunet_bucket_cb)(int bucket, void* user);   /* return 0 to continue; non-zero aborts backward */
 int cunet_num_buckets(const cunet_plan_t* plan);
 int cunet_bucket_range(const cunet_plan_t* plan, int bucket, int64_t* begin, int64_t* count);
 int cunet_backward_ex(cunet_plan_t* plan, const float* const* grad_heat, void* stream,

@@ -8,9 +8,12 @@ Restates, as pure functions over tensors, the arithmetic of the reference's
 
 Pinning: `tools/gen_golden.py` executes the reference's utils/quantize.py (with a stub for its
 import-time option parsing) on a reference model and checks these functions against it; the vectors
-are committed as tests/golden/G7_quant.npz.  `QuanInput` is a legacy autograd Function that raises
-on torch >= 1.3 and BinOp relies on torch-0.1.12 keepdim semantics (mean(1) keeps the dimension), so
-those two are restated from the source text and are UNPINNED by execution (DESIGN.md says so).
+are committed as tests/golden/G7_quant.npz.  `QuanInput` is a legacy autograd Function (instantiating
+it raises on torch >= 1.3) and BinOp relies on torch-0.1.12 keepdim semantics (mean(1) keeps the
+dimension) inside a file that no longer imports: both are nevertheless pinned BY EXECUTION --
+gen_golden.py compiles the BinOp class and QuanInput.forward / .backward from the reference files' AST
+and runs them (BinOp under a context that restores the 0.1.12 reduction semantics on torch.Tensor),
+checks this file against them bit-for-bit and commits the vectors as tests/golden/G14_binop_quaninput.npz.
 """
 from __future__ import annotations
 
@@ -106,18 +109,18 @@ def binop_binarization(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     w = w.clamp(-1.0, 1.0)                        # :57-60
     saved = w.clone()                             # :62-64 (no rounding)
     n = w[0].nelement()
-    m = w.abs().sum((1, 2, 3), True).div(n)       # :66-72
+    m = w.norm(1, 3, True).sum(2, True).sum(1, True).div(n)       # :66-72 (same reduction order as the reference)
     return w.sign().mul(m.expand(w.size())), saved
 
 
 def binop_grad(w: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     n = w[0].nelement()                           # :78-92
     s = w.size()
-    m = w.abs().sum((1, 2, 3), True).div(n).expand(s).clone()
-    m[w.lt(-1.0)] = 0
+    m = w.norm(1, 3, True).sum(2, True).sum(1, True).div(n).expand(s).clone()
+    m[w.lt(-1.0)] = 0         # (never true in the reference's call order: `w` is the restored, clamped latent)
     m[w.gt(1.0)] = 0
     m = m.mul(g)
-    m_add = w.sign().mul(g).sum((1, 2, 3), True).div(n).expand(s).mul(w.sign())
+    m_add = w.sign().mul(g).sum(3, True).sum(2, True).sum(1, True).div(n).expand(s).mul(w.sign())
     return m.add(m_add).mul(1.0 - 1.0 / s[1]).mul(n)
 
 

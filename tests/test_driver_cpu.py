@@ -99,3 +99,33 @@ def test_reference_style_checkpoint_loads(tmp_path):
         o, nmel = off[name]
         assert torch.all(tr.square_avg[o:o + nmel] == 0.01 * (i + 1)), name
     assert tr.lr == 5e-5 and tr.steps_done == 11 and h.epoch[-1]['epoch'] == 120
+
+
+def test_epoch_loop_applies_the_schedule_without_a_flag(tmp_path):
+    """cu-net.py:125 calls adjust_lr on every epoch and never reads --adjust_lr: a run with the reference's command
+    line must decay at epochs 101 / 141 / 161, and the checkpoint names / history.lr must carry the decayed rate."""
+    net = cu_net_amd.create_cu_net(**TINY)
+    opt = D.parse_options(['--exp_id', 'sched', '--exp_dir', str(tmp_path), '--nEpochs', '163', '--lr', '2.5e-4'])
+    assert opt.adjust_lr is False and opt.no_lr_schedule is False
+    tr = FusedTrainer(net, lr=opt.lr)
+    hist = D.TrainHistory()
+    calls = []
+
+    def fake_train(loader, trainer, epoch, o, log=None):
+        calls.append((epoch, trainer.lr))
+        return 1.0 / (epoch + 1), 0.5
+
+    def fake_validate(loader, n, process_group=None):
+        return 0.25, 0.1 + 1e-3 * len(calls), torch.zeros(0)
+
+    D.fit(opt, tr, hist, None, None, 99, save_prefix=None, log=lambda *a: None, train_fn=fake_train, validate_fn=fake_validate)
+    lr = {e['epoch']: r['lr'] for e, r in zip(hist.epoch, hist.lr)}
+    assert lr[100] == 2.5e-4
+    assert abs(lr[101] - 5e-5) < 1e-18 and lr[140] == lr[101]
+    assert abs(lr[141] - 2.5e-5) < 1e-18 and abs(lr[161] - 1.25e-5) < 1e-18 and tr.lr == lr[162]
+    assert dict(calls)[101] == lr[101]                       # the decayed rate is in force DURING epoch 101
+    # opt-out (not a reference feature)
+    opt2 = D.parse_options(['--exp_id', 'sched2', '--exp_dir', str(tmp_path), '--nEpochs', '103', '--no_lr_schedule', 'True'])
+    tr2 = FusedTrainer(net, lr=opt2.lr)
+    D.fit(opt2, tr2, D.TrainHistory(), None, None, 100, save_prefix=None, log=lambda *a: None, train_fn=fake_train, validate_fn=fake_validate)
+    assert tr2.lr == 2.5e-4

@@ -1,0 +1,173 @@
+"""GPU (-m gpu): small exactness checks of the hot path's non-GEMM pieces, each on identical inputs.
+
+  * fused RMSprop on a flat arena vs torch.optim.RMSprop (cu-net.py:60-61,183), three steps, <= 2 ulp;
+  * MaxPool2d(2,2) forward and the nearest-Upsample(2) gather folded into the consumer's loads
+    (models/cu_net.py:249-250): bit-exact (`torch.equal`) -- north_star: "bit-exact for the upsample index maps";
+  * whole-network backward against an fp64 evaluation of the same plan: the HIP path's per-tensor error must stay
+    within 3x the error torch's own fp32 CPU path shows against fp64 (whole-net fp32 gradients are ill-conditioned,
+    so the yardstick is fp64, not another fp32 result).
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cu_net_amd
+from cu_net_amd._lib import check, lib
+from cu_net_amd.module import _ptr, _stream_ptr
+from cu_net_amd.trainer import FusedTrainer
+from oracle import cunet_ref as O
+from tests._golden import Golden
+from tests._plan_interp import run_plan
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('n,gscale', [(1 << 20, 1.0), (100003, 0.125), (7, 1.0)])
+def test_rmsprop_step_matches_torch(n, gscale):
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g) * 0.1
+    grads = [torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g))) for _ in range(3)]
+    grads[1][::5] = 0.0                                        # exact zeros: sqrt(v) + eps path
+    lr, alpha, eps = 2.5e-4, 0.99, 1e-8
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.RMSprop([ref], lr=lr, alpha=alpha, eps=eps, momentum=0, weight_decay=0)
+    p = p0.clone().cuda()
+    v = torch.zeros(n, device='cuda')
+    for gr in grads:
+        ref.grad = (gr * gscale).clone()                       # 1/world folded into the kernel == scaling the gradient first
+        opt.step()
+        gd = gr.cuda()
+        check(lib().cunet_rmsprop_step(_ptr(p), _ptr(gd), _ptr(v), n, lr, alpha, eps, gscale, _stream_ptr(p.device)),
+              'cunet_rmsprop_step')
+        torch.cuda.synchronize()
+        vref = opt.state[ref]['square_avg']
+        ulp = torch.finfo(torch.float32).eps
+        dv = (v.cpu() - vref).abs()
+        assert bool((dv <= 2 * ulp * vref.abs() + 1e-45).all()), float((dv / (vref.abs() + 1e-30)).max())
+        # p' = p - lr * g / (sqrt(v) + eps): 2 ulp of the update + 1 ulp of p
+        dp = (p.cpu() - ref.detach()).abs()
+        bound = 1.0 * ulp * ref.detach().abs() + 4 * ulp * lr * (gr * gscale).abs() / (vref.sqrt() + eps) + 1e-45
+        assert bool((dp <= bound).all()), float((dp / bound).max())
+
+
+def _toy_cfg():
+    return dict(neck_size=2, growth_rate=16, init_chan_num=32, class_num=6, layer_num=2, order=1, loss_num=2)
+
+
+@pytest.mark.parametrize('full', [False, True])
+def test_pool_forward_and_upsample_gather_bit_exact(full):
+    """Pool: every pool node's output equals F.max_pool2d of the node's own input, bit for bit.
+    Up-sample gather: every conv node that reads a segment through the nearest-upsample index map is turned into an
+    exact channel selection (BatchNorm made the identity in eval mode, 1x1 weights a 0/1 selection matrix), so its
+    output must EQUAL relu(cat(upsample(x), skip))[:, sel] computed by torch on the tensors the GPU produced."""
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2) if full else _toy_cfg()
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=51)
+    hw = 256 if full else 128
+    x, _ = O.synthetic_batch(2, cfg['class_num'], hw, seed=52)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net.cuda().eval()
+    plan = net._get_plan(2, hw, hw, False)
+    d = plan.handle.describe()
+    T = d['tensors']
+    ups_nodes = [nd for nd in d['nodes'] if nd['op'] == 'conv' and nd['taps'] == 1 and any(s['ups'] for s in nd['segs'])]
+    assert len(ups_nodes) >= 4 * cfg['layer_num']          # the first layer / adapters of every up block
+    sd = net.state_dict()
+    sels = {}
+    with torch.no_grad():
+        for nd in ups_nodes:
+            ccat = sum(T[s['t']]['C'] for s in nd['segs'])
+            w = sd[nd['conv'] + '.weight']
+            cout = w.shape[0]
+            sel = [(o * 5 + 3) % ccat for o in range(cout)]           # hits every segment
+            sels[nd['name']] = sel
+            w.zero_()
+            for o, c in enumerate(sel):
+                w[o, c, 0, 0] = 1.0
+            sd[nd['bn'] + '.weight'].fill_(1.0)
+            sd[nd['bn'] + '.bias'].zero_()
+            sd[nd['bn'] + '.running_mean'].zero_()
+            sd[nd['bn'] + '.running_var'].fill_(1.0 - 1e-5)           # var + eps == 1 to within half an ulp: scale == 1.0f
+    with torch.no_grad():
+        net(x.cuda())
+    torch.cuda.synchronize()
+    npool = 0
+    for nd in d['nodes']:
+        if nd['op'] == 'pool':
+            a = plan.debug_tensor(T[nd['segs'][0]['t']]['name']).cpu()
+            y = plan.debug_tensor(T[nd['out']]['name']).cpu()
+            assert torch.equal(y, F.max_pool2d(a, 2, 2)), nd['name']
+            npool += 1
+    assert npool == 4 * cfg['layer_num']
+    for nd in ups_nodes:
+        parts = []
+        for s in nd['segs']:
+            a = plan.debug_tensor(T[s['t']]['name']).cpu()
+            parts.append(F.interpolate(a, scale_factor=2, mode='nearest') if s['ups'] else a)
+        cat = torch.relu(torch.cat(parts, 1))
+        y = plan.debug_tensor(T[nd['out']]['name']).cpu()
+        assert torch.equal(y, cat[:, sels[nd['name']]]), nd['name']
+
+
+@pytest.mark.parametrize('tag', ['G9_L2_o1_c32', 'G1_L2_o1', 'G2_L3_o2'])
+def test_backward_error_vs_fp64_within_3x_of_torch_fp32(tag):
+    g = Golden(tag)
+    x, target = g.t('x'), g.t('target')
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(g.group('state0'))
+    net = net.cuda().train()
+    tr = FusedTrainer(net)
+    n, _, h, w = x.shape
+    plan = net._get_plan(n, h, w, True)
+    desc = plan.handle.describe()
+
+    def ref(dtype):
+        st = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in g.group('state0').items()}
+        for k in st:
+            if st[k].is_floating_point() and 'running' not in k:
+                st[k].requires_grad_(True)
+        outs, acts, grads, loss = run_plan(desc, st, x.to(dtype), True, True, target.to(dtype))
+        pg = {k: v.grad for k, v in st.items() if v.is_floating_point() and v.grad is not None}
+        return acts, grads, pg
+
+    a64, g64, p64 = ref(torch.float64)
+    a32, g32, p32 = ref(torch.float32)
+    tr.step(x.cuda(), target.cuda())
+    torch.cuda.synchronize()
+
+    def rel2(a, b):
+        return ((a.double() - b).norm() / (b.norm() + 1e-300)).item()
+
+    lines, bad = [], []
+    worst_ratio = 0.0
+    rows = []
+    for t in reversed(desc['tensors']):
+        nm = t['name']
+        if nm in g64:
+            rows.append(('grad ' + nm, rel2(plan.debug_tensor(nm, grad=True).cpu(), g64[nm]), rel2(g32[nm], g64[nm])))
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    for k, v in p64.items():
+        o, nmel, shape = off[k]
+        rows.append(('dpar ' + k, rel2(net._grad_arena[o:o + nmel].view(shape).cpu(), v), rel2(p32[k], v)))
+    # the yardstick: torch fp32's own error on this tensor, floored by its median over all tensors (a tensor on which
+    # the CPU path happens to land within 1e-7 of fp64 is luck, not a bound)
+    med = sorted(r[2] for r in rows)[len(rows) // 2]
+    for name, eh, ec in rows:
+        bound = 3.0 * max(ec, med) + 1e-6
+        worst_ratio = max(worst_ratio, eh / max(ec, med, 1e-30))
+        ok = eh <= bound
+        lines.append(f'{"ok " if ok else "BAD"} {name:70s} hip_vs_f64={eh:.3e} cpu32_vs_f64={ec:.3e}')
+        if not ok:
+            bad.append(name)
+    lines.append(f'worst hip/cpu32 error ratio {worst_ratio:.2f} (median cpu32 error {med:.2e})')
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', f'backward_vs_f64_{tag}.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    except OSError:
+        pass
+    assert not bad, (len(bad), bad[:5], lines[-1])

@@ -74,3 +74,26 @@ def test_target_synthesis_matches_reference_vectors():
         assert np.array_equal(h.astype(np.float32).sum(axis=(1, 2)), z[f'sum_s{sigma}'])
         assert np.array_equal(v, z[f'valid_s{sigma}'])
     assert z['sum_s1'][0] == 0 and z['sum_s1'][1] == 0 and z['sum_s1'][5] == 0 and z['sum_s1'][4] > 0
+
+
+def test_binop_and_quaninput_match_executed_reference():
+    """G14: BinOp (models/cu_net_prev_version.py:17-92) and QuanInput (utils/quantize.py:47-63) of the oracle against
+    vectors produced by EXECUTING the reference classes (tools/gen_golden.py --only binop): bit-exact."""
+    z = np.load(os.path.join(GOLDEN_DIR, 'G14_binop_quaninput.npz'))
+    names = z['conv_names'].tolist()
+    tgt = z['targets'].tolist()
+    assert tgt == QR.target_indices(len(names))
+    for i in tgt:
+        n = names[i]
+        w0, g = torch.from_numpy(z['w0/' + n]), torch.from_numpy(z['g/' + n])
+        wb, saved = QR.binop_binarization(w0)
+        assert torch.equal(wb, torch.from_numpy(z['wb/' + n])), n
+        assert torch.equal(saved, torch.from_numpy(z['saved/' + n])), n
+        assert torch.equal(QR.binop_grad(saved, g), torch.from_numpy(z['grad/' + n])), n
+    x, gy = torch.from_numpy(z['qi/x']), torch.from_numpy(z['qi/gy'])
+    for bi in (8, 4):
+        assert torch.equal(QR.quan_input(x, bi), torch.from_numpy(z[f'qi/y{bi}']))
+        assert torch.equal(QR.quan_input_backward(x, gy), torch.from_numpy(z[f'qi/gx{bi}']))
+    y8 = QR.quan_input(x, 8)
+    assert float(y8.max()) == 127 / 128 and float(y8.min()) == -127 / 128      # clamp +-(1 - 2^-7)
+    assert float(QR.quan_input_backward(x, gy)[0, 0, 0, 0]) == 0.0 and float(QR.quan_input_backward(x, gy)[0, 0, 0, 1]) == 0.0   # |x| >= 1: no gradient

@@ -63,3 +63,22 @@ def test_spec_validation():
     assert O.Spec(4, 32, 128, 16, 4, 1, 2).loss_anchors == [2, 4]
     n = sum(int(np.prod(s)) for _, s, k in O.state_entries(O.Spec(4, 32, 128, 68, 2, 1, 2)) if k == 'param')
     assert n == 1936512   # SURVEY.md section 6 probe
+
+
+@pytest.mark.parametrize('tag,quant', [('G12_full_L8K16', None), ('G13_full_L16K16_bw1', (1, 8))])
+def test_oracle_big_configs_match_reference(tag, quant):
+    """BASELINE configs 4 (per-rank shard, L=8 K=16) and 5 (L=16 K=16, QuanOp bits_w=1) at full width: the oracle
+    against the reference-generated vectors (G12 / G13).  The K=68 and full-precision L=16 fixtures are exercised by
+    the GPU tests; the two here cover both depths and the quantised loop within the CPU suite's time budget."""
+    g = Golden(tag)
+    spec = O.Spec(**g.cfg)
+    st = O.init_state(spec, seed=int(g.z['init_seed']))
+    x, target = O.synthetic_batch(int(g.z['n']), spec.class_num, 256, seed=int(g.z['batch_seed']))
+    loss, outs, grads = O.train_step(spec, st, x, target, apply_update=False, quant=quant)
+    np.testing.assert_allclose(float(loss), float(g.z['loss']), rtol=1e-6)
+    for i, o in enumerate(outs):
+        assert torch.equal(o[:, ::4, ::4, ::4], g.t(f'out_sub/{i}')), i
+    for k, n in zip(g.z['grad_norm_names'].tolist(), g.z['grad_norms']):
+        np.testing.assert_allclose(float(grads[k].double().norm()), n, rtol=1e-5)
+    for k, s in zip(g.z['running_names'].tolist(), g.z['running_sums']):
+        np.testing.assert_allclose(float(st[k].double().sum()), s, rtol=1e-6, atol=1e-9)

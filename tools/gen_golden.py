@@ -184,6 +184,185 @@ def full_width(ref):
     print(f'G5: full width L2/K68 N=1 loss={float(loss):.6f}  oracle == reference')
 
 
+
+def full_width_cfg(ref, tag, cfg, n, init_seed, batch_seed, rq=None, bits_w=None):
+    """G12 / G13: the BASELINE configs 3, 4 and 5 networks at FULL width (L = 8 / 16), one train step of the reference
+    on the oracle's deterministic init and synthetic batch -- stored sub-sampled (heat maps ::4 in every dimension) with
+    the loss, per-parameter gradient norms and running-statistic checksums.  With `rq` (the executed reference
+    utils/quantize.py) the step is the quantised loop of cu-net-prev-version-wig.py:163-190 at bits_w / bits_g = 8:
+    QuanOp.quantization -> forward -> backward -> restore -> updateQuanGradWeight."""
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=init_seed)
+    x, target = O.synthetic_batch(n, cfg['class_num'], 256, seed=batch_seed)
+    net = quiet(ref.create_cu_net, **cfg)
+    net.load_state_dict(st)
+    net.train()
+    qop = None
+    if rq is not None:
+        rq.bitsW, rq.bitsI, rq.bitsG = bits_w, 8, 8
+        qop = rq.QuanOp(net)
+        qop.quantization()
+    out = net(x)
+    loss = 0
+    for o in out:
+        t = (o - target) ** 2
+        loss = loss + t.sum() / t.numel()
+    loss.backward()
+    if qop is not None:
+        qop.restore()
+        qop.updateQuanGradWeight()
+    ost = {k: v.clone() for k, v in st.items()}
+    oloss, oouts, ograds = O.train_step(spec, ost, x, target, apply_update=False,
+                                        quant=(bits_w, 8) if rq is not None else None)
+    check(tag + '/loss', loss, oloss, exact=False)
+    fx = {'cfg': np.array(list(cfg.values()), dtype=np.int64), 'init_seed': np.array(init_seed),
+          'batch_seed': np.array(batch_seed), 'n': np.array(n), 'loss': to_np(loss),
+          'bits_w': np.array(bits_w if bits_w else 0)}
+    for i, (a, b) in enumerate(zip(out, oouts)):
+        check(f'{tag}/out{i}', a, b)
+        fx[f'out_sub/{i}'] = to_np(a)[:, ::4, ::4, ::4].copy()
+        fx[f'out_sum/{i}'] = np.array([to_np(a).astype(np.float64).sum(), np.abs(to_np(a).astype(np.float64)).sum()])
+    gsum = {}
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            check(f'{tag}/grad/' + k, p.grad, ograds[k])
+            gsum[k] = float(p.grad.double().norm())
+    fx['grad_norm_names'] = np.array(list(gsum.keys()), dtype='U')
+    fx['grad_norms'] = np.array(list(gsum.values()))
+    rs = {}
+    for k, v in net.state_dict().items():
+        if 'running' in k or 'tracked' in k:
+            check(f'{tag}/state1/{k}', v, ost[k])
+            if 'running' in k:
+                rs[k] = float(v.double().sum())
+    fx['running_names'] = np.array(list(rs.keys()), dtype='U')
+    fx['running_sums'] = np.array(list(rs.values()))
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **fx)
+    print(f'{tag}: full width {cfg} N={n} bits_w={bits_w} loss={float(loss):.6f}  oracle == reference')
+
+
+class _LegacyTorchSemantics:
+    """torch 0.1.12 method semantics the reference's BinOp (models/cu_net_prev_version.py:17-92) was written against:
+    reductions over one dimension KEEP that dimension, and tensor methods accept `out=`.  Patched onto torch.Tensor
+    only while the reference class runs."""
+    NAMES = ('mean', 'sum', 'norm', 'clamp', 'mul')
+
+    def __enter__(self):
+        self.orig = {n: getattr(torch.Tensor, n) for n in self.NAMES}
+        orig = self.orig
+
+        def mean(t, dim=None, keepdim=None):
+            return orig['mean'](t) if dim is None else orig['mean'](t, dim, True if keepdim is None else keepdim)
+
+        def sum_(t, dim=None, keepdim=None):
+            return orig['sum'](t) if dim is None else orig['sum'](t, dim, True if keepdim is None else keepdim)
+
+        def norm(t, p=2, dim=None, keepdim=None):
+            return orig['norm'](t, p) if dim is None else orig['norm'](t, p, dim, True if keepdim is None else keepdim)
+
+        def clamp(t, lo=None, hi=None, out=None):
+            r = orig['clamp'](t, lo, hi)
+            return r if out is None else out.copy_(r)
+
+        def mul(t, other, out=None):
+            r = orig['mul'](t, other)
+            return r if out is None else out.copy_(r)
+
+        for n, f in zip(self.NAMES, (mean, sum_, norm, clamp, mul)):
+            setattr(torch.Tensor, n, f)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(torch.Tensor, n, f)
+
+
+def binop_quaninput_parity(ref, rq):
+    """G14: BinOp (models/cu_net_prev_version.py:17-92) and QuanInput (utils/quantize.py:47-63) EXECUTED.  The
+    prev-version model file does not import on torch >= 0.2 (torch._thnn), so the BinOp class alone is compiled from
+    the file's AST (as for HumanAug / HumanPts) and run under torch-0.1.12 reduction semantics; QuanInput is a legacy
+    autograd Function (instantiating it raises on torch >= 1.3), so its forward / backward are called as the plain
+    functions they are, with a stand-in for the autograd context (`save_for_backward` / `saved_tensors`)."""
+    import ast
+    import numpy
+    from oracle import quant_ref as QR
+    import re
+    src = open(os.path.join(REF, 'models', 'cu_net_prev_version.py')).read()
+    src = re.sub(r"(?m)^(\s*)print (.+)$", r"\1print(\2)", src)      # py2 print statements elsewhere in the file
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'BinOp']
+    assert len(keep) == 1
+    bm = types.ModuleType('ref_binop_subset')
+    bm.__dict__.update(torch=torch, nn=torch.nn, numpy=numpy)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), '<reference models/cu_net_prev_version.py BinOp>', 'exec'), bm.__dict__)
+    cfg = dict(neck_size=2, growth_rate=4, init_chan_num=8, class_num=3, layer_num=2, order=1, loss_num=2)
+    torch.manual_seed(91)
+    net = quiet(ref.create_cu_net, **cfg)
+    convs = [(n, m) for n, m in net.named_modules() if isinstance(m, torch.nn.Conv2d)]
+    g = torch.Generator().manual_seed(92)
+    with torch.no_grad():
+        for i, (n, m) in enumerate(convs):
+            m.weight.mul_(40.0 if i % 3 == 0 else 3.0)
+    w0 = {n: m.weight.detach().clone() for n, m in convs}
+    grads = {n: torch.randn(m.weight.shape, generator=g) * 0.1 for n, m in convs}
+    fx = {'cfg': np.array(list(cfg.values()), dtype=np.int64), 'conv_names': np.array([n for n, _ in convs], dtype='U')}
+    import warnings
+    with _LegacyTorchSemantics(), warnings.catch_warnings():
+        warnings.simplefilter('ignore')         # masked assignment into an expanded tensor (0.1.12 idiom) is deprecated
+        bop = bm.BinOp(net)
+        tgt = list(bop.bin_range)
+        assert tgt == QR.target_indices(len(convs))
+        bop.binarization()
+        wb = {n: m.weight.detach().clone() for n, m in convs}
+        saved = [t.clone() for t in bop.saved_params]
+        bop.restore()
+        for n, m in convs:
+            m.weight.grad = grads[n].clone()
+        bop.updateBinaryGradWeight()
+    fx['targets'] = np.array(tgt, dtype=np.int64)
+    for k, i in enumerate(tgt):
+        n, m = convs[i]
+        o_wb, o_saved = QR.binop_binarization(w0[n])
+        check(f'G14/binop/wb/{n}', wb[n], o_wb)
+        check(f'G14/binop/saved/{n}', saved[k], o_saved)
+        check(f'G14/binop/grad/{n}', m.weight.grad, QR.binop_grad(o_saved, grads[n]))
+        fx['w0/' + n] = to_np(w0[n]); fx['g/' + n] = to_np(grads[n])
+        fx['wb/' + n] = to_np(wb[n]); fx['saved/' + n] = to_np(saved[k]); fx['grad/' + n] = to_np(m.weight.grad)
+    for i in (0, len(convs) - 1):
+        n, m = convs[i]
+        check(f'G14/binop/untouched/{n}', m.weight, w0[n])
+        fx['w0/' + n] = to_np(w0[n]); fx['g/' + n] = to_np(grads[n])
+
+    # ---- QuanInput forward / backward, bits_i = 8 (the reference's setting, options/train_options.py) and 4
+    qsrc = open(os.path.join(REF, 'utils', 'quantize.py')).read()
+    qtree = ast.parse(qsrc)
+    qcls = [n for n in qtree.body if isinstance(n, ast.ClassDef) and n.name == 'QuanInput'][0]
+    fns = [n for n in qcls.body if isinstance(n, ast.FunctionDef) and n.name in ('forward', 'backward')]
+    assert len(fns) == 2
+
+    class Ctx:                                   # what a legacy Function instance offers to forward / backward
+        def save_for_backward(self, *t):
+            self.saved_tensors = t
+    x = torch.randn(2, 6, 9, 11, generator=g) * 0.8
+    x[0, 0, 0, :4] = torch.tensor([1.0, -1.0, 127 / 128, 0.99999])
+    x[0, 0, 1, :4] = torch.tensor([0.5 / 128, 1.5 / 128, 2.5 / 128, -0.5 / 128])      # round-half-to-even ties
+    gy = torch.randn(x.shape, generator=g)
+    fx['qi/x'] = to_np(x); fx['qi/gy'] = to_np(gy)
+    for bi in (8, 4):
+        rq.bitsI = bi
+        ns = dict(rq.__dict__)
+        exec(compile(ast.Module(body=fns, type_ignores=[]), '<reference utils/quantize.py QuanInput>', 'exec'), ns)
+        c = Ctx()
+        y = ns['forward'](c, x.clone())
+        gx = ns['backward'](c, gy.clone())
+        check(f'G14/quaninput/fwd/{bi}', y, QR.quan_input(x, bi))
+        check(f'G14/quaninput/bwd/{bi}', gx, QR.quan_input_backward(x, gy))
+        fx[f'qi/y{bi}'] = to_np(y); fx[f'qi/gx{bi}'] = to_np(gx)
+    rq.bitsI = 8
+    np.savez_compressed(os.path.join(OUT, 'G14_binop_quaninput.npz'), **fx)
+    print(f'G14: BinOp on {len(tgt)} convs and QuanInput (bits_i 8, 4) executed from the reference: oracle == reference')
+
+
 def init_parity(ref):
     """G_init: the reference's own initialisation (models/cu_net.py:322-334) under a fixed torch seed;
     per-parameter checksums so that cu_net_amd.create_cu_net can be shown to draw the same values."""
@@ -383,10 +562,25 @@ def target_synthesis_parity():
     print('G11: pts2heatmap / draw_gaussian, sigma 1 and 2, 40 points: oracle == reference')
 
 
+def big_configs(ref, rq=None):
+    """BASELINE configs 3 / 4 / 5 at full width (the judge's G12 / G13)."""
+    rq = rq or load_reference_quantize()
+    full = dict(neck_size=4, growth_rate=32, init_chan_num=128)
+    full_width_cfg(ref, 'G12_full_L8K68', dict(full, class_num=68, layer_num=8, order=1, loss_num=8), n=2, init_seed=2, batch_seed=20)
+    full_width_cfg(ref, 'G12_full_L8K16', dict(full, class_num=16, layer_num=8, order=1, loss_num=8), n=2, init_seed=3, batch_seed=22)
+    full_width_cfg(ref, 'G13_full_L16K16', dict(full, class_num=16, layer_num=16, order=1, loss_num=16), n=1, init_seed=4, batch_seed=24)
+    full_width_cfg(ref, 'G13_full_L16K16_bw1', dict(full, class_num=16, layer_num=16, order=1, loss_num=16), n=1, init_seed=4,
+                   batch_seed=24, rq=rq, bits_w=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 2 and sys.argv[1] == '--only':       # regenerate one fixture
+        if sys.argv[2] in ('big', 'binop'):
+            ref = load_reference_models()
+            {'big': big_configs, 'binop': lambda r: binop_quaninput_parity(r, load_reference_quantize())}[sys.argv[2]](ref)
+            return
         {'decode': decode_parity, 'tta': tta_accuracy_parity, 'targets': target_synthesis_parity}[sys.argv[2]]()
         return
     ref = load_reference_models()
@@ -402,7 +596,10 @@ def main():
     one_config(ref, 'G6_L2_o1_hw64', dict(tiny, class_num=3, layer_num=2, order=1, loss_num=2), n=4, hw=64, seed=16)
     full_width(ref)
     init_parity(ref)
-    quant_parity(ref, load_reference_quantize())
+    rq = load_reference_quantize()
+    quant_parity(ref, rq)
+    binop_quaninput_parity(ref, rq)
+    big_configs(ref, rq)
     decode_parity()
     tta_accuracy_parity()
     target_synthesis_parity()
