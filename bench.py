@@ -12,14 +12,19 @@ Workload at N=1 is BASELINE.json configs[1]: L=2, order=1, loss_num=2, bs=24, 25
 fp32, synthetic MPII/300-W-shaped input (U[0,1) images, one 7x7 Gaussian blob per landmark), random
 reference-scheme init.  Weak scaling: every rank processes its own 24 images.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel class (chosen from a profiled
-warm-up step): achieved = algorithmic FLOPs of its launches / their HIP-event time measured inside
-the timed region on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/cunet_ref.py, a
-restatement of the reference pinned bit-exact to it) on this host for a bounded sample.
+Rank 0 prints ONE JSON line.  `value` / `ms_per_step` are the wall clock of exactly K steps between barriers
+(the driver's contract); `ms_per_step_median` is the median of the K per-step times taken from events on the
+stream.  `roofline` describes the dominant kernel class (chosen from a profiled warm-up step):
+achieved = algorithmic FLOPs of its launches / their HIP-event time measured inside the timed region on the
+launch stream.  `cpu_baseline` times the CPU oracle (oracle/cunet_ref.py, a restatement of the reference pinned
+bit-exact to it) on this host for a bounded sample.  At N=1 the same run also times the other single-GPU
+headline configurations of BASELINE.json -- config 3 (CU-Net-8, bf16 storage) and config 5 (CU-Net-16, binary
+weights) -- and attaches them as `also: [...]` (BASELINE's metric names "CU-Net-2 and CU-Net-8").
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,10 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
-# algorithmic train-step GFLOP per image, conv MACs x2 only, no credit for recompute
+# algorithmic GFLOP per image, conv MACs x2 only, no credit for recompute
 TRAIN_GFLOP_PER_IMG = {(2, 68): 16.252, (8, 68): 65.731, (8, 16): 64.422, (16, 16): 129.086}
 FWD_GFLOP_PER_IMG = {(2, 68): 5.623, (8, 68): 22.116, (8, 16): 21.680, (16, 16): 43.234}
+# algorithmic forward bytes per image at perfect per-node fusion, fp32 (bf16: half); train step = 3x
+FWD_MB_PER_IMG_F32 = {(2, 68): 110.4, (8, 68): 443.5, (8, 16): 436.7, (16, 16): 873.9}
 
 
 def log(*a):
@@ -75,22 +83,181 @@ def cpu_baseline(layers, class_num, steps):
                       f'(fwd+MSE+bwd+RMSprop) after 1 warm-up, torch CPU {torch.__version__}'}
 
 
+def load_traffic(cls, workload_key):
+    """HBM bytes per launch of a kernel class from the newest committed PMC passes of THIS workload
+    (rocprofv3 --pmc cannot run inside this process): profiles/rNN_traffic.json, produced by tools/profile_round.sh +
+    tools/pmc_traffic.py.  Returns (bytes or None, source string)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        if tj.get('workload', '2,68,24,f32') != workload_key:
+            continue
+        ent = tj.get('classes', {}).get(cls)
+        if ent:
+            return ent['hbm_bytes_per_launch'], (f'{os.path.basename(path)} (FETCH_SIZE x2 + WRITE_SIZE per launch; '
+                                                 f'separate rocprofv3 --pmc passes at commit {tj.get("commit", "r01")}, not this run)')
+    return None, None
+
+
+def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0, forward_only=False, popcount=False,
+            profile_out='', seed=2):
+    """Time `steps` steps of one workload.  mode: 'fp32' | 'bf16' (activations) | 'bf16_grads' (+ gradient tensors)."""
+    import cu_net_amd
+    from cu_net_amd.trainer import FusedTrainer
+    bf16 = mode != 'fp32'
+    torch.manual_seed(seed)
+    net = cu_net_amd.create_cu_net(neck_size=4, growth_rate=32, init_chan_num=128, class_num=K,
+                                   layer_num=L, order=1, loss_num=L).to(dev)
+    net.train()
+    quan = None
+    if bits_w > 0:
+        from cu_net_amd.quant import QuanOp
+        quan = QuanOp(net, bits_w=bits_w, bits_i=8, bits_g=8)
+    kw = {}
+    if popcount:
+        kw['popcount'] = True
+    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=bf16,
+                      bf16_grads=mode == 'bf16_grads', **kw)
+    tr.broadcast_parameters(0)
+    x, t = synthetic_batch(bs, K, 256, seed=1000 + rank, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if pg is not None:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if forward_only:
+        net.eval()
+
+        def one_step():
+            with torch.no_grad():
+                outs = net.forward_bf16(x) if bf16 else net(x)      # the public path: loss_num NCHW heat maps
+            return outs[-1][0, 0, 0, 0]
+    else:
+        def one_step():
+            return tr.step(x, t)
+    plan = net._get_plan(bs, 256, 256, not forward_only, bf16=bf16)
+    # ---- warm-up; the last warm-up step is profiled per kernel class to pick the dominant one
+    for i in range(max(warmup, 1)):
+        if i == max(warmup, 1) - 1:
+            plan.handle.profile_reset()
+            plan.handle.profile_begin(1)
+        loss = one_step()
+    torch.cuda.synchronize(dev)
+    prof_all = plan.handle.profile_collect()
+    plan.handle.profile_begin(0)
+    have_classes = any(v[0] for v in prof_all.values())
+    dominant = max(prof_all.items(), key=lambda kv: kv[1][1])[0]
+    if rank == 0 and have_classes:
+        tot = sum(v[1] for v in prof_all.values())
+        lines = [f'per-class profile of one warm-up step, CU-Net-{L} K={K} {mode} bits_w={bits_w} (sum of kernel times {tot:.3f} ms):']
+        for name, (cnt, ms, fl, by) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
+            if cnt:
+                lines.append(f'  {name:22s} launches={cnt:4d} ms={ms:8.3f} ({100 * ms / tot:5.1f}%) '
+                             f'TFLOP/s={fl / ms / 1e9 if ms else 0:7.2f} GB/s={by / ms / 1e6 if ms else 0:8.1f}')
+        log('\n'.join(lines))
+        if profile_out:
+            with open(profile_out, 'a') as f:
+                f.write('\n'.join(lines) + '\n')
+
+    # ---- timed region: exactly `steps` steps; HIP events only around the dominant class, one event per step
+    plan.handle.profile_reset()
+    plan.handle.profile_begin(2, plan.handle.profile_class_index(dominant))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        loss = one_step()
+        evs[i + 1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = plan.handle.profile_collect()
+    plan.handle.profile_begin(0)
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    if pg is not None:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    res = {'dt': dt, 'final_loss': float(loss), 'per_step_ms': per_step}
+    imgs = world * bs * steps
+    value = imgs / dt
+    res['value'] = value
+    res['ms_per_step'] = 1e3 * dt / steps
+    res['ms_per_step_median'] = statistics.median(per_step)
+    cnt, ms, fl, by = prof[dominant]
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS if dominant.endswith('_bf16') else PEAK_F32_MFMA_TFLOPS      # classes that run on bf16 MFMA carry the suffix
+    roof = None
+    if have_classes and ms > 0:
+        if fl > 0:
+            achieved = fl / (ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 3), 'peak': peak_mfma,
+                    'unit': 'TFLOP/s', 'frac': round(achieved / peak_mfma, 4), 'traffic': None,
+                    'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2),
+                    'achieved_algorithmic_GBs': round(by / (ms * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        else:
+            achieved = by / (ms * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS,
+                    'unit': 'GB/s', 'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
+                    'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
+        tb, src = load_traffic(dominant, f'{L},{K},{bs},{"f32" if not bf16 else mode}')
+        if tb is not None:
+            roof['traffic'] = tb
+            roof['traffic_source'] = src
+            roof['algorithmic_bytes_per_launch'] = round(by / max(cnt, 1))
+    res['roofline'] = roof
+    g = (FWD_GFLOP_PER_IMG if forward_only else TRAIN_GFLOP_PER_IMG).get((L, K))
+    if g:
+        res['step_tflops'] = round(g * value / 1e3, 2)
+        if bf16:
+            res['step_frac_of_bf16_mfma_peak'] = round(g * value / 1e3 / (PEAK_BF16_MFMA_TFLOPS * world), 4)
+        else:
+            res['step_frac_of_f32_mfma_peak'] = round(g * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)
+    fb = FWD_MB_PER_IMG_F32.get((L, K))
+    if fb:      # whole-step algorithmic bytes (SURVEY 8d: B_train = 3 x B_fwd; bf16 storage halves them) against the HBM peak
+        mb = fb * (0.5 if bf16 else 1.0) * (1.0 if forward_only else 3.0)
+        res['step_algorithmic_GBs'] = round(mb * value / 1e3, 1)
+        res['step_frac_of_hbm_peak'] = round(mb * value / 1e3 / (PEAK_HBM_GBS * world), 4)
+    del tr, net, plan
+    torch.cuda.empty_cache()
+    return res
+
+
+def workload_name(L, K, bs, mode, bits_w, forward_only, world, popcount=False):
+    return (f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
+            + (f'QuanOp bits_w={bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if bits_w > 0 else '')
+            + ('AND-popcount forward convs, ' if popcount else '')
+            + (('bf16-storage' if mode != 'fp32' else 'fp32') + ' eval-mode forward only' if forward_only else
+               {'fp32': 'fp32', 'bf16': 'bf16-activation', 'bf16_grads': 'bf16 activation + gradient tensors'}[mode]
+               + ' train step (fwd + MSE + bwd + RMSprop')
+            + ('' if forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--class-num', type=int, default=68)
     ap.add_argument('--bs', type=int, default=24, help='per-GPU batch')
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the extra CU-Net-8 bf16 / CU-Net-16 binary-weight lines')
+    ap.add_argument('--also-steps', type=int, default=20)
     ap.add_argument('--profile-out', default='')
     ap.add_argument('--forward-only', action='store_true', help='inference: eval-mode forward (running statistics), no loss / backward')
     ap.add_argument('--bf16', action='store_true', help='bf16 activation storage + bf16 MFMA forward (train step: gradients, weights, optimiser stay fp32; '
                     'with --forward-only: bf16-storage inference)')
     ap.add_argument('--bf16-grads', action='store_true', help='with --bf16: the gradient tensors of backward (dY, dz, dX) stored as bf16 too')
     ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
+    ap.add_argument('--popcount', action='store_true', help='with --bits-w 1/2: forward convs of the quantised layers on the AND-popcount kernel')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -103,152 +270,71 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
+    ranks_seen = 1
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run even one rank goes through RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                    # what RCCL itself saw: every rank contributes 1
+        ranks_seen = int(one.item())
 
     import cu_net_amd
-    from cu_net_amd.trainer import FusedTrainer
-
     L, K, bs = args.layers, args.class_num, args.bs
-    torch.manual_seed(2)
-    net = cu_net_amd.create_cu_net(neck_size=4, growth_rate=32, init_chan_num=128, class_num=K,
-                                   layer_num=L, order=1, loss_num=L).to(dev)
-    net.train()
-    quan = None
-    if args.bits_w > 0:
-        from cu_net_amd.quant import QuanOp
-        quan = QuanOp(net, bits_w=args.bits_w, bits_i=8, bits_g=8)
-    tr = FusedTrainer(net, lr=2.5e-4, alpha=0.99, eps=1e-8, process_group=pg, quan_op=quan, bf16=args.bf16 or args.bf16_grads, bf16_grads=args.bf16_grads)
-    tr.broadcast_parameters(0)
-    x, t = synthetic_batch(bs, K, 256, seed=1000 + rank, device=dev)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if pg is not None:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    if args.forward_only:
-        net.eval()
-
-        def one_step():
-            with torch.no_grad():
-                outs = net.forward_bf16(x) if args.bf16 else net(x)      # the public path: loss_num NCHW heat maps
-            return outs[-1][0, 0, 0, 0]
-    else:
-        def one_step():
-            return tr.step(x, t)
-    args.bf16 = args.bf16 or args.bf16_grads
-    plan = net._get_plan(bs, 256, 256, not args.forward_only, bf16=args.bf16)
-    # ---- warm-up; one of the warm-up steps is profiled per kernel class to pick the dominant one
-    for i in range(max(args.warmup, 1)):
-        if i == max(args.warmup, 1) - 1:
-            plan.handle.profile_reset()
-            plan.handle.profile_begin(1)
-        loss = one_step()
-    torch.cuda.synchronize(dev)
-    prof_all = plan.handle.profile_collect()
-    plan.handle.profile_begin(0)
-    have_classes = any(v[0] for v in prof_all.values())       # the bf16 path is not instrumented per class
-    dominant = max(prof_all.items(), key=lambda kv: kv[1][1])[0]
+    mode = 'bf16_grads' if args.bf16_grads else ('bf16' if args.bf16 else 'fp32')
+    is_default = (L, K, bs, mode, args.bits_w, args.forward_only, args.popcount) == (2, 68, 24, 'fp32', 0, False, False)
+    r = measure(dev, pg, rank, world, L, K, bs, args.steps, args.warmup, mode, args.bits_w, args.forward_only,
+                args.popcount, args.profile_out)
     if rank == 0:
-        tot = sum(v[1] for v in prof_all.values())
-        log(f'per-class profile of one warm-up step (sum of kernel times {tot:.3f} ms):')
-        lines = []
-        for name, (cnt, ms, fl, by) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
-            if cnt:
-                lines.append(f'  {name:22s} launches={cnt:4d} ms={ms:8.3f} ({100 * ms / tot:5.1f}%) '
-                             f'TFLOP/s={fl / ms / 1e9 if ms else 0:7.2f} GB/s={by / ms / 1e6 if ms else 0:8.1f}')
-        log('\n'.join(lines))
-        if args.profile_out:
-            with open(args.profile_out, 'w') as f:
-                f.write('\n'.join(lines) + '\n')
-
-    # ---- timed region: exactly K steps, events only around the dominant class
-    plan.handle.profile_reset()
-    plan.handle.profile_begin(2, plan.handle.profile_class_index(dominant))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = plan.handle.profile_collect()
-    plan.handle.profile_begin(0)
-    if pg is not None:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    final_loss = float(loss)
-
-    if rank == 0:
-        imgs = world * bs * args.steps
-        value = imgs / dt
-        cnt, ms, fl, by = prof[dominant]
-        mfma_bound = fl > 0
-        roof = None
-        if not have_classes or ms <= 0:
-            pass
-        elif mfma_bound:
-            achieved = fl / (ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
-        else:
-            achieved = by / (ms * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS,
-                    'unit': 'GB/s', 'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
-                    'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
-        if not have_classes and args.forward_only:      # bf16 inference: whole-forward algorithmic bytes (bf16 forward is HBM-bound) against HBM peak
-            fb = {(2, 68): 55.2e6, (8, 68): 221.7e6, (8, 16): 218.3e6, (16, 16): 437.0e6}.get((L, K))
-            ach = (fb * value / 1e9) if fb else 0.0
-            roof = {'bound': 'hbm', 'kernel': 'whole forward (conv inputs + outputs once, bf16)', 'achieved': round(ach, 1),
-                    'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
-        # HBM bytes per launch of that kernel class from the committed PMC passes (rocprofv3 --pmc cannot run inside
-        # this process): profiles/r01_traffic.json, produced by tools/profile_round.sh + tools/pmc_traffic.py on
-        # this workload.  null when the file has no entry for the class or the workload is not the profiled one.
-        try:
-            if (L, K, bs) == (2, 68, 24) and have_classes:
-                tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')))
-                ent = tj['classes'].get(dominant)
-                if ent:
-                    roof['traffic'] = ent['hbm_bytes_per_launch']
-                    roof['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)'
-                    roof['algorithmic_bytes_per_launch'] = round(by / max(cnt, 1))
-        except Exception:
-            pass
         out = {
             'metric': ('images/sec inference forward' if args.forward_only else 'images/sec train step')
                       + ', 256x256x3 -> 64x64xK heatmaps, CU-Net-%d' % L,
-            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
-                                   + (f'QuanOp bits_w={args.bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if args.bits_w > 0 else '')
-                                   + (('bf16-storage' if args.bf16 else 'fp32') + ' eval-mode forward only' if args.forward_only else
-                                      ('bf16 activation + gradient tensors' if args.bf16_grads else 'bf16-activation' if args.bf16 else 'fp32') + ' train step (fwd + MSE + bwd + RMSprop')
-                                   + ('' if args.forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')),
+            'value': round(r['value'], 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(r['ms_per_step'], 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if mode != 'fp32' else 'f32', 'data': 'synthetic',
+            'config': {'workload': workload_name(L, K, bs, mode, args.bits_w, args.forward_only, world, args.popcount),
                        'global_batch': world * bs, 'parallelism': f'dp{world}'},
-            'roofline': roof,
-            'final_loss': final_loss,
+            'ms_per_step_median': round(r['ms_per_step_median'], 3),
+            'value_at_median': round(bs * world / r['ms_per_step_median'] * 1e3, 2),
+            'ranks_seen_by_rccl': ranks_seen,
+            'library': cu_net_amd._lib.lib().cunet_version().decode(),
+            'roofline': r['roofline'],
+            'final_loss': r['final_loss'],
         }
-        g = (FWD_GFLOP_PER_IMG if args.forward_only else TRAIN_GFLOP_PER_IMG).get((L, K))
-        if g:
-            out['step_tflops'] = round(g * value / 1e3, 2)
-            if args.bf16:
-                out['step_frac_of_bf16_mfma_peak'] = round(g * value / 1e3 / (2500.0 * world), 4)      # dense bf16 MFMA ~2.5 PFLOP/s
-            else:
-                out['step_frac_of_f32_mfma_peak'] = round(g * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)
+        for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
+            if k in r:
+                out[k] = r[k]
+    # ---- the other single-GPU headline configurations (BASELINE.json configs[2] and configs[4]), N=1 only
+    if world == 1 and is_default and not args.no_also:
+        also = []
+        extra = [(8, 68, 'bf16_grads', 0, False), (16, 16, 'fp32', 1, False)]
+        try:
+            from cu_net_amd import trainer as _T
+            import inspect
+            if 'popcount' in inspect.signature(_T.FusedTrainer.__init__).parameters:
+                extra.append((16, 16, 'fp32', 1, True))
+        except Exception:
+            pass
+        for (l2, k2, m2, bw, pc) in extra:
+            try:
+                e = measure(dev, None, 0, 1, l2, k2, bs, args.also_steps, max(3, args.warmup), m2, bw, False, pc, args.profile_out)
+                ent = {'workload': workload_name(l2, k2, bs, m2, bw, False, 1, pc), 'value': round(e['value'], 2), 'unit': 'images/sec',
+                       'steps': args.also_steps, 'ms_per_step': round(e['ms_per_step'], 3), 'ms_per_step_median': round(e['ms_per_step_median'], 3),
+                       'dtype': 'bf16' if m2 != 'fp32' else 'f32', 'roofline': e['roofline'], 'final_loss': e['final_loss']}
+                for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
+                    if k in e:
+                        ent[k] = e[k]
+                also.append(ent)
+            except Exception as ex:      # an extra line must never take the headline measurement down
+                also.append({'workload': workload_name(l2, k2, bs, m2, bw, False, 1, pc), 'error': repr(ex)})
+        out['also'] = also
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out['cpu_baseline'] = cpu_baseline(L, K, args.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

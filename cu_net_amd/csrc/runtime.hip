@@ -11,7 +11,7 @@
 #include "plan.h"
 
 enum { PC_C1F = 0, PC_C3F, PC_STEMF, PC_C1D, PC_C3D, PC_C1W, PC_C3W, PC_STEMW, PC_APPLY, PC_POOLF, PC_POOLB,
-       PC_STEMBPF, PC_STEMBPB, PC_MISC, CUNET_PROF_NCLS };
+       PC_STEMBPF, PC_STEMBPB, PC_MISC, PC_C1F16, PC_C3F16, PC_C1D16, PC_C3D16, PC_C1W16, CUNET_PROF_NCLS };
 
 using namespace cunet;
 
@@ -55,7 +55,9 @@ struct cunet_plan {
 static const char* kProfNames[CUNET_PROF_NCLS] = {
     "conv1x1_fwd", "conv3x3_fwd", "stem_conv_fwd", "conv1x1_bwd_data", "conv3x3_bwd_data", "conv1x1_bwd_weight",
     "conv3x3_bwd_weight", "stem_bwd_weight", "bn_bwd_apply", "pool_fwd", "pool_bwd", "stem_bnpool_fwd",
-    "stem_bnpool_bwd", "misc"};
+    "stem_bnpool_bwd", "misc",
+    // the same node classes when they run on bf16 MFMA (bf16 storage modes): priced against the bf16 peak
+    "conv1x1_fwd_bf16", "conv3x3_fwd_bf16", "conv1x1_bwd_data_bf16", "conv3x3_bwd_data_bf16", "conv1x1_bwd_weight_bf16"};
 
 static hipError_t prof_begin(cunet_plan* h, int cls, hipStream_t s, int& slot) {
     slot = -1;
@@ -381,7 +383,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
                 ConvArgs b16 = a;
                 b16.wB = reinterpret_cast<const float*>(E.a16 + c.wB);
                 int slot_;
-                HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3D : PC_C1D, s, slot_));
+                HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3D16 : PC_C1D16, s, slot_));
                 const hipError_t e = launch_dgrad_bf16(b16, cus, s);
                 if (e == hipSuccess) {
                     HIPCHK(prof_end(h, slot_, 2.0 * a.M * a.K * a.Nout * a.taps, 2.0 * (double)a.M * (a.K + 2.0 * a.Nout), s));
@@ -597,10 +599,13 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
             a.ldy = o.ld; a.Nout = c.Cout; a.ystats = (training && !is_head) ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            int slot_;
+            HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3F16 : PC_C1F16, s, slot_));
             hipError_t e = launch_conv_bf16(a, is_head, cus, s);
             if (e == hipErrorInvalidValue)
                 return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 32 and rows of 32 (node " + n.name + ")");
             HIPCHK(e);
+            HIPCHK(prof_end(h, slot_, 2.0 * a.M * a.K * a.Nout * a.taps, 2.0 * (double)a.M * (a.K + a.Nout), s));
         }
     }
     if (training)

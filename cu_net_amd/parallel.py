@@ -29,6 +29,8 @@ class BucketAllReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if process_group is not None else 1
         self.overlap = overlap
+        # gloo on GPU tensors (two ranks sharing one device in tests/test_gpu_dp.py): the bucket is staged through the host
+        self._host_staged = process_group is not None and dist.get_backend(process_group) == 'gloo'
         self._stream = None
         self.reduced: List[int] = []        # bucket ids in the order they were reduced (tests)
 
@@ -54,11 +56,21 @@ class BucketAllReducer:
             if join_side is not None:
                 join_side(ctypes.c_void_p(self._stream.cuda_stream))
             with torch.cuda.stream(self._stream):
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+                if self._host_staged:
+                    h = g.to('cpu')                      # (synchronises the communication stream)
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+                    g.copy_(h)
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
         else:
             if join_side is not None and flat.is_cuda:
                 join_side(ctypes.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream))
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            if self._host_staged and flat.is_cuda:
+                h = g.to('cpu')
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+                g.copy_(h)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self, flat: torch.Tensor):
         """Make the current stream wait for every outstanding bucket reduction."""
@@ -79,8 +91,14 @@ def broadcast_state(tensors: Sequence[torch.Tensor], src: int = 0, process_group
     """One-time replacement of DataParallel's per-iteration replicate."""
     if process_group is None:
         return
+    staged = dist.get_backend(process_group) == 'gloo'
     for t in tensors:
-        dist.broadcast(t, src, group=process_group)
+        if staged and t.is_cuda:
+            h = t.to('cpu')
+            dist.broadcast(h, src, group=process_group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src, group=process_group)
 
 
 def shard_batch(global_batch: int, rank: int, world: int) -> Tuple[int, int]:

@@ -1,0 +1,130 @@
+"""GPU (-m gpu): the data-parallel step (cu-net.py:59 torch.nn.DataParallel -> one process per GPU + bucketed
+all-reduce) with TWO ranks launched by torch.distributed.run.
+
+With >= 2 GPUs each rank owns one and the buckets go over RCCL; on a one-GPU box both ranks share cuda:0 and the
+buckets go over gloo (host-staged) -- everything else (per-rank BatchNorm statistics, cunet_backward_ex bucket
+callbacks in backward's completion order, side-stream joins, 1/world folded into the fused RMSprop) is the same code.
+
+Checks: (1) the one-time broadcast made rank 1 start from rank 0's parameters; (2) both ranks end with IDENTICAL
+gradient arenas and parameters; (3) the all-reduced arena equals g_A + g_B where g_A, g_B are the HIP path's own
+single-process gradients of the two shards (1e-5: the weight-gradient atomics are order-dependent in the last bits);
+(4) the parameters equal RMSprop(p0, (g_A + g_B) / 2); (5) each rank's loss equals the oracle's loss on its shard, and
+the reduced arena equals the oracle's summed shard gradients at the whole-network sanity bound; (6) buckets were
+reduced in the order cunet_bucket_order promises."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(neck_size=2, growth_rate=16, init_chan_num=32, class_num=6, layer_num=3, order=1, loss_num=3)
+GLOBAL_BATCH, HW = 4, 128
+
+
+def make_inputs():
+    g = torch.Generator().manual_seed(62)
+    x = torch.rand(GLOBAL_BATCH, 3, HW, HW, generator=g)
+    t = torch.rand(GLOBAL_BATCH, CFG['class_num'], HW // 4, HW // 4, generator=g) * 0.3
+    return x, t
+
+
+def test_two_rank_step_equals_mean_of_shard_gradients(tmp_path):
+    import cu_net_amd
+    from cu_net_amd.parallel import shard_batch
+    from cu_net_amd.trainer import FusedTrainer
+    from oracle import cunet_ref as O
+    env = dict(os.environ)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    port = 29700 + os.getpid() % 1500
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', '_dp_worker.py'), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [torch.load(os.path.join(str(tmp_path), f'rank{i}.pt')) for i in range(2)]
+    spec = O.Spec(**CFG)
+    st = O.init_state(spec, seed=61)
+    x, t = make_inputs()
+    # (1) broadcast
+    ref_net = cu_net_amd.create_cu_net(**CFG)
+    ref_net.load_state_dict(st)
+    assert torch.equal(ranks[1]['p0'], ranks[0]['p0']) and torch.equal(ranks[0]['p0'], ref_net._param_arena)
+    # (2) replicas agree
+    assert torch.equal(ranks[0]['grads'], ranks[1]['grads'])
+    assert torch.equal(ranks[0]['params'], ranks[1]['params'])
+    assert ranks[0]['ranks_seen'] == 2
+    # (6) bucket order
+    for rk in ranks:
+        assert rk['reduced'] == rk['order'] == list(range(CFG['layer_num'] - 1, -1, -1)) + [CFG['layer_num']]
+    # single-process shard gradients on the HIP path
+    gs, losses = [], []
+    for i in range(2):
+        lo, hi = shard_batch(GLOBAL_BATCH, i, 2)
+        net = cu_net_amd.create_cu_net(**CFG)
+        net.load_state_dict(st)
+        net = net.cuda().train()
+        tr = FusedTrainer(net)
+        losses.append(float(tr.step(x[lo:hi].cuda(), t[lo:hi].cuda())))
+        torch.cuda.synchronize()
+        gs.append(net._grad_arena.detach().cpu().clone())
+        if i == 0:                                                   # rank 0's BatchNorm running statistics are ITS shard's
+            assert torch.allclose(ranks[0]['buffers'], net._buffer_arena.cpu(), rtol=1e-5, atol=1e-6)
+    gsum = gs[0] + gs[1]
+    scale = float(gsum.abs().max())
+    # (3)
+    assert float((ranks[0]['grads'] - gsum).abs().max()) <= 1e-5 * scale, float((ranks[0]['grads'] - gsum).abs().max()) / scale
+    # (4) RMSprop on the averaged gradient (first step: v = (1 - alpha) g^2)
+    g = ranks[0]['grads'] * 0.5
+    v = 0.01 * g * g
+    expect = ranks[0]['p0'] - 2.5e-4 * g / (v.sqrt() + 1e-8)
+    assert float((ranks[0]['params'] - expect).abs().max()) <= 2e-6
+    # (5) the oracle on each shard
+    off = {name: (o, n, shape) for name, kind, shape, o, n in ref_net._entries if kind == 0}
+    osum = torch.zeros_like(gsum)
+    for i in range(2):
+        lo, hi = shard_batch(GLOBAL_BATCH, i, 2)
+        ol, _, og = O.train_step(spec, {k: v.clone() for k, v in st.items()}, x[lo:hi], t[lo:hi], apply_update=False)
+        assert abs(ranks[i]['loss'] - float(ol)) <= 2e-3 * abs(float(ol)), (i, ranks[i]['loss'], float(ol))
+        assert abs(losses[i] - ranks[i]['loss']) <= 1e-6 * abs(losses[i])
+        for k, gr in og.items():
+            if gr is not None:
+                o, n, shape = off[k]
+                osum[o:o + n] += gr.reshape(-1)
+    rel2 = float((ranks[0]['grads'] - osum).double().norm() / osum.double().norm())
+    assert rel2 <= 0.2, rel2
+
+
+def test_failing_bucket_callback_aborts_the_step():
+    """A collective that cannot be issued (an exception inside the bucket callback, which C calls) must surface as that
+    exception and must NOT reach the optimiser (ctypes would print and swallow it)."""
+    import cu_net_amd
+    from cu_net_amd.trainer import FusedTrainer
+    from oracle import cunet_ref as O
+    spec = O.Spec(**CFG)
+    net = cu_net_amd.create_cu_net(**CFG)
+    net.load_state_dict(O.init_state(spec, seed=3))
+    net = net.cuda().train()
+    x, t = make_inputs()
+    plan = net._get_plan(2, HW, HW, True)
+    plan.forward(x[:2].cuda(), True, want_outputs=False)
+    plan.loss_mse(t[:2].cuda())
+    p0 = net._param_arena.clone()
+    calls = []
+
+    def boom(b):
+        calls.append(b)
+        if len(calls) == 2:
+            raise RuntimeError('simulated RCCL failure')
+    with pytest.raises(RuntimeError, match='simulated RCCL failure'):
+        plan.backward(None, on_bucket=boom)
+    torch.cuda.synchronize()
+    assert len(calls) == 2                                  # backward stopped at the failing bucket
+    assert torch.equal(net._param_arena, p0)
+    with pytest.raises(cu_net_amd.CUNetError):              # the aborted backward consumed the forward
+        plan.backward(None)
+    # and the plan is usable again
+    tr = FusedTrainer(net)
+    assert torch.isfinite(tr.step(x[:2].cuda(), t[:2].cuda()))

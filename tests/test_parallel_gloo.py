@@ -1,6 +1,8 @@
 """CPU, world_size 2 over gloo: the data-parallel plumbing (bucket layout from the C plan, per-bucket
 all-reduce in backward's completion order, one-time state broadcast, 1/world scaling, batch sharding).
-The kernels themselves need a GPU; here the per-rank gradients come from the CPU oracle."""
+The kernels themselves need a GPU (tests/test_gpu_dp.py runs the same two-rank step on the HIP path); here
+`test_two_rank_bucket_allreduce_gloo` moves seeded random arenas through the bucket plumbing and
+`test_two_rank_step_equals_dataparallel_semantics` feeds it per-rank gradients computed by the CPU oracle."""
 import os
 
 import pytest
@@ -93,6 +95,78 @@ def test_two_rank_bucket_allreduce_gloo():
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def _dp_worker(rank, world, port, q):
+    """Each rank: oracle gradient of ITS shard (own BatchNorm statistics, loss = mean over the local elements), laid
+    out in the C plan's flat arena, summed bucket by bucket, scaled by 1/world as the fused RMSprop does.  Rank 0 also
+    evaluates torch.nn.DataParallel's semantics directly (cu-net.py:59,171-182: replicas forward their chunks with
+    per-replica BatchNorm, the gathered outputs enter ONE loss over the global batch) and compares."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import cunet_ref as O
+        torch.set_num_threads(2)
+        plan, ents, buckets, numel, order = _layout()
+        spec = O.Spec(**CFG)
+        st = O.init_state(spec, seed=5)
+        gen = torch.Generator().manual_seed(6)
+        gb = 4
+        x = torch.rand(gb, 3, 128, 128, generator=gen)
+        tgt = torch.rand(gb, CFG['class_num'], 32, 32, generator=gen)
+        lo, hi = shard_batch(gb, rank, world)
+        _, _, grads = O.train_step(spec, {k: v.clone() for k, v in st.items()}, x[lo:hi], tgt[lo:hi], apply_update=False)
+        off = {name: (o, n, shape) for name, kind, shape, o, n in ents if kind == 0}
+        arena = torch.zeros(numel)
+        for k, g in grads.items():
+            if g is not None:
+                o, n, shape = off[k]
+                arena[o:o + n] = g.reshape(-1)
+        red = BucketAllReducer(buckets, dist.group.WORLD, overlap=True)
+        red.begin_step()
+        for b in order:
+            red.reduce_bucket(arena, b)
+        red.finish(arena)
+        arena.mul_(1.0 / red.world)
+        if rank == 0:
+            state = {k: v.clone() for k, v in st.items()}
+            names = O.param_names(spec)
+            for n in names:
+                state[n].requires_grad_(True)
+            outs = []
+            for r in range(world):                       # replicas: per-replica BatchNorm statistics
+                a, b = shard_batch(gb, r, world)
+                outs.append(O.forward(spec, state, x[a:b], True))
+            gathered = [torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))]
+            O.mse_loss(gathered, tgt).backward()          # one loss over the global batch
+            worst = 0.0
+            for n in names:
+                if state[n].grad is None:
+                    continue
+                o, cnt, shape = off[n]
+                ref = state[n].grad.reshape(-1)
+                worst = max(worst, float((arena[o:o + cnt] - ref).abs().max() / (ref.abs().max() + 1e-12)))
+            assert worst < 2e-5, worst
+        q.put((rank, 'ok'))
+    except Exception as e:   # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_dataparallel_semantics():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
