@@ -68,7 +68,7 @@ def lib():
         'cunet_backward_ex': (i32, [vp, C.POINTER(vp), vp, BUCKET_CB, vp]),
         'cunet_side_stream_join': (i32, [vp, vp]),
         'cunet_forward_bf16': (i32, [vp, vp, C.POINTER(vp), i32, vp]),
-        'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
+        'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
         'cunet_final_preds': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'cunet_flip_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -608,8 +608,10 @@ hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, flo
 // ---------------------------------------------------------------------------------------------
 // Fused RMSprop over the flat arena (torch.optim.RMSprop, momentum 0, centered False; cu-net.py:60-61):
 //   v = alpha*v + (1-alpha)*g*g ;  p -= lr * g / (sqrt(v) + eps)
+// torch's op order (torch/optim/rmsprop.py: v.mul_(alpha).addcmul_(g, g, value=1-alpha); p.addcdiv_(g, sqrt(v)+eps, value=-lr)),
+// each operation rounded separately (no fma contraction), `oma` = (float)(1 - alpha) formed in double on the host.
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                      float* __restrict__ v, long n, float lr, float alpha,
+                                                      float* __restrict__ v, long n, float lr, float alpha, float oma,
                                                       float eps, float gscale) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -617,32 +619,32 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, con
         float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
-        vv.x = alpha * vv.x + (1.f - alpha) * gg.x * gg.x;
-        vv.y = alpha * vv.y + (1.f - alpha) * gg.y * gg.y;
-        vv.z = alpha * vv.z + (1.f - alpha) * gg.z * gg.z;
-        vv.w = alpha * vv.w + (1.f - alpha) * gg.w * gg.w;
-        pp.x -= lr * gg.x / (sqrtf(vv.x) + eps);
-        pp.y -= lr * gg.y / (sqrtf(vv.y) + eps);
-        pp.z -= lr * gg.z / (sqrtf(vv.z) + eps);
-        pp.w -= lr * gg.w / (sqrtf(vv.w) + eps);
+        vv.x = __fadd_rn(__fmul_rn(alpha, vv.x), __fmul_rn(__fmul_rn(oma, gg.x), gg.x));
+        vv.y = __fadd_rn(__fmul_rn(alpha, vv.y), __fmul_rn(__fmul_rn(oma, gg.y), gg.y));
+        vv.z = __fadd_rn(__fmul_rn(alpha, vv.z), __fmul_rn(__fmul_rn(oma, gg.z), gg.z));
+        vv.w = __fadd_rn(__fmul_rn(alpha, vv.w), __fmul_rn(__fmul_rn(oma, gg.w), gg.w));
+        pp.x = __fadd_rn(pp.x, -__fmul_rn(lr, __fdiv_rn(gg.x, __fadd_rn(__fsqrt_rn(vv.x), eps))));
+        pp.y = __fadd_rn(pp.y, -__fmul_rn(lr, __fdiv_rn(gg.y, __fadd_rn(__fsqrt_rn(vv.y), eps))));
+        pp.z = __fadd_rn(pp.z, -__fmul_rn(lr, __fdiv_rn(gg.z, __fadd_rn(__fsqrt_rn(vv.z), eps))));
+        pp.w = __fadd_rn(pp.w, -__fmul_rn(lr, __fdiv_rn(gg.w, __fadd_rn(__fsqrt_rn(vv.w), eps))));
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(v)[i] = vv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = (n4 << 2) + threadIdx.x;
         const float gg = g[i] * gscale;
-        const float vv = alpha * v[i] + (1.f - alpha) * gg * gg;
+        const float vv = __fadd_rn(__fmul_rn(alpha, v[i]), __fmul_rn(__fmul_rn(oma, gg), gg));
         v[i] = vv;
-        p[i] -= lr * gg / (sqrtf(vv) + eps);
+        p[i] = __fadd_rn(p[i], -__fmul_rn(lr, __fdiv_rn(gg, __fadd_rn(__fsqrt_rn(vv), eps))));
     }
 }
 
-hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
+hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float oma, float eps,
                           float gscale, hipStream_t s) {
     long gx = (n / 4 + 255) / 256;
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)gx), dim3(256), 0, s, p, g, v, n, lr, alpha, eps, gscale);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)gx), dim3(256), 0, s, p, g, v, n, lr, alpha, oma, eps, gscale);
     return hipGetLastError();
 }
 

@@ -20,7 +20,7 @@ hipError_t launch_loss_finalize(const double* acc, float* loss, hipStream_t s);
 hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* stats_base, float* buffers,
                                  int64_t* counters, int mode, hipStream_t s);
 hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, float* ws, hipStream_t s);
-hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float eps,
+hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, float alpha, float one_minus_alpha, float eps,
                           float gscale, hipStream_t s);
 hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long rows, int C, int num_cus, hipStream_t s);
 hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, int with_backward, hipStream_t s);

@@ -741,12 +741,12 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     return CUNET_OK;
 }
 
-int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n, float lr, float alpha,
-                       float eps, float grad_scale, void* stream) {
+int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n, double lr, double alpha,
+                       double eps, double grad_scale, void* stream) {
     if (!params || !grads || !square_avg || n < 0) return fail(CUNET_ERR_INVALID, "null argument");
     if (((uintptr_t)params & 15) || ((uintptr_t)grads & 15) || ((uintptr_t)square_avg & 15))
         return fail(CUNET_ERR_INVALID, "arenas must be 16-byte aligned");
-    HIPCHK(launch_rmsprop(params, grads, square_avg, (long)n, lr, alpha, eps, grad_scale, (hipStream_t)stream));
+    HIPCHK(launch_rmsprop(params, grads, square_avg, (long)n, (float)lr, (float)alpha, (float)(1.0 - alpha), (float)eps, (float)grad_scale, (hipStream_t)stream));
     return CUNET_OK;
 }
 

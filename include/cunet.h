@@ -138,9 +138,11 @@ int cunet_side_stream_join(cunet_plan_t* plan, void* stream);
 int cunet_bucket_order(const cunet_plan_t* plan, int32_t* order, int capacity);
 
 /* fused RMSprop over a flat arena: torch.optim.RMSprop(lr, alpha, eps, momentum=0, weight_decay=0)
- * (cu-net.py:60-61,183). g is multiplied by grad_scale first (1/world_size under data parallelism). */
+ * (cu-net.py:60-61,183). g is multiplied by grad_scale first (1/world_size under data parallelism).
+ * Hyper-parameters are doubles, as torch receives them (python floats): 1 - alpha is formed in double before it is
+ * rounded to fp32 -- (float)(1 - 0.99) and 1.f - 0.99f differ by 9e-7 relative, which would be a systematic bias of v. */
 int cunet_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n,
-                       float lr, float alpha, float eps, float grad_scale, void* stream);
+                       double lr, double alpha, double eps, double grad_scale, void* stream);
 
 /* argmax landmark decode: replaces pylib/Evaluation.py:6-23 get_preds.
  *   heat : N x K x H x W fp32 NCHW; preds: N x K x 2 fp32 (1-based x, y; 0,0 where max <= 0) */

@@ -159,3 +159,82 @@ def _check_all_nodes(cfg, st, x, bf16=False):
             torch.cuda.synchronize()
             _close(f'{nd["name"]} dW', pgrad(nd['conv'] + '.weight'), wt.grad, bad)
     assert not bad, f'{len(bad)} mismatches:\n' + '\n'.join(bad[:40])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Composition of the whole backward, exact: after ONE real backward pass every tensor's gradient must equal the sum of
+# the contributions of ALL its consumer nodes, each differentiated by torch from the GPU's own d(loss)/d(output) of
+# that consumer and the GPU's own activations.  Unlike a whole-network comparison with a CPU run this does not chain
+# rounding through the (chaotic) network, so it keeps the per-kernel tolerance while covering what the node tests do
+# not: the per-tensor consumer lists (order-K FIFO, skip connections, intermedia carries), the 4-child sums behind
+# the up-sample maps, pool routing, and that no contribution is dropped or counted twice.
+def _check_composition(cfg, st, x, target):
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    n, _, h, w = x.shape
+    plan = net._get_plan(n, h, w, True)
+    plan.forward(x.cuda(), True, want_outputs=False)
+    plan.loss_mse(target.cuda())
+    plan.backward(None)
+    torch.cuda.synchronize()
+    desc = plan.handle.describe()
+    T = desc['tensors']
+    acts = {t['name']: plan.debug_tensor(t['name']).cpu() for t in T}
+    produced = {T[nd['out']]['name'] for nd in desc['nodes']}
+    grads = {nm: plan.debug_tensor(nm, grad=True).cpu() for nm in produced}
+    expect = {}
+
+    def add(nm, g):
+        expect[nm] = g if nm not in expect else expect[nm] + g
+
+    heads = 0
+    for nd in desc['nodes']:
+        oname = T[nd['out']]['name']
+        dy = grads[oname]
+        if nd.get('head', -1) >= 0:           # d(loss)/d(head) = 2 (out - target) / numel (cu-net.py:175-178)
+            ref = 2.0 * (acts[oname] - target) / target.numel()
+            assert (dy - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-12, oname
+            heads += 1
+        op = nd['op']
+        if op == 'conv':
+            leaves = [acts[T[s['t']]['name']].clone().requires_grad_(True) for s in nd['segs']]
+            parts = [F.interpolate(l, scale_factor=2, mode='nearest') if s['ups'] else l for l, s in zip(leaves, nd['segs'])]
+            cat = torch.cat(parts, 1) if len(parts) > 1 else parts[0]
+            y = F.conv2d(F.relu(F.batch_norm(cat, None, None, st[nd['bn'] + '.weight'], st[nd['bn'] + '.bias'], True, 0.1, 1e-5)),
+                         st[nd['conv'] + '.weight'], None, 1, 1 if nd['taps'] == 9 else 0)
+            y.backward(dy)
+            for l, s in zip(leaves, nd['segs']):
+                add(T[s['t']]['name'], l.grad)
+        elif op == 'pool':
+            nm = T[nd['segs'][0]['t']]['name']
+            leaf = acts[nm].clone().requires_grad_(True)
+            F.max_pool2d(leaf, 2, 2).backward(dy)
+            add(nm, leaf.grad)
+        elif op == 'stem_bnpool':
+            nm = T[nd['segs'][0]['t']]['name']
+            leaf = acts[nm].clone().requires_grad_(True)
+            F.max_pool2d(F.relu(F.batch_norm(leaf, None, None, st[nd['bn'] + '.weight'], st[nd['bn'] + '.bias'], True, 0.1, 1e-5)), 2, 2).backward(dy)
+            add(nm, leaf.grad)
+    assert heads == cfg['loss_num']
+    bad = []
+    for nm, g in expect.items():
+        _close('d ' + nm, grads[nm], g, bad)
+    assert len(expect) >= len(produced) - cfg['loss_num']
+    assert not bad, f'{len(bad)} tensors whose gradient is not the sum of their consumers\' contributions:\n' + '\n'.join(bad[:30])
+
+
+@pytest.mark.parametrize('tag', ['G2_L3_o2', 'G3_L4_o1_ln2', 'G4_L2_o0', 'G9_L2_o1_c32'])
+def test_whole_backward_is_the_sum_of_consumer_contributions(tag):
+    g = Golden(tag)
+    _check_composition(g.cfg, g.group('state0'), g.t('x'), g.t('target'))
+
+
+def test_whole_backward_composition_full_width_cu_net4():
+    """Production widths, L = 4 (U-Net indices beyond 1: intermedia adapters i >= 2 and FIFO pops at 128-wide channels)."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=4, order=1, loss_num=4)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=71)
+    x, target = O.synthetic_batch(1, 16, 256, seed=72)
+    _check_composition(cfg, st, x, target)

@@ -237,8 +237,35 @@ def full_width_cfg(ref, tag, cfg, n, init_seed, batch_seed, rq=None, bits_w=None
                 rs[k] = float(v.double().sum())
     fx['running_names'] = np.array(list(rs.keys()), dtype='U')
     fx['running_sums'] = np.array(list(rs.values()))
+    # --- the same step of the REFERENCE in float64: the yardstick for every fp32 implementation.  At random init these
+    # deep nets amplify a 1e-7 perturbation by ~3.5x per U-Net (train-mode BatchNorm), so torch's own fp32 result is
+    # 4e-2 away from the fp64 one at the 8th head: tolerances in the GPU tests are multiples of THAT distance.
+    net64 = quiet(ref.create_cu_net, **cfg)
+    net64.load_state_dict(st)
+    net64.double().train()
+    if rq is not None:
+        qop64 = rq.QuanOp(net64)
+        qop64.quantization()
+    out64 = net64(x.double())
+    loss64 = 0
+    for o in out64:
+        t = (o - target.double()) ** 2
+        loss64 = loss64 + t.sum() / t.numel()
+    loss64.backward()
+    if rq is not None:
+        qop64.restore()
+        qop64.updateQuanGradWeight()
+    fx['loss64'] = to_np(loss64)
+    for i, o in enumerate(out64):
+        fx[f'out64_sub/{i}'] = to_np(o)[:, ::4, ::4, ::4].copy()
+    g64 = dict(net64.named_parameters())
+    fx['grad_norms64'] = np.array([float(g64[k].grad.norm()) for k in gsum.keys()])
+    sd64 = net64.state_dict()
+    fx['running_sums64'] = np.array([float(sd64[k].sum()) for k in rs.keys()])
+    e = [float((a.double() - b).norm() / b.norm()) for a, b in zip(out, out64)]
     np.savez_compressed(os.path.join(OUT, tag + '.npz'), **fx)
-    print(f'{tag}: full width {cfg} N={n} bits_w={bits_w} loss={float(loss):.6f}  oracle == reference')
+    print(f'{tag}: full width {cfg} N={n} bits_w={bits_w} loss={float(loss):.6f}  oracle == reference; '
+          f'fp32-vs-fp64 relL2 per head {["%.1e" % v for v in e]}')
 
 
 class _LegacyTorchSemantics:
