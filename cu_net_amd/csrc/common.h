@@ -87,6 +87,21 @@ struct WgradArgs {
     int xbf16;             // 1 = the segments' x are bf16; 2 = x and dy are bf16 (dw stays fp32)
 };
 
+// third-generation 1x1 weight gradient (wgrad3_kernels.hip): one workgroup owns the whole [128][CW] output for a range
+// of pixels and writes a partial tile; wgrad_reduce_kernel sums the partials of a gradient bucket
+struct Wg3Args {
+    WgradArgs w;
+    float* part;           // [splits][128][Ccat] partial sums
+    int rows_per_split;    // multiple of 32
+    int c0, CW;            // channel slice of this launch (CW <= 320, multiple of 32)
+    int any_ups;
+};
+struct WgReduceEntry {     // grads[dst + i] = sum_s ws[part + s*numel + i]
+    int64_t part;          // float offset in the workspace float region
+    int64_t dst;           // float offset in the gradient arena
+    int S, numel;
+};
+
 constexpr int MAXGSRC = 8;  // conv consumers gathered per launch (more: further launches with accumulate = 1)
 
 struct GradSrc {           // one conv node that reads the tensor: its BN backward contributes A*dz + E - D*x

@@ -394,6 +394,39 @@ void Plan::layout_workspace() {
     }
     off_runstat_tab = off;
     off += round_up64((int64_t)n_runstat * (int64_t)sizeof(RunStatEntry), 256);
+    // wgrad3 eligibility and split geometry (host-only decision; the kernel's requirements are re-checked at launch).
+    // Nodes are visited bucket by bucket so that a bucket's entries are contiguous in the reduce table.
+    {
+        const int P = 32;
+        const int min_chunks = tune_int("CUNET_WG3_MIN_CHUNKS", 8), smax = tune_int("CUNET_WG3_SMAX", 256);
+        const int min_m = tune_int("CUNET_WG3_MIN_M", 0), enable = tune_int("CUNET_WG3", 1);
+        const int nb = cfg.layer_num + 1;
+        wgred_first.assign(nb, 0); wgred_count.assign(nb, 0); wgred_maxnumel.assign(nb, 0);
+        n_wgred = 0;
+        for (int b = 0; b < nb; ++b) {
+            wgred_first[b] = n_wgred;
+            for (auto& n : nodes) {
+                if (n.type != N_CONV || n.bucket != b || n.taps != 1 || !enable) continue;
+                const ConvInfo& c = convs[n.conv];
+                const TensorInfo& o = tensors[n.out];
+                bool ok = c.Cout == 128 && o.ld == 128 && n.Ccat % 32 == 0 && n.Ccat >= 128 && o.rows() >= min_m;
+                for (auto& sr : n.segs) ok = ok && tensors[sr.tensor].C % 4 == 0 && tensors[sr.tensor].ld % 4 == 0;
+                if (!ok) continue;
+                const int64_t M = o.rows();
+                int64_t S = (M + (int64_t)P * min_chunks - 1) / ((int64_t)P * min_chunks);
+                if (S > smax) S = smax;
+                if (S < 1) S = 1;
+                int64_t rows = (M + S - 1) / S;
+                rows = (rows + 63) / 64 * 64;                // whole chunks of both kernels (32 fp32 / 64 bf16 pixels)
+                S = (M + rows - 1) / rows;
+                n.wg3_S = (int)S; n.wg3_rows = (int)rows; n.wg3_entry = n_wgred++;
+                wgred_count[b]++;
+                wgred_maxnumel[b] = std::max(wgred_maxnumel[b], c.Cout * n.Ccat);
+            }
+        }
+    }
+    off_wgred_tab = off;
+    off += round_up64((int64_t)(n_wgred > 0 ? n_wgred : 1) * (int64_t)sizeof(WgReduceEntry), 256);
     loss_acc = n_zero_doubles;
     n_zero_doubles += 2;
     off_zero = off;
@@ -422,6 +455,19 @@ void Plan::layout_workspace() {
     (void)dzmax;
     const TensorInfo& h0 = tensors[head_tensors[0]];
     target_off = take(h0.rows() * h0.ld);
+    {   // partial tiles of the wgrad3 nodes: ONE region, reused bucket after bucket (the stream that runs a bucket's
+        // weight gradients also runs its reduce, so the next bucket's partials cannot overtake it)
+        int64_t region = 0;
+        for (int b = 0; b <= cfg.layer_num; ++b) {
+            int64_t sum = 0;
+            for (auto& n : nodes)
+                if (n.wg3_S > 0 && n.bucket == b) { n.wg3_part = sum; sum += round_up64((int64_t)n.wg3_S * convs[n.conv].Cout * n.Ccat, 64); }
+            region = std::max(region, sum);
+        }
+        const int64_t base = take(region);
+        for (auto& n : nodes)
+            if (n.wg3_S > 0) n.wg3_part += base;
+    }
     n_floats_train = f;
     ws_bytes_infer = off_floats + n_floats_infer * 4;
     ws_bytes_train = off_floats + n_floats_train * 4;

@@ -70,6 +70,10 @@ struct Node {
     int64_t red = -1;         // double offset in the zeroed region: [2][Ccat] backward reductions
     int bucket = 0;           // gradient bucket this node's parameters live in
     int64_t dz = -1;          // float offset of this node's own [M][Ccat] dz buffer (training)
+    // LDS-staged 1x1 weight gradient (wgrad3): pixel splits, rows per split, float offset of the [S][Cout][Ccat]
+    // partial tiles inside the per-bucket partial region, index into the reduce table; wg3_S == 0: not eligible
+    int wg3_S = 0, wg3_rows = 0, wg3_entry = -1;
+    int64_t wg3_part = -1;
 };
 
 struct Plan {
@@ -99,6 +103,10 @@ struct Plan {
     int64_t off_bf16 = 0, ws_bytes_bf16 = 0;     // bf16 inference: a bf16 arena of n_floats_infer elements behind the fp32 inference layout
     int64_t off_bf16_train = 0, ws_bytes_bf16_train = 0;   // the same arena behind the training layout (bf16 activations, fp32 gradients)
     int n_runstat = 0;
+    int64_t off_wgred_tab = 0;                // reduce table of the wgrad3 nodes (bytes), entries grouped by bucket
+    int n_wgred = 0;
+    std::vector<int> wgred_first, wgred_count;   // per bucket: slice of the reduce table
+    std::vector<int> wgred_maxnumel;             // per bucket: largest numel in its slice
 
     std::string json;
     std::string error;

@@ -29,6 +29,7 @@ struct cunet_plan {
     // host copies of the device tables (kept alive for async uploads)
     std::vector<RepackEntry> repack;
     std::vector<RunStatEntry> runstat;
+    std::vector<WgReduceEntry> wgred;
     // call-order state
     int fwd_training_done = 0;
     int loss_done = 0;
@@ -221,7 +222,14 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         }
     }
     if ((int)h->runstat.size() != P.n_runstat) return fail(CUNET_ERR_STATE, "internal: running-stat table size");
+    h->wgred.assign((size_t)(P.n_wgred > 0 ? P.n_wgred : 1), WgReduceEntry{});
+    for (auto& n : P.nodes)
+        if (n.wg3_S > 0) {
+            WgReduceEntry& e = h->wgred[n.wg3_entry];
+            e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.S = n.wg3_S; e.numel = P.convs[n.conv].Cout * n.Ccat;
+        }
     hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(h->ws + P.off_wgred_tab, h->wgred.data(), h->wgred.size() * sizeof(WgReduceEntry), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->ws + P.off_repack_tab, h->repack.data(), h->repack.size() * sizeof(RepackEntry), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->ws + P.off_runstat_tab, h->runstat.data(), h->runstat.size() * sizeof(RunStatEntry), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -348,6 +356,17 @@ static int bn_param_grads(cunet_plan* h, int k0, int k1, int bucket, hipStream_t
     return CUNET_OK;
 }
 
+// Sums the partial tiles of the wgrad3 nodes [first, first + count) of the reduce table into the gradient arena, on the
+// stream that ran those weight gradients.
+static int reduce_wgrad3(cunet_plan* h, int first, int count, int max_numel, hipStream_t s) {
+    Exec E(h);
+    if (count <= 0) return CUNET_OK;
+    Plan& P = h->plan;
+    const WgReduceEntry* tab = reinterpret_cast<const WgReduceEntry*>(h->ws + P.off_wgred_tab) + first;
+    PROF_ON(s, PC_MISC, 0.0, 0.0, launch_wgrad_reduce(tab, count, max_numel, E.wsf, h->grads, s));
+    return CUNET_OK;
+}
+
 // Backward of one node: data gradient (+ReLU mask + BN reductions), weight gradient, BN apply.
 static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s) {
     Exec E(h);
@@ -406,8 +425,14 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
             w.dw = h->grads + c.w;
             w.xbf16 = E.xmode;
-            PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
-                    launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));
+            if (n.wg3_S > 0 && wgrad3_supported(w) && (E.xmode != 2 || n.wg3_rows % 64 == 0)) {
+                // LDS-staged, atomics-free: partial tiles now, summed into the arena by the bucket's reduce (reduce_wgrad3)
+                PROF_ON(ws, E.xmode == 2 ? PC_C1W16 : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat, (E.xmode == 2 ? 2.0 : 4.0) * (double)w.M * (w.Cout + w.Ccat),
+                        launch_wgrad3(w, E.wsf + n.wg3_part, n.wg3_S, n.wg3_rows, ws));
+            } else {
+                PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
+                        launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));
+            }
         }
     } else if (n.type == N_POOL) {
         const int tin = n.segs[0].tensor;
@@ -704,6 +729,9 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
+            const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket],
+                                          (h->use_side && h->side) ? h->side : s);
+            if (rcr != CUNET_OK) return rcr;
             const int rcg = bn_param_grads(h, k + 1, bucket_hi, cur_bucket, s);
             if (rcg != CUNET_OK) return rcg;
             if (on_bucket && on_bucket(cur_bucket, user) != 0) {   // the consumer joins the side stream itself (cunet_side_stream_join)
@@ -722,6 +750,11 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         if (rc != CUNET_OK) return rc;
     }
     {
+        if (cur_bucket >= 0) {
+            const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket],
+                                          (h->use_side && h->side) ? h->side : s);
+            if (rcr != CUNET_OK) return rcr;
+        }
         const int rcg = bn_param_grads(h, 0, bucket_hi, cur_bucket, s);
         if (rcg != CUNET_OK) return rcg;
     }
@@ -837,6 +870,10 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
     const int rc = bwd_node(h, n, node, s);
     if (rc != CUNET_OK) return rc;
+    if (n.wg3_S > 0) {
+        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, P.convs[n.conv].Cout * n.Ccat, (h->use_side && h->side) ? h->side : s);
+        if (rcr != CUNET_OK) return rcr;
+    }
     if (n.type == N_CONV) {                // this node's contribution to each of its inputs, and its BN parameter gradients
         for (size_t j = 0; j < n.segs.size(); ++j) {
             bool seen = false;

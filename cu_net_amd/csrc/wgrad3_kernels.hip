@@ -1,0 +1,554 @@
+// 1x1 weight gradient, third generation: LDS-staged, atomics-free.
+//     dW[n][c] = sum_m dY[m][n] * relu(bn(X))[m][c]          (autograd wgrad of models/cu_net.py:24,43)
+//
+// Why a third design.  wgrad2 (one wave = 4 x 2 output tiles fed by its own per-lane global loads) moves 6 operand
+// dwords per lane for every 8 MFMAs, re-reads dY once per 64-channel group, keeps only 2 waves per SIMD at 256 VGPRs
+// and commits with one fp32 atomic per output element per block (23 % of its time): 0.185 of the fp32 MFMA peak, 1.85x
+// the algorithmic HBM traffic (profiles/r01_*).  Here a 512-thread workgroup owns the WHOLE output [Cout = 128][CW <= 320]
+// for a range of pixels:
+//   * a chunk of P = 32 pixels of dY [P][128] and of the ACTIVATED X [P][CW] is staged once in LDS (BatchNorm + ReLU
+//     applied on the way in, once per element instead of once per use), double buffered: the global loads of chunk
+//     j+1 are issued before the MFMA loop of chunk j and written to the other buffer after it -- one barrier per chunk;
+//   * the 8 waves share the chunk: wave w owns output-channel tile (w & 3) and half of the input-channel tiles (or, when
+//     there are <= 5 of them, all of them on every other pixel pair); MFMA operands are conflict-free ds_read_b32;
+//     every byte of dY and X is read from HBM exactly once per launch;
+//   * each workgroup stores its partial [128][CW] tile with plain coalesced stores into part[split][n][c]; one
+//     deterministic reduce kernel per gradient bucket sums the splits into the gradient arena (no atomics, bitwise
+//     reproducible dW).
+// Roofline: 2*128*CW flops per (128 + CW)*4 bytes = 45.7 flop/B at CW = 320 > the fp32 ridge (~25): MFMA-bound.
+#include "common.h"
+#include "kernels.h"
+
+namespace cunet {
+
+constexpr int WG3_P = 32;            // pixels per chunk
+constexpr int WG3_THREADS = 512;
+constexpr int WG3_NOUT = 128;        // output channels (4 tiles): the bottleneck / adapter convs of the network
+constexpr int WG3_MAXCW = 320;
+
+template <int CTW, bool SPLITK, int XB>
+__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_kernel(const Wg3Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WgradArgs& p = q.w;
+    const int CW = q.CW;                                   // channels of this launch's slice (multiple of 32)
+    const int ct = CW >> 5;
+    float* sc = reinterpret_cast<float*>(smem);            // [CW] BatchNorm scale
+    float* sh = sc + WG3_MAXCW;                            // [CW] BatchNorm shift
+    float* buf0 = sh + WG3_MAXCW;                          // 2 x { dY [P][128], X [P][CW] }
+    const int bufsz = WG3_P * (WG3_NOUT + CW);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int HW = p.H * p.W;
+
+    // ---- BatchNorm scale / shift of this slice (batch statistics of the segment tensors, as every consumer derives them)
+    for (int c = tid; c < CW; c += WG3_THREADS) {
+        const int cc = q.c0 + c;
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cc >= p.seg[t].choff) s = t;
+        const Seg& sg = p.seg[s];
+        const int lc = cc - sg.choff;
+        const double sum = sg.stats[lc], sq = sg.stats[sg.C + lc];
+        const double mean = sum / sg.count;
+        double var = sq / sg.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[cc] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[cc] - mean * scale);
+    }
+
+    // ---- staging plan of this thread (chunk-invariant): 2 float4 of dY, up to NX float4 of X
+    constexpr int NX = SPLITK ? (CTW + 1) / 2 : CTW;       // ceil(ct / 2) float4 per thread: P * CW / 4 / 512
+    const int cw4 = CW >> 2;
+    const int nx4 = WG3_P * cw4;                           // float4 items of X per chunk
+    int xp[NX], xc[NX];                                    // pixel within the chunk, first channel within the slice
+    const float* xbase[NX];
+    int xld[NX], xups[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        int idx = tid + WG3_THREADS * j;
+        if (idx >= nx4) idx = nx4 - 1;                     // duplicates of the last item: same value to the same LDS address
+        xp[j] = idx / cw4;
+        xc[j] = (idx - xp[j] * cw4) << 2;
+        const int cc = q.c0 + xc[j];
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cc >= p.seg[t].choff) s = t;
+        const Seg& sg = p.seg[s];
+        xbase[j] = xadv<XB>(sg.x, (size_t)(cc - sg.choff));
+        xld[j] = sg.ld;
+        xups[j] = sg.ups;
+    }
+    const int ap0 = tid >> 5, ac0 = (tid & 31) << 2;       // dY item 0: pixel tid/32, channels 4*(tid%32); item 1: pixel + 16
+
+    const int row_begin = blockIdx.x * q.rows_per_split;
+    int row_end = row_begin + q.rows_per_split;
+    if (row_end > p.M) row_end = p.M;
+    const int nchunks = (row_end - row_begin + WG3_P - 1) / WG3_P;
+
+    float4 av[2], xv[NX];
+    bool aok[2], xok[NX];
+    auto issue = [&](int chunk) {                          // raw global loads of one chunk into registers (clamped addresses)
+        const int m0 = row_begin + chunk * WG3_P;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ap0 + 16 * j;
+            aok[j] = m < row_end;
+            const int mc = aok[j] ? m : row_begin;
+            av[j] = ldg4(p.dy + (size_t)mc * p.lddy + ac0);
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int m = m0 + xp[j];
+            xok[j] = m < row_end;
+            const int mc = xok[j] ? m : row_begin;
+            int row = mc;
+            if (q.any_ups) {                               // nearest-upsample index map (models/cu_net.py:250,265): (y >> 1, x >> 1)
+                const int nimg = mc / HW;
+                const int rem = mc - nimg * HW;
+                const int py = rem / p.W;
+                const int px = rem - py * p.W;
+                const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+                row = xups[j] ? rowU : mc;
+            }
+            xv[j] = ldx4<XB>(xbase[j], (size_t)row * xld[j]);
+        }
+    };
+    auto commit = [&](float* buf) {                        // registers -> LDS, BatchNorm + ReLU on X, zeros beyond the range
+        float* A = buf;
+        float* X = buf + WG3_P * WG3_NOUT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 v = aok[j] ? av[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(A + (ap0 + 16 * j) * WG3_NOUT + ac0) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sc + xc[j]);
+            const float4 h4 = *reinterpret_cast<const float4*>(sh + xc[j]);
+            float4 v;
+            v.x = fmaxf(fmaf(xv[j].x, s4.x, h4.x), 0.f);
+            v.y = fmaxf(fmaf(xv[j].y, s4.y, h4.y), 0.f);
+            v.z = fmaxf(fmaf(xv[j].z, s4.z, h4.z), 0.f);
+            v.w = fmaxf(fmaf(xv[j].w, s4.w, h4.w), 0.f);
+            if (!xok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(X + xp[j] * CW + xc[j]) = v;
+        }
+    };
+
+    // ---- tile ownership: n tile = wave & 3; c tiles: split-K -> all ct on pixel pairs of parity (wave >> 2),
+    //      otherwise half (wave >> 2) owns tiles [half * CTW, half * CTW + CTW) (the last one clamped when ct is odd)
+    const int nt = wave & 3;
+    const int half = wave >> 2;
+    const int cb = SPLITK ? 0 : half * CTW;
+    int ctile[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) ctile[t] = (cb + t < ct) ? cb + t : ct - 1;
+
+    f32x16 acc[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    issue(0);
+    __syncthreads();                                       // sc / sh visible
+    commit(buf0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        float* cur = buf0 + (chunk & 1) * bufsz;
+        const bool more = chunk + 1 < nchunks;
+        if (more) issue(chunk + 1);                        // in flight across the MFMA loop
+        const float* A = cur + nt * 32 + li;
+        const float* X = cur + WG3_P * WG3_NOUT + li;
+#pragma unroll 4
+        for (int kk = (SPLITK ? half : 0); kk < WG3_P / 2; kk += (SPLITK ? 2 : 1)) {
+            const int r = 2 * kk + hi;
+            const float a = A[r * WG3_NOUT];
+            float x[CTW];
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) x[t] = X[r * CW + ctile[t] * 32];
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[t], acc[t], 0, 0, 0);
+        }
+        if (more) commit(buf0 + ((chunk + 1) & 1) * bufsz);
+        __syncthreads();
+    }
+
+    // ---- split-K: the odd-pair half hands its tiles to the even-pair half through LDS
+    if (SPLITK) {
+        float* red = buf0;                                  // [4 waves][CTW][1024] (<= 80 KB, the chunk buffers are free now)
+        if (half == 1) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((nt * CTW + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((nt * CTW + t) * 16 + r) * 64 + lane];
+        }
+        if (half == 1) return;
+    }
+    // ---- partial tile -> part[split][n][c]: MFMA C layout, lane = input channel (32 consecutive floats per row)
+    float* out = q.part + (size_t)blockIdx.x * WG3_NOUT * p.Ccat;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        if (cb + t >= ct) continue;                         // the clamped duplicate of an odd tile count
+        const int c = q.c0 + (cb + t) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)n * p.Ccat + c] = acc[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same design on bf16 MFMA (bf16 storage of activations AND gradient tensors, FusedTrainer(bf16_grads=True)):
+// v_mfma_f32_32x32x16_bf16 contracts 16 pixels per instruction and wants each lane's 8 k-values (pixels) contiguous,
+// while NHWC keeps a pixel's CHANNELS contiguous.  The transpose happens on the way into LDS: a lane loads 4 consecutive
+// pixels x 8 channels (four 16-byte loads), applies BatchNorm + ReLU in fp32 (X only), re-rounds with v_cvt_pk_bf16_f32 --
+// whose two inputs are the SAME channel of two neighbouring pixels, so the conversion itself produces the pixel-major
+// packing -- and writes eight 8-byte pieces into a channel-major image  T[channel][64 pixels (+8 pad)].  MFMA fragments
+// are then single ds_read_b128 (row pitch 144 B: conflict-free).  Chunk = 64 pixels = 4 MFMA k-steps; 57 KB of HBM data
+// per chunk against 40 MFMAs of 32 cycles: HBM-bound (AI = 91 flop/B << the bf16 ridge ~310), which is the point.
+constexpr int WG3B_P = 64;           // pixels per chunk
+constexpr int WG3B_LDP = 72;         // bf16 elements per LDS row (64 + 8: 144 B pitch)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <int CTW, bool SPLITK>
+__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_bf16_kernel(const Wg3Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WgradArgs& p = q.w;
+    const int CW = q.CW;
+    const int ct = CW >> 5;
+    float* sc = reinterpret_cast<float*>(smem);            // [CW]
+    float* sh = sc + WG3_MAXCW;
+    unsigned short* buf0 = reinterpret_cast<unsigned short*>(sh + WG3_MAXCW);      // 2 x T[128 + CW][LDP] bf16
+    const int bufsz = (WG3_NOUT + CW) * WG3B_LDP;                                  // elements per buffer
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int HW = p.H * p.W;
+    const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(p.dy);
+
+    for (int c = tid; c < CW; c += WG3_THREADS) {
+        const int cc = q.c0 + c;
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cc >= p.seg[t].choff) s = t;
+        const Seg& sg = p.seg[s];
+        const int lc = cc - sg.choff;
+        const double sum = sg.stats[lc], sq = sg.stats[sg.C + lc];
+        const double mean = sum / sg.count;
+        double var = sq / sg.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[cc] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[cc] - mean * scale);
+    }
+
+    // ---- staging: the image has 4 + ct row groups of 32 channels (0..3 = dY, 4.. = X tiles); wave w stages groups w, w + 8.
+    // Inside a group a lane owns pixels 4*q4 .. 4*q4+3 (q4 = lane & 15) of channels 8*c8 .. 8*c8+7 (c8 = lane >> 4).
+    const int q4 = lane & 15, c8 = lane >> 4;
+    const int nrg = 4 + ct;
+    const unsigned short* gbase[2];
+    int gld[2], gups[2], grow[2], gsc[2];
+    bool gx[2], gon[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = wave + 8 * j;
+        gon[j] = g < nrg;
+        const int gg = gon[j] ? g : 0;
+        gx[j] = gg >= 4;
+        grow[j] = gg * 32 + 8 * c8;                        // first LDS row of this lane's 8 channels
+        gsc[j] = gx[j] ? (gg - 4) * 32 + 8 * c8 : 0;       // their position in sc / sh
+        if (gx[j]) {
+            const int cc = q.c0 + (gg - 4) * 32 + 8 * c8;
+            int s = 0;
+            for (int t = 1; t < p.nseg; ++t)
+                if (cc >= p.seg[t].choff) s = t;
+            const Seg& sg = p.seg[s];
+            gbase[j] = reinterpret_cast<const unsigned short*>(sg.x) + (cc - sg.choff);
+            gld[j] = sg.ld; gups[j] = sg.ups;
+        } else {
+            gbase[j] = dy16 + gg * 32 + 8 * c8;
+            gld[j] = p.lddy; gups[j] = 0;
+        }
+    }
+
+    const int row_begin = blockIdx.x * q.rows_per_split;
+    int row_end = row_begin + q.rows_per_split;
+    if (row_end > p.M) row_end = p.M;
+    const int nchunks = (row_end - row_begin + WG3B_P - 1) / WG3B_P;
+
+    uint4 ld[2][4];
+    unsigned okm[2];
+    auto issue = [&](int chunk) {
+        const int m0 = row_begin + chunk * WG3B_P + 4 * q4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            okm[j] = 0;
+            if (!gon[j]) continue;                          // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i;
+                const bool ok = m < row_end;
+                okm[j] |= (unsigned)ok << i;
+                const int mc = ok ? m : row_begin;
+                int row = mc;
+                if (q.any_ups && gups[j]) {
+                    const int nimg = mc / HW;
+                    const int rem = mc - nimg * HW;
+                    const int py = rem / p.W;
+                    const int px = rem - py * p.W;
+                    row = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+                }
+                ld[j][i] = *reinterpret_cast<const uint4*>(gbase[j] + (size_t)row * gld[j]);
+            }
+        }
+    };
+    auto commit = [&](unsigned short* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!gon[j]) continue;
+            unsigned r[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (okm[j] >> i) & 1;
+                r[i][0] = ok ? ld[j][i].x : 0u; r[i][1] = ok ? ld[j][i].y : 0u;
+                r[i][2] = ok ? ld[j][i].z : 0u; r[i][3] = ok ? ld[j][i].w : 0u;
+            }
+            uint2* dst = reinterpret_cast<uint2*>(buf + (size_t)grow[j] * WG3B_LDP + 4 * q4);      // + e * LDP elements per channel
+            if (gx[j]) {
+                float s8[8], h8[8];
+                *reinterpret_cast<float4*>(s8) = *reinterpret_cast<const float4*>(sc + gsc[j]);
+                *reinterpret_cast<float4*>(s8 + 4) = *reinterpret_cast<const float4*>(sc + gsc[j] + 4);
+                *reinterpret_cast<float4*>(h8) = *reinterpret_cast<const float4*>(sh + gsc[j]);
+                *reinterpret_cast<float4*>(h8 + 4) = *reinterpret_cast<const float4*>(sh + gsc[j] + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {              // channel pair (2k, 2k+1)
+                    float lo[4], hh[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool ok = (okm[j] >> i) & 1;
+                        lo[i] = fmaxf(fmaf(bf16_bits_lo(r[i][k]), s8[2 * k], h8[2 * k]), 0.f);
+                        hh[i] = fmaxf(fmaf(bf16_bits_hi(r[i][k]), s8[2 * k + 1], h8[2 * k + 1]), 0.f);
+                        if (!ok) { lo[i] = 0.f; hh[i] = 0.f; }     // relu(shift) of a row beyond the range must not leak in
+                    }
+                    dst[(2 * k) * (WG3B_LDP / 4)] = make_uint2(cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]));
+                    dst[(2 * k + 1) * (WG3B_LDP / 4)] = make_uint2(cvt_pk_bf16(hh[0], hh[1]), cvt_pk_bf16(hh[2], hh[3]));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned a0 = (r[0][k] & 0xffffu) | (r[1][k] << 16), a1 = (r[2][k] & 0xffffu) | (r[3][k] << 16);
+                    const unsigned b0 = (r[0][k] >> 16) | (r[1][k] & 0xffff0000u), b1 = (r[2][k] >> 16) | (r[3][k] & 0xffff0000u);
+                    dst[(2 * k) * (WG3B_LDP / 4)] = make_uint2(a0, a1);
+                    dst[(2 * k + 1) * (WG3B_LDP / 4)] = make_uint2(b0, b1);
+                }
+            }
+        }
+    };
+
+    const int nt = wave & 3;
+    const int half = wave >> 2;
+    const int cb = SPLITK ? 0 : half * CTW;
+    int ctile[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) ctile[t] = (cb + t < ct) ? cb + t : ct - 1;
+
+    f32x16 acc[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    issue(0);
+    __syncthreads();
+    commit(buf0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const unsigned short* cur = buf0 + (size_t)(chunk & 1) * bufsz;
+        const bool more = chunk + 1 < nchunks;
+        if (more) issue(chunk + 1);
+        const unsigned short* A = cur + (size_t)(nt * 32 + li) * WG3B_LDP + 8 * hi;
+        const unsigned short* X = cur + (size_t)(WG3_NOUT + li) * WG3B_LDP + 8 * hi;
+#pragma unroll
+        for (int kk = (SPLITK ? half : 0); kk < WG3B_P / 16; kk += (SPLITK ? 2 : 1)) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(A + 16 * kk);
+            bf16x8_t x[CTW];
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) x[t] = *reinterpret_cast<const bf16x8_t*>(X + (size_t)ctile[t] * 32 * WG3B_LDP + 16 * kk);
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t], acc[t], 0, 0, 0);
+        }
+        if (more) commit(buf0 + (size_t)((chunk + 1) & 1) * bufsz);
+        __syncthreads();
+    }
+
+    if (SPLITK) {
+        float* red = reinterpret_cast<float*>(buf0);
+        if (half == 1) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((nt * CTW + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((nt * CTW + t) * 16 + r) * 64 + lane];
+        }
+        if (half == 1) return;
+    }
+    float* out = q.part + (size_t)blockIdx.x * WG3_NOUT * p.Ccat;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        if (cb + t >= ct) continue;
+        const int c = q.c0 + (cb + t) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)n * p.Ccat + c] = acc[t][r];
+        }
+    }
+}
+
+// dst[i] = sum_s part[s][i]: fixed summation order (bitwise reproducible).  blockIdx.y = table entry.
+// A block covers 64 float4 of the output; its four 64-thread groups take every fourth split and meet in LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgReduceEntry* __restrict__ tab, const float* __restrict__ ws,
+                                                           float* __restrict__ grads) {
+    const WgReduceEntry e = tab[blockIdx.y];
+    const int n4 = e.numel >> 2;
+    const int i4 = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (blockIdx.x * 64 >= n4) return;
+    __shared__ float4 red[256];
+    const int sg = threadIdx.x >> 6;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n4) {
+        const float* src = ws + e.part + (size_t)i4 * 4;
+        for (int s = sg; s < e.S; s += 4) {
+            const float4 v = ldg4(src + (size_t)s * e.numel);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && i4 < n4) {
+        const float4 b = red[64 + threadIdx.x], c = red[128 + threadIdx.x], d = red[192 + threadIdx.x];
+        acc.x = (acc.x + b.x) + (c.x + d.x); acc.y = (acc.y + b.y) + (c.y + d.y);
+        acc.z = (acc.z + b.z) + (c.z + d.z); acc.w = (acc.w + b.w) + (c.w + d.w);
+        *reinterpret_cast<float4*>(grads + e.dst + (size_t)i4 * 4) = acc;
+    }
+}
+
+bool wgrad3_supported(const WgradArgs& a) {
+    if (a.taps != 1 || a.Cout != WG3_NOUT || a.lddy != WG3_NOUT || a.img != nullptr) return false;
+    if (a.Ccat % 32 || a.Ccat < 128) return false;
+    const int al = a.xbf16 == 2 ? 8 : 4;                  // 16-byte pieces: 8 bf16 / 4 fp32 channels
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % al || a.seg[i].ld % al) return false;
+    return true;
+}
+
+static hipError_t launch_wg3_bf16(const Wg3Args& q, int ct, dim3 grid, size_t smem, hipStream_t s) {
+#define CUNET_WG3B(CTW_, SK_) hipLaunchKernelGGL((wgrad3_bf16_kernel<CTW_, SK_>), grid, dim3(WG3_THREADS), smem, s, q)
+    switch (ct) {
+        case 4: CUNET_WG3B(4, true); break;
+        case 5: CUNET_WG3B(5, true); break;
+        case 6: CUNET_WG3B(3, false); break;
+        case 7: case 8: CUNET_WG3B(4, false); break;
+        case 9: case 10: CUNET_WG3B(5, false); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CUNET_WG3B
+    return hipGetLastError();
+}
+
+template <int XB>
+static hipError_t launch_wg3_x(const Wg3Args& q, int ct, dim3 grid, size_t smem, hipStream_t s) {
+#define CUNET_WG3(CTW_, SK_) hipLaunchKernelGGL((wgrad3_kernel<CTW_, SK_, XB>), grid, dim3(WG3_THREADS), smem, s, q)
+    switch (ct) {
+        case 4: CUNET_WG3(4, true); break;
+        case 5: CUNET_WG3(5, true); break;
+        case 6: CUNET_WG3(3, false); break;
+        case 7: case 8: CUNET_WG3(4, false); break;
+        case 9: case 10: CUNET_WG3(5, false); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CUNET_WG3
+    return hipGetLastError();
+}
+
+// part: [S][128][Ccat] floats.  Slices of at most 320 channels (more: several launches, dY is then re-read per slice).
+hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s) {
+    if (!wgrad3_supported(a) || S < 1 || rows_per_split % (a.xbf16 == 2 ? WG3B_P : WG3_P)) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        const void* fns[] = {
+            (const void*)&wgrad3_kernel<4, true, 0>, (const void*)&wgrad3_kernel<5, true, 0>, (const void*)&wgrad3_kernel<3, false, 0>,
+            (const void*)&wgrad3_kernel<4, false, 0>, (const void*)&wgrad3_kernel<5, false, 0>,
+            (const void*)&wgrad3_kernel<4, true, 1>, (const void*)&wgrad3_kernel<5, true, 1>, (const void*)&wgrad3_kernel<3, false, 1>,
+            (const void*)&wgrad3_kernel<4, false, 1>, (const void*)&wgrad3_kernel<5, false, 1>,
+            (const void*)&wgrad3_bf16_kernel<4, true>, (const void*)&wgrad3_bf16_kernel<5, true>, (const void*)&wgrad3_bf16_kernel<3, false>,
+            (const void*)&wgrad3_bf16_kernel<4, false>, (const void*)&wgrad3_bf16_kernel<5, false>};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        attr_done = true;
+    }
+    Wg3Args q{};
+    q.w = a;
+    q.part = part;
+    q.rows_per_split = rows_per_split;
+    q.any_ups = 0;
+    for (int i = 0; i < a.nseg; ++i) q.any_ups |= a.seg[i].ups;
+    const int ct_all = a.Ccat / 32;
+    const int nslices = (ct_all + 9) / 10;
+    const int per = (ct_all + nslices - 1) / nslices;
+    for (int c0t = 0; c0t < ct_all; c0t += per) {
+        int ct = ct_all - c0t < per ? ct_all - c0t : per;
+        if (ct < 4) { c0t -= 4 - ct; ct = 4; }          // a short tail slice overlaps its predecessor (same values written twice)
+        q.c0 = c0t * 32;
+        q.CW = ct * 32;
+        size_t buf_bytes = a.xbf16 == 2 ? (size_t)2 * (WG3_NOUT + q.CW) * WG3B_LDP * 2 : (size_t)2 * WG3_P * (WG3_NOUT + q.CW) * 4;
+        if (ct <= 5 && buf_bytes < (size_t)4 * ct * 4096) buf_bytes = (size_t)4 * ct * 4096;      // split-K hand-over area
+        const size_t smem = (size_t)2 * WG3_MAXCW * 4 + buf_bytes;
+        const hipError_t e = a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)
+                           : a.xbf16 ? launch_wg3_x<1>(q, ct, dim3(S), smem, s) : launch_wg3_x<0>(q, ct, dim3(S), smem, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, const float* ws, float* grads, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int gx = (max_numel / 4 + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, n), dim3(256), 0, s, tab, ws, grads);
+    return hipGetLastError();
+}
+
+}  // namespace cunet

@@ -576,14 +576,19 @@ static hipError_t launch_wgrad2(const WgradArgs& a, int num_cus, hipStream_t s) 
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2, 0>));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_stem_kernel));
         if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1, 0>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2, 1>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<2, 2>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1, 1>));
+        if (e == hipSuccess) e = set_attr(reinterpret_cast<const void*>(&wgrad2_kernel<1, 2>));
         if (e != hipSuccess) return e;
         done = true;
     }
     if (q.stem) hipLaunchKernelGGL(wgrad2_stem_kernel, grid, dim3(256), smem, s, q);
-    else if (a.xbf16) {
-        if (ntw != 4) return hipErrorInvalidValue;       // bf16 activations: heads and bottlenecks have > 64 output channels
-        if (a.xbf16 == 2) hipLaunchKernelGGL((wgrad2_kernel<4, 2>), grid, dim3(256), smem, s, q);
-        else hipLaunchKernelGGL((wgrad2_kernel<4, 1>), grid, dim3(256), smem, s, q);
+    else if (a.xbf16) {          // (heads with <= 64 landmarks -- MPII's 16 joints -- take the narrow variants)
+#define CUNET_WG2X(N) do { if (a.xbf16 == 2) hipLaunchKernelGGL((wgrad2_kernel<N, 2>), grid, dim3(256), smem, s, q); \
+                           else hipLaunchKernelGGL((wgrad2_kernel<N, 1>), grid, dim3(256), smem, s, q); } while (0)
+        if (ntw == 4) CUNET_WG2X(4); else if (ntw == 2) CUNET_WG2X(2); else CUNET_WG2X(1);
+#undef CUNET_WG2X
     } else if (ntw == 4) hipLaunchKernelGGL((wgrad2_kernel<4, 0>), grid, dim3(256), smem, s, q);
     else if (ntw == 2) hipLaunchKernelGGL((wgrad2_kernel<2, 0>), grid, dim3(256), smem, s, q);
     else hipLaunchKernelGGL((wgrad2_kernel<1, 0>), grid, dim3(256), smem, s, q);
