@@ -48,6 +48,7 @@ def lib():
         'cunet_last_error': (C.c_char_p, []),
         'cunet_version': (C.c_char_p, []),
         'cunet_plan_create': (i32, [C.POINTER(Cfg), C.POINTER(vp)]),
+        'cunet_set_planner_option': (i32, [C.c_char_p, i32]),
         'cunet_plan_destroy': (None, [vp]),
         'cunet_state_count': (i32, [vp]),
         'cunet_state_entry': (i32, [vp, i32, C.POINTER(StateDesc)]),
@@ -96,7 +97,7 @@ def lib():
     return L
 
 
-EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_plan_destroy', 'cunet_state_count',
+EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set_planner_option', 'cunet_plan_destroy', 'cunet_state_count',
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind',
             'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
@@ -111,6 +112,11 @@ def check(rc: int, what: str = ''):
         msg = lib().cunet_last_error().decode()
         raise CUNetError(f'{what}: {msg} (status {rc})')
     return rc
+
+
+def set_planner_option(name: str, value: int):
+    """include/cunet.h cunet_set_planner_option: kernel selection knobs read when a plan is created."""
+    check(lib().cunet_set_planner_option(name.encode(), int(value)), 'cunet_set_planner_option')
 
 
 class PlanHandle:

@@ -20,6 +20,8 @@ namespace cunet {
 
 static const int NUM_BLOCKS = 4;   // models/cu_net.py:232
 
+PlannerOptions& planner_options() { static PlannerOptions o; return o; }
+
 void Plan::add_state(const std::string& name, int kind, std::vector<int64_t> shape, int bucket) {
     StateEntry e;
     e.name = name;
@@ -398,8 +400,9 @@ void Plan::layout_workspace() {
     // Nodes are visited bucket by bucket so that a bucket's entries are contiguous in the reduce table.
     {
         const int P = 32;
-        const int min_chunks = tune_int("CUNET_WG3_MIN_CHUNKS", 8), smax = tune_int("CUNET_WG3_SMAX", 256);
-        const int min_m = tune_int("CUNET_WG3_MIN_M", 0), enable = tune_int("CUNET_WG3", 1);
+        const PlannerOptions& po = planner_options();
+        const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits));
+        const int min_m = tune_int("CUNET_WG3_MIN_M", po.wgrad3_min_rows), enable = tune_int("CUNET_WG3", 1);
         const int nb = cfg.layer_num + 1;
         wgred_first.assign(nb, 0); wgred_count.assign(nb, 0); wgred_maxnumel.assign(nb, 0);
         n_wgred = 0;
@@ -499,7 +502,7 @@ void Plan::describe() {
         o << (i ? "," : "") << "{\"op\":\"" << tn[n.type] << "\",\"name\":\"" << n.name << "\",\"out\":" << n.out;
         if (n.bn >= 0) o << ",\"bn\":\"" << bns[n.bn].name << "\",\"ckpt\":" << (bns[n.bn].ckpt ? 1 : 0);
         if (n.conv >= 0) o << ",\"conv\":\"" << convs[n.conv].name << "\",\"taps\":" << n.taps;
-        o << ",\"head\":" << n.head << ",\"segs\":[";
+        o << ",\"head\":" << n.head << ",\"wg3\":" << n.wg3_S << ",\"segs\":[";
         for (size_t s = 0; s < n.segs.size(); ++s)
             o << (s ? "," : "") << "{\"t\":" << n.segs[s].tensor << ",\"ups\":" << n.segs[s].ups
               << "}";

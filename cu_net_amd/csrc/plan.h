@@ -76,6 +76,9 @@ struct Node {
     int64_t wg3_part = -1;
 };
 
+struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256; };
+PlannerOptions& planner_options();
+
 struct Plan {
     cunet_cfg cfg;
     std::vector<int> anchors;

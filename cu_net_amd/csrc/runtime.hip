@@ -104,6 +104,17 @@ extern "C" {
 const char* cunet_last_error(void) { return g_err.c_str(); }
 const char* cunet_version(void) { return "cunet-hip 0.1 (gfx950, fp32 MFMA)"; }
 
+int cunet_set_planner_option(const char* name, int value) {
+    if (!name || value < 0) return fail(CUNET_ERR_INVALID, "bad planner option");
+    PlannerOptions& o = planner_options();
+    const std::string n(name);
+    if (n == "wgrad3_min_rows") o.wgrad3_min_rows = value;
+    else if (n == "wgrad3_min_chunks") o.wgrad3_min_chunks = value;
+    else if (n == "wgrad3_max_splits") o.wgrad3_max_splits = value;
+    else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
+    return CUNET_OK;
+}
+
 int cunet_plan_create(const cunet_cfg* cfg, cunet_plan_t** out) {
     if (!cfg || !out) return fail(CUNET_ERR_INVALID, "null argument");
     cunet_plan* p = new (std::nothrow) cunet_plan();

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_kernel(const Wg3Args q)
     const int ct = CW >> 5;
     float* sc = reinterpret_cast<float*>(smem);            // [CW] BatchNorm scale
     float* sh = sc + WG3_MAXCW;                            // [CW] BatchNorm shift
-    float* buf0 = sh + WG3_MAXCW;                          // 2 x { dY [P][128], X [P][CW] }
-    const int bufsz = WG3_P * (WG3_NOUT + CW);
+    float* buf0 = sh + WG3_MAXCW;                          // 2 x { dY [P][128], X [P][LDX] }
+    constexpr int LDX = (SPLITK ? CTW : 2 * CTW) * 32;     // compile-time row pitch of X (>= CW): every LDS offset of the MFMA loop is an immediate
+    constexpr int bufsz = WG3_P * (WG3_NOUT + LDX);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_kernel(const Wg3Args q)
     const int nchunks = (row_end - row_begin + WG3_P - 1) / WG3_P;
 
     float4 av[2], xv[NX];
+    float4 s4[NX], h4[NX];                                 // BatchNorm scale / shift of this thread's channels (chunk-invariant, filled below)
     bool aok[2], xok[NX];
     auto issue = [&](int chunk) {                          // raw global loads of one chunk into registers (clamped addresses)
         const int m0 = row_begin + chunk * WG3_P;
@@ -129,15 +131,13 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_kernel(const Wg3Args q)
         }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const float4 s4 = *reinterpret_cast<const float4*>(sc + xc[j]);
-            const float4 h4 = *reinterpret_cast<const float4*>(sh + xc[j]);
             float4 v;
-            v.x = fmaxf(fmaf(xv[j].x, s4.x, h4.x), 0.f);
-            v.y = fmaxf(fmaf(xv[j].y, s4.y, h4.y), 0.f);
-            v.z = fmaxf(fmaf(xv[j].z, s4.z, h4.z), 0.f);
-            v.w = fmaxf(fmaf(xv[j].w, s4.w, h4.w), 0.f);
+            v.x = fmaxf(fmaf(xv[j].x, s4[j].x, h4[j].x), 0.f);
+            v.y = fmaxf(fmaf(xv[j].y, s4[j].y, h4[j].y), 0.f);
+            v.z = fmaxf(fmaf(xv[j].z, s4[j].z, h4[j].z), 0.f);
+            v.w = fmaxf(fmaf(xv[j].w, s4[j].w, h4[j].w), 0.f);
             if (!xok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(X + xp[j] * CW + xc[j]) = v;
+            *reinterpret_cast<float4*>(X + xp[j] * LDX + xc[j]) = v;
         }
     };
 
@@ -158,23 +158,46 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_kernel(const Wg3Args q)
 
     issue(0);
     __syncthreads();                                       // sc / sh visible
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        s4[j] = *reinterpret_cast<const float4*>(sc + xc[j]);
+        h4[j] = *reinterpret_cast<const float4*>(sh + xc[j]);
+    }
     commit(buf0);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         float* cur = buf0 + (chunk & 1) * bufsz;
         const bool more = chunk + 1 < nchunks;
         if (more) issue(chunk + 1);                        // in flight across the MFMA loop
-        const float* A = cur + nt * 32 + li;
-        const float* X = cur + WG3_P * WG3_NOUT + li;
-#pragma unroll 4
-        for (int kk = (SPLITK ? half : 0); kk < WG3_P / 2; kk += (SPLITK ? 2 : 1)) {
-            const int r = 2 * kk + hi;
-            const float a = A[r * WG3_NOUT];
-            float x[CTW];
+        // k-step i of this wave contracts pixel pair KS*i + (SPLITK ? half : 0); operands are fetched PF steps ahead of
+        // the MFMAs that use them (left to itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per tile, which
+        // exposes the whole LDS latency on every MFMA: measured 47 % of the matrix pipe)
+        constexpr int NK = SPLITK ? WG3_P / 4 : WG3_P / 2;
+        constexpr int KS = SPLITK ? 2 : 1;
+        constexpr int PF = 2;
+        const float* A = cur + nt * 32 + li + (2 * (SPLITK ? half : 0) + hi) * WG3_NOUT;
+        const float* X = cur + WG3_P * WG3_NOUT + li + (2 * (SPLITK ? half : 0) + hi) * LDX;
+        float ar[PF + 1], xr[PF + 1][CTW];
 #pragma unroll
-            for (int t = 0; t < CTW; ++t) x[t] = X[r * CW + ctile[t] * 32];
+        for (int i = 0; i < PF; ++i) {
+            ar[i] = A[2 * KS * i * WG3_NOUT];
 #pragma unroll
-            for (int t = 0; t < CTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < CTW; ++t) xr[i][t] = X[2 * KS * i * LDX + ctile[t] * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            if (i + PF < NK) {
+                ar[(i + PF) % (PF + 1)] = A[2 * KS * (i + PF) * WG3_NOUT];
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) xr[(i + PF) % (PF + 1)][t] = X[2 * KS * (i + PF) * LDX + ctile[t] * 32];
+            }
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i % (PF + 1)], xr[i % (PF + 1)][t], acc[t], 0, 0, 0);
+            // pin the software pipeline: this step's LDS reads (for step i + PF) BEFORE this step's MFMAs -- without it the
+            // scheduler sinks the reads next to their uses and both waves of a SIMD stall on the LDS latency in phase
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + CTW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CTW, 0);
         }
         if (more) commit(buf0 + ((chunk + 1) & 1) * bufsz);
         __syncthreads();
@@ -391,16 +414,27 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_bf16_kernel(const Wg3Ar
         const unsigned short* cur = buf0 + (size_t)(chunk & 1) * bufsz;
         const bool more = chunk + 1 < nchunks;
         if (more) issue(chunk + 1);
-        const unsigned short* A = cur + (size_t)(nt * 32 + li) * WG3B_LDP + 8 * hi;
-        const unsigned short* X = cur + (size_t)(WG3_NOUT + li) * WG3B_LDP + 8 * hi;
+        constexpr int NK = SPLITK ? WG3B_P / 32 : WG3B_P / 16;
+        constexpr int KS = SPLITK ? 2 : 1;
+        const unsigned short* A = cur + (size_t)(nt * 32 + li) * WG3B_LDP + 8 * hi + (SPLITK ? 16 * half : 0);
+        const unsigned short* X[CTW];
 #pragma unroll
-        for (int kk = (SPLITK ? half : 0); kk < WG3B_P / 16; kk += (SPLITK ? 2 : 1)) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(A + 16 * kk);
-            bf16x8_t x[CTW];
+        for (int t = 0; t < CTW; ++t) X[t] = cur + (size_t)(WG3_NOUT + ctile[t] * 32 + li) * WG3B_LDP + 8 * hi + (SPLITK ? 16 * half : 0);
+        bf16x8_t ar[2], xr[2][CTW];                          // operands one k-step ahead of the MFMAs
+        ar[0] = *reinterpret_cast<const bf16x8_t*>(A);
 #pragma unroll
-            for (int t = 0; t < CTW; ++t) x[t] = *reinterpret_cast<const bf16x8_t*>(X + (size_t)ctile[t] * 32 * WG3B_LDP + 16 * kk);
+        for (int t = 0; t < CTW; ++t) xr[0][t] = *reinterpret_cast<const bf16x8_t*>(X[t]);
 #pragma unroll
-            for (int t = 0; t < CTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t], acc[t], 0, 0, 0);
+        for (int i = 0; i < NK; ++i) {
+            if (i + 1 < NK) {
+                ar[(i + 1) & 1] = *reinterpret_cast<const bf16x8_t*>(A + 16 * KS * (i + 1));
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) xr[(i + 1) & 1][t] = *reinterpret_cast<const bf16x8_t*>(X[t] + 16 * KS * (i + 1));
+            }
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i & 1], xr[i & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + CTW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CTW, 0);
         }
         if (more) commit(buf0 + (size_t)((chunk + 1) & 1) * bufsz);
         __syncthreads();
@@ -534,7 +568,8 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
         if (ct < 4) { c0t -= 4 - ct; ct = 4; }          // a short tail slice overlaps its predecessor (same values written twice)
         q.c0 = c0t * 32;
         q.CW = ct * 32;
-        size_t buf_bytes = a.xbf16 == 2 ? (size_t)2 * (WG3_NOUT + q.CW) * WG3B_LDP * 2 : (size_t)2 * WG3_P * (WG3_NOUT + q.CW) * 4;
+        const int ldx = (ct <= 5 ? ct : 2 * ((ct + 1) / 2)) * 32;          // the fp32 kernel's compile-time X pitch
+        size_t buf_bytes = a.xbf16 == 2 ? (size_t)2 * (WG3_NOUT + q.CW) * WG3B_LDP * 2 : (size_t)2 * WG3_P * (WG3_NOUT + ldx) * 4;
         if (ct <= 5 && buf_bytes < (size_t)4 * ct * 4096) buf_bytes = (size_t)4 * ct * 4096;      // split-K hand-over area
         const size_t smem = (size_t)2 * WG3_MAXCW * 4 + buf_bytes;
         const hipError_t e = a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)

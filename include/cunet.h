@@ -203,6 +203,16 @@ int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float*
  *   out:   N*K x H x W fp32, fully written */
 int cunet_render_targets(const double* pts, const float* patch, int half, float* out, int nk, int hh, int w, void* stream);
 
+/* Planner options (host only, process-wide, read when a plan is CREATED).  They select between equivalent kernels and
+ * never change results beyond summation order:
+ *   "wgrad3_min_rows"    1x1 weight gradients of nodes with at least this many output rows (N*H*W) use the LDS-staged
+ *                        atomics-free kernel, smaller ones the per-wave atomic kernel (default 0: every eligible node --
+ *                        measured best on MI355X; tests also run with a large value to keep the other kernel covered)
+ *   "wgrad3_min_chunks"  at least this many 32-pixel chunks per workgroup of that kernel (default 2)
+ *   "wgrad3_max_splits"  at most this many workgroups (= partial tiles) per launch (default 256)
+ * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
+int cunet_set_planner_option(const char* name, int value);
+
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);
  * negative if unknown. Names are those listed by cunet_plan_describe. */

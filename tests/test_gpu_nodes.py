@@ -53,6 +53,19 @@ def test_every_node_backward_full_width():
     _check_all_nodes(cfg, st, x)
 
 
+@pytest.mark.parametrize('mode', [False, True, 2])
+def test_every_node_backward_full_width_wgrad3(mode):
+    """The LDS-staged, atomics-free 1x1 weight gradient (wgrad3: fp32 MFMA on fp32 / bf16 activations, bf16 MFMA with bf16
+    gradient tensors) forced onto every eligible node, N = 2: split-K and channel-halved tile ownerships (Ccat 128 ... 320),
+    the up-sample gather, ragged last chunks (32 .. 8192 rows) and the per-node partial reduce."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=27)
+    x, _ = O.synthetic_batch(2, 68, 256, seed=28)
+    _check_all_nodes(cfg, st, x, bf16=mode, wgrad3_all=True)
+
+
 def test_every_node_backward_full_width_bf16_activations():
     """The same node-by-node check with bf16 activation storage (FusedTrainer(bf16=True)): the backward kernels read x
     as bf16 and compute in fp32, so against torch autograd fed with the SAME bf16-rounded activations the fp32 tolerance
@@ -78,7 +91,19 @@ def test_every_node_backward_full_width_bf16_gradient_tensors():
     _check_all_nodes(cfg, st, x, bf16=2)
 
 
-def _check_all_nodes(cfg, st, x, bf16=False):
+def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False):
+    """wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
+    False: the planner is told to keep them on the per-wave atomic kernel (wgrad2), which stays the path of narrow heads,
+    non-32-multiple concats and the stem and must remain covered at production widths."""
+    from cu_net_amd._lib import set_planner_option
+    set_planner_option('wgrad3_min_rows', 0 if wgrad3_all else 1 << 30)
+    try:
+        _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all)
+    finally:
+        set_planner_option('wgrad3_min_rows', 0)
+
+
+def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
@@ -94,6 +119,8 @@ def _check_all_nodes(cfg, st, x, bf16=False):
     torch.cuda.synchronize()
     desc = plan.handle.describe()
     T = desc['tensors']
+    if wgrad3_all:
+        assert sum(1 for nd in desc['nodes'] if nd.get('wg3', 0) > 0) >= 20 * cfg['layer_num'], 'the planner did not select wgrad3'
     acts = {t['name']: plan.debug_tensor(t['name']).cpu() for t in T}
     off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
 
@@ -119,8 +146,12 @@ def _check_all_nodes(cfg, st, x, bf16=False):
             if gb and nd.get('head', -1) < 0:
                 wt = wt.bfloat16().float()              # the bf16-MFMA data gradient contracts with bf16-rounded weights
             wt.requires_grad_(True)
-            y = F.conv2d(F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5)), wt, None, 1,
-                         1 if nd['taps'] == 9 else 0)
+            act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
+            if gb and nd.get('wg3', 0) > 0:
+                # the bf16-MFMA weight gradient contracts dY with the bf16-ROUNDED activation -- exactly the operand the bf16
+                # forward multiplied the weights with, i.e. the exact gradient of that forward (straight-through here)
+                act = act + (act.bfloat16().float() - act).detach()
+            y = F.conv2d(act, wt, None, 1, 1 if nd['taps'] == 9 else 0)
             y.backward(dy)
             plan.debug_poke(oname, dy, grad=True)
             plan.debug_run_node_backward(k)
