@@ -109,7 +109,7 @@ def _check_step(tag, mode, quan_bits=0):
     # floors: 5e-2 (fp32) / 0.15 (bf16 storage, 8-bit gradient grid); in the chaotic regime the gradient of an early layer
     # sums exploding contributions of every later U-Net (|g| reaches 1e6 at L = 16), so the floor grows with the
     # reference's own decorrelation at the last head
-    floor = min(0.5, max(5e-2 if fp32 and not quan_bits else 0.15, 5 * e_ref[-1]))
+    floor = min(0.5, max(5e-2 if fp32 and not quan_bits else 0.15, 5 * e_ref[-1])) if fp32 else 0.5      # bf16: the late heads are decorrelated outright
     worst, nb = 0.0, 0
     for k, n32, n64 in zip(names, g.z['grad_norms'], g.z['grad_norms64']):
         o, nmel = off[k]
