@@ -63,6 +63,9 @@ struct ConvArgs {
     const float* img;
     int IH, IW;
     int xbf16;             // EP_BWD: 1 = the segments' x are bf16; 2 = x, the A operand (dY) and the dz output are bf16 (wB stays fp32)
+    int qin_bits;          // > 0: QuanInput2d of that many bits sits between the ReLU and the conv (utils/quantize.py:47-73, placement
+                           // models/cu_net_prev_version_wig.py:96-98,277-279): forward loaders quantise the activation,
+                           // EP_BWD applies its straight-through mask (no gradient where the activation is >= 1)
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)
@@ -85,6 +88,7 @@ struct WgradArgs {
     const float* img;      // stem
     int IH, IW;
     int xbf16;             // 1 = the segments' x are bf16; 2 = x and dy are bf16 (dw stays fp32)
+    int qin_bits;          // > 0: the conv's input is QuanInput(relu(bn(x))): the weight gradient contracts dY with the QUANTISED activation
 };
 
 // third-generation 1x1 weight gradient (wgrad3_kernels.hip): one workgroup owns the whole [128][CW] output for a range
@@ -176,13 +180,26 @@ struct QuantEntry {      // one target conv: weight [O][I][KK] at float offset `
 };
 
 struct TernArgs {
-    const float* x;          // [M][C] raw (pre-BN) activations
-    const float* scale;      // [C] folded BatchNorm (eval) scale / shift
+    const float* x;          // [M][ldx] raw (pre-BN) activations
+    const float* scale;      // [C] folded BatchNorm scale / shift, or null: fold in the kernel from the fields below
     const float* shift;
     const uint64_t* wpos;    // [taps][G][Opad] bit c of word (tap,g,o) = (w[o][64g+c][tap] == +1)
     const uint64_t* wneg;
-    float* y;                // [M][O]
+    float* y;                // [M][ldy]
     int M, H, W, C, O, Opad, taps, bits_i;
+    int ldx, ldy;
+    // in-kernel BatchNorm fold (scale == null): batch statistics of the input tensor (training) or running statistics
+    const double* xstats;    // [2][C] sum, sum of squares
+    double count;
+    const float* gamma; const float* beta; const float* rmean; const float* rvar;
+    int training;
+    double* ystats;          // [2][O] sum / sum of squares of the output (or null)
+};
+
+struct TernPackEntry {       // one conv whose (ternary) weights are packed into AND-popcount bit masks
+    int64_t src;             // float offset of the weight [O][C][taps] in the parameter arena
+    int64_t dst;             // uint64 offset of wpos in the mask region; wneg follows at dst + taps*G*Opad
+    int O, C, taps, Opad;
 };
 
 // Explicit global-address-space loads.  A pointer that reaches a lane through LDS or through a
@@ -261,6 +278,13 @@ inline int tune_int(const char*, int dflt) { return dflt; }
 inline float tune_float(const char*, float dflt) { return dflt; }
 #define CUNET_DBG(p, bit) 0
 #endif
+
+// QuanInput forward on a post-ReLU activation (utils/quantize.py:15-42,52-55 with bits in 3..15): clamp to 1 - 2^-(b-1),
+// round half to even onto the grid 2^-(b-1).  (v >= 0 here, so the lower clamp of C() never acts.)
+__device__ __forceinline__ float quan_input_act(float v, int bits) {
+    const float qs = (float)(1 << (bits - 1));
+    return rintf(fminf(v, 1.f - 1.f / qs) * qs) / qs;
+}
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 __host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

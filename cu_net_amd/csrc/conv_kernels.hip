@@ -225,6 +225,10 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                         a[q].y = fmaxf(fmaf(a[q].y, s.y, h.y), 0.f);
                         a[q].z = fmaxf(fmaf(a[q].z, s.z, h.z), 0.f);
                         a[q].w = fmaxf(fmaf(a[q].w, s.w, h.w), 0.f);
+                        if (p.qin_bits) {                       // QuanInput2d between the ReLU and the conv (uniform branch)
+                            a[q].x = quan_input_act(a[q].x, p.qin_bits); a[q].y = quan_input_act(a[q].y, p.qin_bits);
+                            a[q].z = quan_input_act(a[q].z, p.qin_bits); a[q].w = quan_input_act(a[q].w, p.qin_bits);
+                        }
                     } else {
                         a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
@@ -309,6 +313,10 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                         acur[q].y = fmaxf(fmaf(acur[q].y, s4.y, h4.y), 0.f);
                         acur[q].z = fmaxf(fmaf(acur[q].z, s4.z, h4.z), 0.f);
                         acur[q].w = fmaxf(fmaf(acur[q].w, s4.w, h4.w), 0.f);
+                        if (p.qin_bits) {
+                            acur[q].x = quan_input_act(acur[q].x, p.qin_bits); acur[q].y = quan_input_act(acur[q].y, p.qin_bits);
+                            acur[q].z = quan_input_act(acur[q].z, p.qin_bits); acur[q].w = quan_input_act(acur[q].w, p.qin_bits);
+                        }
                         if (LD == LD_3X3 && !vthis) acur[q] = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding is post-activation
                     }
                 }
@@ -410,7 +418,9 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                     if ((FAST || mm < p.M) && colok) {
                         const float xv = xq[nt & 1][r];
                         const float z = fmaf(xv, csc, csh);
-                        const float dz = z > 0.f ? acc[nt][r] : 0.f;
+                        // ReLU mask; with a QuanInput behind the ReLU also its straight-through mask (utils/quantize.py:58-63:
+                        // no gradient where the activation is >= 1, i.e. z >= 1)
+                        const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[nt][r] : 0.f;
                         stx1<GB>(p.y, (size_t)mm * p.ldy + col, dz);
                         s1 += dz;
                         s2 = fmaf(dz, (xv - cmu) * cis, s2);
@@ -650,7 +660,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     static const int use_ts = tune_int("CUNET_CONV_TS", 1);
     if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
         a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups &&
-        a_in.M / 32 <= use_ts * 4 * num_cus)      // beyond ~4 tiles per CU the barrier-free kernel is ahead (93 vs 106 us at 64x64, bs 24)
+        a_in.qin_bits == 0 && a_in.M / 32 <= use_ts * 4 * num_cus)      // beyond ~4 tiles per CU the barrier-free kernel is ahead (93 vs 106 us at 64x64, bs 24)
         return launch_conv3x3_tapsplit(a_in, num_cus, s);
     static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: work-skipping timing experiments
     ConvArgs a = a_in;

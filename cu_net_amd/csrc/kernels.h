@@ -43,5 +43,6 @@ hipError_t launch_quant_grad(const QuantEntry* tab, int nconv, int maxO, const f
                              int bits_w, int bits_g, int keep_scale, hipStream_t s);
 hipError_t launch_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int O, int C, int taps, int Opad, hipStream_t s);
 hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_ternary_pack_all(const TernPackEntry* tab, int n, const float* params, uint64_t* masks, hipStream_t s);
 
 }  // namespace cunet

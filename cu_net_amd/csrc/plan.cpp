@@ -430,6 +430,24 @@ void Plan::layout_workspace() {
     }
     off_wgred_tab = off;
     off += round_up64((int64_t)(n_wgred > 0 ? n_wgred : 1) * (int64_t)sizeof(WgReduceEntry), 256);
+    // QuanInput sites (3x3 convs and heads): bit-mask storage for the AND-popcount forward of the quantised-input mode
+    {
+        int64_t words = 0;
+        n_tern_sites = 0;
+        for (auto& n : nodes) {
+            if (n.type != N_CONV || !(n.taps == 9 || n.head >= 0)) continue;
+            ConvInfo& c = convs[n.conv];
+            const int G = (c.Cin + 63) / 64;
+            if (G > (n.taps == 9 ? 2 : 6)) continue;           // the kernel keeps the masks in registers
+            c.tern = words;
+            words += 2 * (int64_t)c.taps * G * round_up(c.Cout, 64);
+            ++n_tern_sites;
+        }
+        off_ternpack_tab = off;
+        off += round_up64((int64_t)(n_tern_sites > 0 ? n_tern_sites : 1) * (int64_t)sizeof(TernPackEntry), 256);
+        off_tern = off;
+        off += round_up64(words * 8, 256);
+    }
     loss_acc = n_zero_doubles;
     n_zero_doubles += 2;
     off_zero = off;

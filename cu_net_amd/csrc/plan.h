@@ -47,6 +47,7 @@ struct ConvInfo {
     int Cout, Cin, taps;
     int64_t w;                // param arena
     int64_t wF = -1, wB = -1; // workspace float offsets of the repacked operands
+    int64_t tern = -1;        // uint64 offset of the AND-popcount bit masks (wpos, then wneg) in the mask region; -1: not a QuanInput site
     int KpadF, NpadF, KpadB, NpadB;
 };
 
@@ -106,6 +107,8 @@ struct Plan {
     int64_t off_bf16 = 0, ws_bytes_bf16 = 0;     // bf16 inference: a bf16 arena of n_floats_infer elements behind the fp32 inference layout
     int64_t off_bf16_train = 0, ws_bytes_bf16_train = 0;   // the same arena behind the training layout (bf16 activations, fp32 gradients)
     int n_runstat = 0;
+    int64_t off_ternpack_tab = 0, off_tern = 0;   // pack table / bit-mask region of the quantised-input mode (bytes)
+    int n_tern_sites = 0;
     int64_t off_wgred_tab = 0;                // reduce table of the wgrad3 nodes (bytes), entries grouped by bucket
     int n_wgred = 0;
     std::vector<int> wgred_first, wgred_count;   // per bucket: slice of the reduce table

@@ -153,9 +153,40 @@ constexpr int TC_MAXG9 = 2;     // 3x3: C <= 128 (9 taps x 2 groups x 2 masks)
 
 template <int TAPS, int MAXG>
 __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    __shared__ float s_sc[64 * MAXG], s_sh[64 * MAXG];
+    __shared__ double s_red[2][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int G = (p.C + 63) >> 6;
+    // ---- BatchNorm folded to scale / shift: given (stand-alone operator) or derived here from the input tensor's batch
+    //      statistics (training) / the running statistics (eval), exactly as every other consumer kernel derives them
+    for (int c = tid; c < 64 * MAXG; c += 256) {
+        float sc = 0.f, sh = 0.f;
+        if (c < p.C) {
+            if (p.scale != nullptr) { sc = p.scale[c]; sh = p.shift[c]; }
+            else {
+                double mean, istd;
+                if (p.training) {
+                    const double sum = p.xstats[c], sq = p.xstats[p.C + c];
+                    mean = sum / p.count;
+                    double var = sq / p.count - mean * mean;
+                    var = var < 0.0 ? 0.0 : var;
+                    istd = 1.0 / sqrt(var + (double)BN_EPS);
+                } else {
+                    mean = (double)p.rmean[c];
+                    istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+                }
+                const double scale = (double)p.gamma[c] * istd;
+                sc = (float)scale;
+                sh = (float)((double)p.beta[c] - mean * scale);
+            }
+        }
+        s_sc[c] = sc; s_sh[c] = sh;
+    }
+    if (tid < 128) s_red[tid >> 6][tid & 63] = 0.0;
+    __syncthreads();
+
     const int o = blockIdx.y * 64 + lane;                 // this lane's output channel
     uint64_t P[TAPS][MAXG], N[TAPS][MAXG];
 #pragma unroll
@@ -172,6 +203,7 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
     const float qs = exp2f((float)nb);
     const int HW = p.H * p.W;
     const int nwaves = gridDim.x * 4;
+    double d1 = 0.0, d2 = 0.0;
     for (int m = blockIdx.x * 4 + wave; m < p.M; m += nwaves) {
         const int ni = m / HW;
         const int rem = m - ni * HW;
@@ -193,7 +225,7 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
                 const int c = 64 * g + lane;
                 int q = 0;
                 if (valid && c < p.C) {
-                    float a = fmaxf(fmaf(p.x[(size_t)row * p.C + c], p.scale[c], p.shift[c]), 0.f);
+                    float a = fmaxf(fmaf(p.x[(size_t)row * p.ldx + c], s_sc[c], s_sh[c]), 0.f);
                     a = fminf(a, 1.f - 1.f / qs);                          // C(x, bits_i); relu already >= 0
                     q = (int)rintf(a * qs);                                // Q(x, bits_i) * 2^(bits_i-1)
                 }
@@ -204,7 +236,48 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
                 }
             }
         }
-        if (o < p.O) p.y[(size_t)m * p.O + o] = (float)acc / qs;
+        const float yv = (float)acc / qs;
+        if (o < p.O) {
+            p.y[(size_t)m * p.ldy + o] = yv;
+            d1 += (double)yv;
+            d2 += (double)yv * (double)yv;
+        }
+    }
+    if (p.ystats != nullptr) {        // batch statistics of the output for the consumer BatchNorms
+        atomicAdd(&s_red[0][lane], d1);
+        atomicAdd(&s_red[1][lane], d2);
+        __syncthreads();
+        if (tid < 64 && o < p.O) {
+            __hip_atomic_fetch_add(p.ystats + o, s_red[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ystats + p.O + o, s_red[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// every conv of a table in one launch: blockIdx.y = table entry (same packing as ternary_pack_kernel)
+__global__ __launch_bounds__(256) void ternary_pack_all_kernel(const TernPackEntry* __restrict__ tab, const float* __restrict__ params,
+                                                               uint64_t* __restrict__ masks) {
+    const TernPackEntry e = tab[blockIdx.y];
+    const int G = (e.C + 63) >> 6;
+    const long total = (long)e.taps * G * e.Opad;
+    const float* w = params + e.src;
+    uint64_t* wpos = masks + e.dst;
+    uint64_t* wneg = wpos + total;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int o = (int)(i % e.Opad);
+        const int g = (int)((i / e.Opad) % G);
+        const int t = (int)(i / ((long)e.Opad * G));
+        uint64_t pp = 0, nn = 0;
+        if (o < e.O)
+            for (int c = 0; c < 64; ++c) {
+                const int ch = 64 * g + c;
+                if (ch >= e.C) break;
+                const float v = w[((size_t)o * e.C + ch) * e.taps + t];
+                if (v > 0.f) pp |= (uint64_t)1 << c;
+                if (v < 0.f) nn |= (uint64_t)1 << c;
+            }
+        wpos[i] = pp;
+        wneg[i] = nn;
     }
 }
 
@@ -234,6 +307,12 @@ __global__ __launch_bounds__(256) void ternary_pack_kernel(const float* __restri
 hipError_t launch_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int O, int C, int taps, int Opad, hipStream_t s) {
     const long total = (long)taps * ((C + 63) / 64) * Opad;
     hipLaunchKernelGGL(ternary_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wpos, wneg, O, C, taps, Opad);
+    return hipGetLastError();
+}
+
+hipError_t launch_ternary_pack_all(const TernPackEntry* tab, int n, const float* params, uint64_t* masks, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ternary_pack_all_kernel, dim3(5, n), dim3(256), 0, s, tab, params, masks);      // 9*2*64 = 1152 words at most
     return hipGetLastError();
 }
 

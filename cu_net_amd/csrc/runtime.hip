@@ -11,7 +11,7 @@
 #include "plan.h"
 
 enum { PC_C1F = 0, PC_C3F, PC_STEMF, PC_C1D, PC_C3D, PC_C1W, PC_C3W, PC_STEMW, PC_APPLY, PC_POOLF, PC_POOLB,
-       PC_STEMBPF, PC_STEMBPB, PC_MISC, PC_C1F16, PC_C3F16, PC_C1D16, PC_C3D16, PC_C1W16, CUNET_PROF_NCLS };
+       PC_STEMBPF, PC_STEMBPB, PC_MISC, PC_C1F16, PC_C3F16, PC_C1D16, PC_C3D16, PC_C1W16, PC_TERN, CUNET_PROF_NCLS };
 
 using namespace cunet;
 
@@ -30,6 +30,12 @@ struct cunet_plan {
     std::vector<RepackEntry> repack;
     std::vector<RunStatEntry> runstat;
     std::vector<WgReduceEntry> wgred;
+    // quantised-input mode (cunet_set_quant_input): per node the QuanInput bit width (0 = none) and whether its forward
+    // runs on the AND-popcount kernel; the pack table of those nodes' convs
+    int qin_bits = 0;
+    std::vector<int> node_qin, node_tern;
+    std::vector<TernPackEntry> ternpack;
+    int ternpack_dirty = 0;
     // call-order state
     int fwd_training_done = 0;
     int loss_done = 0;
@@ -58,7 +64,8 @@ static const char* kProfNames[CUNET_PROF_NCLS] = {
     "conv3x3_bwd_weight", "stem_bwd_weight", "bn_bwd_apply", "pool_fwd", "pool_bwd", "stem_bnpool_fwd",
     "stem_bnpool_bwd", "misc",
     // the same node classes when they run on bf16 MFMA (bf16 storage modes): priced against the bf16 peak
-    "conv1x1_fwd_bf16", "conv3x3_fwd_bf16", "conv1x1_bwd_data_bf16", "conv3x3_bwd_data_bf16", "conv1x1_bwd_weight_bf16"};
+    "conv1x1_fwd_bf16", "conv3x3_fwd_bf16", "conv1x1_bwd_data_bf16", "conv3x3_bwd_data_bf16", "conv1x1_bwd_weight_bf16",
+    "conv_fwd_popcount"};
 
 static hipError_t prof_begin(cunet_plan* h, int cls, hipStream_t s, int& slot) {
     slot = -1;
@@ -266,6 +273,36 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
     return CUNET_OK;
 }
 
+int cunet_set_quant_input(cunet_plan_t* h, int bits_i, const char* const* ternary_convs, int n_ternary) {
+    if (!h || (bits_i != 0 && (bits_i < 3 || bits_i > 15)) || n_ternary < 0 || (n_ternary > 0 && !ternary_convs))
+        return fail(CUNET_ERR_INVALID, "cunet_set_quant_input: bits_i must be 0 or 3..15");
+    Plan& P = h->plan;
+    h->qin_bits = bits_i;
+    h->node_qin.assign(P.nodes.size(), 0);
+    h->node_tern.assign(P.nodes.size(), 0);
+    h->ternpack.clear();
+    int count = 0;
+    if (bits_i > 0) {
+        for (size_t k = 0; k < P.nodes.size(); ++k) {
+            const Node& n = P.nodes[k];
+            if (n.type != N_CONV || !(n.taps == 9 || n.head >= 0)) continue;
+            h->node_qin[k] = bits_i;
+            const ConvInfo& c = P.convs[n.conv];
+            if (c.tern < 0) continue;
+            bool tern = false;
+            for (int i = 0; i < n_ternary && !tern; ++i) tern = ternary_convs[i] && c.name == ternary_convs[i];
+            if (!tern) continue;
+            h->node_tern[k] = 1;
+            TernPackEntry e{};
+            e.src = c.w; e.dst = c.tern; e.O = c.Cout; e.C = c.Cin; e.taps = c.taps; e.Opad = round_up(c.Cout, 64);
+            h->ternpack.push_back(e);
+            ++count;
+        }
+    }
+    h->ternpack_dirty = 1;
+    return count;
+}
+
 }  // extern "C"
 
 // ---- executor helpers -----------------------------------------------------------------------
@@ -403,6 +440,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
             a.training = 1;
             a.xbf16 = E.xmode;
+            a.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
             a.a = E.grad(n.out); a.lda = o.ld;
             a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
             a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
@@ -436,6 +474,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
             w.dw = h->grads + c.w;
             w.xbf16 = E.xmode;
+            w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
             if (n.wg3_S > 0 && wgrad3_supported(w) && (E.xmode != 2 || n.wg3_rows % 64 == 0)) {
                 // LDS-staged, atomics-free: partial tiles now, summed into the arena by the bucket's reduce (reduce_wgrad3)
                 PROF_ON(ws, E.xmode == 2 ? PC_C1W16 : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat, (E.xmode == 2 ? 2.0 : 4.0) * (double)w.M * (w.Cout + w.Ccat),
@@ -491,6 +530,15 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     const int cus = h->num_cus;
     HIPCHK(hipMemsetAsync(h->ws + P.off_zero, 0, (size_t)P.zero_bytes, s));
     HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
+    if (h->qin_bits && !h->ternpack.empty()) {          // bit masks of the convs that run on AND-popcount this pass
+        if (h->ternpack_dirty) {
+            HIPCHK(hipMemcpyAsync(h->ws + P.off_ternpack_tab, h->ternpack.data(), h->ternpack.size() * sizeof(TernPackEntry), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));             // (the host vector may change before an async copy has read it)
+            h->ternpack_dirty = 0;
+        }
+        HIPCHK(launch_ternary_pack_all(reinterpret_cast<const TernPackEntry*>(h->ws + P.off_ternpack_tab), (int)h->ternpack.size(), h->params,
+                                       reinterpret_cast<uint64_t*>(h->ws + P.off_tern), s));
+    }
     const bool fork_fwd = training && h->use_side && h->side && !h->done_ev.empty();
     h->pending.assign(P.tensors.size(), -1);
     hipStream_t s_main = s;
@@ -546,8 +594,25 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             a.K = n.Ccat; a.taps = c.taps; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            PROF(c.taps == 9 ? PC_C3F : PC_C1F, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + a.Nout),
-                 launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
+            a.qin_bits = h->qin_bits ? h->node_qin[ni] : 0;
+            if (a.qin_bits && h->node_tern[ni]) {
+                // ternary weights x quantised activations: multiplier-free AND-popcount forward (one input tensor: the
+                // bottleneck output for a 3x3 conv, the U-Net output for a head)
+                const TensorInfo& ti = P.tensors[n.segs[0].tensor];
+                const int64_t words = (int64_t)c.taps * ((c.Cin + 63) / 64) * round_up(c.Cout, 64);
+                TernArgs t{};
+                t.x = E.act(n.segs[0].tensor); t.ldx = ti.ld; t.scale = nullptr; t.shift = nullptr;
+                t.wpos = reinterpret_cast<const uint64_t*>(h->ws + P.off_tern) + c.tern; t.wneg = t.wpos + words;
+                t.y = E.act(n.out); t.ldy = o.ld;
+                t.M = (int)o.rows(); t.H = o.H; t.W = o.W; t.C = c.Cin; t.O = c.Cout; t.Opad = round_up(c.Cout, 64); t.taps = c.taps; t.bits_i = a.qin_bits;
+                t.xstats = E.stats(n.segs[0].tensor); t.count = (double)ti.rows();
+                t.gamma = a.gamma; t.beta = a.beta; t.rmean = a.rmean; t.rvar = a.rvar; t.training = training ? 1 : 0;
+                t.ystats = a.ystats;
+                PROF(PC_TERN, 0.0, 4.0 * (double)a.M * (a.K + a.Nout), launch_ternary_conv(t, cus, s));
+            } else {
+                PROF(c.taps == 9 ? PC_C3F : PC_C1F, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + a.Nout),
+                     launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
+            }
         }
         if (forked) {
             HIPCHK(hipEventRecord(h->done_ev[ni], h->side));
@@ -578,6 +643,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
     if (!h->ws) return fail(CUNET_ERR_STATE, "cunet_bind has not been called");
     Plan& P = h->plan;
     if (training && !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
+    if (h->qin_bits) return fail(CUNET_ERR_STATE, "the quantised-input mode (cunet_set_quant_input) is fp32 only");
     const int64_t off16 = h->bound_training ? P.off_bf16_train : P.off_bf16;
     if (h->ws_bytes < off16 + P.n_floats_infer * 2) return fail(CUNET_ERR_STATE, "workspace has no bf16 arena: size it with cunet_workspace_bytes(plan, 2 or 3)");
     hipStream_t s = (hipStream_t)stream;
@@ -865,6 +931,7 @@ int cunet_ternary_conv(const float* x, const float* scale, const float* shift, c
     TernArgs a{};
     a.x = x; a.scale = scale; a.shift = shift; a.wpos = wpos; a.wneg = wneg; a.y = y;
     a.M = n * hh * w; a.H = hh; a.W = w; a.C = c; a.O = o; a.Opad = round_up(o, 64); a.taps = taps; a.bits_i = bits_i;
+    a.ldx = c; a.ldy = o;
     hipError_t e = launch_ternary_conv(a, device_cus(), (hipStream_t)stream);
     if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? CUNET_ERR_INVALID : CUNET_ERR_HIP, std::string("ternary conv: ") + hipGetErrorString(e));
     return CUNET_OK;

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 float v = bv[u][a];
                 if (LD == WG_SEG) v = fmaxf(fmaf(v, xsc[a], xsh[a]), 0.f);
                 else if (LD == WG_3X3) v = fmaxf(fmaf(v, xsc[0], xsh[0]), 0.f);
+                if (LD != WG_STEM && p.qin_bits) v = quan_input_act(v, p.qin_bits);      // the conv saw QuanInput(relu(bn(x)))
                 v = ((vmask[u] >> a) & 1) ? v : 0.f;
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, v, acc[a], 0, 0, 0);
             }
@@ -409,6 +410,10 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
                 } else {
                     x[0] = (okk && cok) ? fmaxf(fmaf(X1[u], xsc[0], xsh[0]), 0.f) : 0.f;
                 }
+                if (p.qin_bits) {                       // heads behind a QuanInput2d (uniform branch)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) x[t] = quan_input_act(x[t], p.qin_bits);
+                }
                 issue_asm(mm + (u + PD) * 8, A4[u], A2[GB ? u : 0], X2[u], X1[u], OK[u]);        // refill this slot PD pairs ahead
 #pragma unroll
                 for (int ta = 0; ta < 4; ++ta)
@@ -445,6 +450,10 @@ __device__ __forceinline__ void wg2_body(const Wg2Args& q, const Wg2Group g, int
             for (int t = 0; t < CT; ++t)
                 x[t] = STEM ? (xok[u] ? xv[u][t] : 0.f)          // raw image, validity already applied per element
                             : ((xok[u] && cok) ? fmaxf(fmaf(xv[u][t], xsc[t], xsh[t]), 0.f) : 0.f);
+            if (!STEM && p.qin_bits) {
+#pragma unroll
+                for (int t = 0; t < CT; ++t) x[t] = quan_input_act(x[t], p.qin_bits);
+            }
             issue(m0 + (uu + WG2_PD) * stride, av[u], xv[u], xok[u]);       // refill this slot PD pairs ahead
 #pragma unroll
             for (int ta = 0; ta < NTW; ++ta)

@@ -56,6 +56,9 @@ class _BoundPlan:
                                _ptr(net._buffer_arena), _ptr(net._counter_arena), _ptr(self.workspace), nbytes,
                                1 if training_ws else 0, _stream_ptr(dev)), 'cunet_bind')
         self._cb_keepalive = None
+        self.popcount_nodes = 0
+        if net._quant_input[0] and not bf16:
+            self.popcount_nodes = self.handle.set_quant_input(*net._quant_input)
 
     def forward(self, x: torch.Tensor, training: bool, want_outputs: bool = True) -> List[torch.Tensor]:
         n, h, w = self.shape
@@ -213,6 +216,7 @@ class CUNet(nn.Module):
         self._build_tree()
         self._reference_init()
         self._plans: Dict[Tuple[int, int, int], _BoundPlan] = {}
+        self._quant_input = (0, ())        # (bits_i, ternary conv names): see set_quant_input
         self._param_arena = None
         self._flatten(torch.device('cpu'))
 
@@ -353,6 +357,16 @@ class CUNet(nn.Module):
             plan = _BoundPlan(self, n, h, w, need_grad, bf16=bf16)
             self._plans[key] = plan
         return plan
+
+    def set_quant_input(self, bits_i: int = 8, ternary_convs=()):
+        """Quantised-input mode: the reference's QuanInput2d (utils/quantize.py:47-73) between the ReLU and every 3x3 conv and
+        every head conv, where models/cu_net_prev_version_wig.py:96-98,277-279 places it.  `ternary_convs`: module paths of
+        convs whose weights are kept in {-1, 0, +1} during forward / backward (QuanOp targets at bits_w 1 or 2): their
+        forward runs on the AND-popcount kernel.  bits_i = 0 switches the mode off.  Applies to every (batch, H, W) plan."""
+        self._quant_input = (int(bits_i), tuple(ternary_convs))
+        for key, plan in self._plans.items():
+            if not plan.bf16:
+                plan.popcount_nodes = plan.handle.set_quant_input(*self._quant_input)
 
     def forward_bf16(self, x):
         """Inference with bf16 storage: activations and weights are bf16 between the stem and the heads, contracted

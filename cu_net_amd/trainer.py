@@ -18,7 +18,8 @@ from .module import CUNet, _ptr, _stream_ptr
 
 class FusedTrainer:
     def __init__(self, net: CUNet, lr: float = 2.5e-4, alpha: float = 0.99, eps: float = 1e-8,
-                 process_group=None, overlap: bool = True, quan_op=None, bf16: bool = False, bf16_grads: bool = False):
+                 process_group=None, overlap: bool = True, quan_op=None, bf16: bool = False, bf16_grads: bool = False,
+                 quan_input_bits: int = 0, popcount: bool = False):
         """RMSprop hyper-parameters default to cu-net.py:60-61. `process_group`: a torch.distributed
         group (backend nccl == RCCL) for data parallelism, or None."""
         if not isinstance(net, CUNet):
@@ -30,6 +31,21 @@ class FusedTrainer:
         self.bf16_grads = bool(bf16_grads)           # ... and the gradient tensors of backward (dY, dz, dX) stored as bf16 too
         self.steps_done = 0           # optimiser steps taken (the `step` entry of torch's RMSprop state)
         self.quan_op = quan_op        # cu_net_amd.quant.QuanOp / BinOp: quantised training (cu-net-prev-version-wig.py:163-190)
+        # QuanInput2d in front of the 3x3 and head convs (the reference's quantised model places it there); with `popcount`
+        # the forward of those convs whose weights QuanOp keeps ternary (bits_w 1 / 2) runs on the AND-popcount kernel
+        if popcount and not quan_input_bits:
+            quan_input_bits = getattr(quan_op, 'bits_i', 8) or 8
+        if quan_input_bits:
+            if self.bf16:
+                raise CUNetError('the quantised-input mode is fp32 only')
+            tern = ()
+            if popcount:
+                if quan_op is None or quan_op.bits_w not in (1, 2) or quan_op.keep_scale:
+                    raise CUNetError('popcount=True needs a QuanOp with bits_w 1 or 2 (ternary weights during forward / backward)')
+                tern = tuple(quan_op.target_names)
+            net.set_quant_input(quan_input_bits, tern)
+        self.quan_input_bits = int(quan_input_bits)
+        self.popcount = bool(popcount)
         self.pg = process_group
         self.world = 1
         self.overlap = overlap

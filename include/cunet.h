@@ -158,6 +158,18 @@ int cunet_quant_restore(float* params, const float* saved, const void* table, in
 int cunet_quant_grad(const float* params, float* grads, const void* table, int nconv, int max_o,
                      int bits_w, int bits_g, int keep_scale, void* stream);
 
+/* ---- quantised-input mode of a plan: the QuanInput2d placement of the reference's quantised model
+ * (models/cu_net_prev_version_wig.py:96-98 before every 3x3 conv, :277-279 before every head conv; utils/quantize.py:47-73)
+ * on this network: an activation quantiser of bits_i bits (3..15) between the ReLU and those convs -- forward
+ * Q(C(x, bits_i), bits_i), backward straight-through with no gradient where the activation is >= 1; the weight gradient
+ * of such a conv contracts d(loss)/d(out) with the quantised activation.  bits_i = 0 switches the mode off.
+ * ternary_convs: module paths (e.g. "hg.down_blocks.0.layers.0.conv2") of those convs whose weights the caller keeps in
+ * {-1, 0, +1} across forward/backward (QuanOp with bits_w 1 or 2, utils/quantize.py:125-149): their FORWARD then runs on
+ * the multiplier-free AND-popcount kernel (below) instead of MFMA -- bit-identical results, every partial sum being a
+ * multiple of 2^-(bits_i-1).  Other quantised-input convs (e.g. the last head, which QuanOp leaves alone) stay on MFMA
+ * with the quantiser folded into their operand loads.  fp32 plans only.  Returns the number of popcount nodes (>= 0). */
+int cunet_set_quant_input(cunet_plan_t* plan, int bits_i, const char* const* ternary_convs, int n_ternary);
+
 /* ---- multiplier-free ternary convolution (AND + popcount over activation bit-planes): the non-MFMA
  * alternative for conv weights in {-1,0,+1} on bits_i-bit activations (QuanInput2d placement,
  * models/cu_net_prev_version_wig.py:96-98,277-279).  cunet_ternary_pack turns torch-layout weights

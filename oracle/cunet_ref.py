@@ -140,15 +140,36 @@ def init_state(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
 
 class _Ctx:
     """Per-forward bookkeeping: which BNs the reference would re-run in backward."""
-    def __init__(self, state, training):
+    def __init__(self, state, training, quan_input_bits=0):
         self.state = state
         self.training = training
         self.recomputed: List[Tuple[str, torch.Tensor]] = []
+        self.quan_input_bits = quan_input_bits
+
+
+class _QuanInputFn(torch.autograd.Function):
+    """utils/quantize.py:47-63 as a modern autograd Function: forward Q(C(x, bits), bits), backward straight-through
+    with no gradient where |x| >= 1.  Forward / backward are oracle/quant_ref.py's quan_input / quan_input_backward,
+    which tools/gen_golden.py pins to the EXECUTED reference class (G14)."""
+
+    @staticmethod
+    def forward(ctx, x, bits):
+        from oracle import quant_ref as QR
+        ctx.save_for_backward(x)
+        return QR.quan_input(x, bits)
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import quant_ref as QR
+        (x,) = ctx.saved_tensors
+        return QR.quan_input_backward(x, g), None
 
 
 def _bn_relu_conv(ctx: _Ctx, inputs: List[torch.Tensor], bn: str, conv: str, pad: int,
-                  checkpointed: bool) -> torch.Tensor:
-    """cat -> BN -> ReLU -> conv  (models/cu_net.py:11-17)."""
+                  checkpointed: bool, quan_site: bool = False) -> torch.Tensor:
+    """cat -> BN -> ReLU -> conv  (models/cu_net.py:11-17).  `quan_site`: one of the places where the reference's
+    quantised model puts a QuanInput2d between the ReLU and the conv (models/cu_net_prev_version_wig.py:96-98 the 3x3
+    convs, :277-279 the heads); active when the forward was asked for quantised inputs."""
     st = ctx.state
     x = torch.cat(inputs, 1) if len(inputs) > 1 else inputs[0]
     if ctx.training:
@@ -158,6 +179,8 @@ def _bn_relu_conv(ctx: _Ctx, inputs: List[torch.Tensor], bn: str, conv: str, pad
     y = F.batch_norm(x, st[bn + '.running_mean'], st[bn + '.running_var'],
                      st[bn + '.weight'], st[bn + '.bias'], ctx.training, BN_MOMENTUM, BN_EPS)
     y = F.relu(y)
+    if quan_site and ctx.quan_input_bits:
+        y = _QuanInputFn.apply(y, ctx.quan_input_bits)
     return F.conv2d(y, st[conv + '.weight'], None, 1, pad)
 
 
@@ -167,7 +190,7 @@ def _dense_block(ctx: _Ctx, prefix: str, xs: List[torch.Tensor], i: int, saved: 
     xs = list(xs) + list(saved)
     p = f'{prefix}.layers.{i}'
     z = _bn_relu_conv(ctx, xs, f'{p}.norm1', f'{p}.conv1', 0, True)       # :53-61 (checkpointed)
-    out = _bn_relu_conv(ctx, [z], f'{p}.norm2', f'{p}.conv2', 1, False)   # :62
+    out = _bn_relu_conv(ctx, [z], f'{p}.norm2', f'{p}.conv2', 1, False, quan_site=True)   # :62
     if i < order:                                                          # :133-137
         saved.append(out)
     elif len(saved) != 0:
@@ -184,14 +207,14 @@ def _dense_block(ctx: _Ctx, prefix: str, xs: List[torch.Tensor], i: int, saved: 
 
 
 def forward(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor,
-            training: bool = True, ctx_out: list | None = None) -> List[torch.Tensor]:
+            training: bool = True, ctx_out: list | None = None, quan_input_bits: int = 0) -> List[torch.Tensor]:
     """`_CU_Net_Wrapper.forward` (models/cu_net.py:336-360).
 
     In training mode BN running statistics in `state` are updated in place exactly once per
     BN (the effect of the reference's *forward*); `finish_backward_stat_updates` applies the
     extra update the reference's checkpoint recompute performs during `backward()`.
     """
-    ctx = _Ctx(state, training)
+    ctx = _Ctx(state, training, quan_input_bits)
     st = state
     # stem, :299-304
     y = F.conv2d(x, st['features.conv0.weight'], None, 2, 3)
@@ -238,7 +261,7 @@ def forward(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor,
         cur = h
         if (i + 1) in spec.loss_anchors:                                   # :353-356
             p = f'linears.{i}'
-            outs.append(_bn_relu_conv(ctx, [cur], f'{p}.norm', f'{p}.conv', 0, False))
+            outs.append(_bn_relu_conv(ctx, [cur], f'{p}.norm', f'{p}.conv', 0, False, quan_site=True))
     if ctx_out is not None:
         ctx_out.append(ctx)
     return outs
@@ -277,7 +300,7 @@ def conv_weight_names(spec: Spec) -> List[str]:
 
 def train_step(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor, target: torch.Tensor,
                opt_state: Dict[str, torch.Tensor] | None = None, lr: float = 2.5e-4,
-               alpha: float = 0.99, eps: float = 1e-8, apply_update: bool = True, quant=None):
+               alpha: float = 0.99, eps: float = 1e-8, apply_update: bool = True, quant=None, quan_input_bits: int = 0):
     """One optimisation step (cu-net.py:171-183) with RMSprop(lr, alpha, eps) (cu-net.py:60-61).
 
     `quant=(bits_w, bits_g)` wraps the step in QuanOp.quantization / restore / updateQuanGradWeight
@@ -302,7 +325,7 @@ def train_step(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor, targ
         state[n].requires_grad_(True)
         state[n].grad = None
     ctxs: list = []
-    outs = forward(spec, state, x, True, ctxs)
+    outs = forward(spec, state, x, True, ctxs, quan_input_bits=quan_input_bits)
     loss = mse_loss(outs, target)
     loss.backward()
     finish_backward_stat_updates(ctxs[0])

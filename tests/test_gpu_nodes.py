@@ -66,6 +66,26 @@ def test_every_node_backward_full_width_wgrad3(mode):
     _check_all_nodes(cfg, st, x, bf16=mode, wgrad3_all=True)
 
 
+@pytest.mark.parametrize('tag', ['full', 'G9_L2_o1_c32'])
+def test_every_node_backward_with_quan_input(tag):
+    """Quantised-input mode (QuanInput2d in front of the 3x3 convs and the heads, utils/quantize.py:47-63): the data
+    gradient applies the straight-through mask (no gradient where the activation is >= 1) and the weight gradient contracts
+    with the QUANTISED activation -- node by node against torch autograd through the oracle's QuanInput function."""
+    from oracle import cunet_ref as O
+    if tag == 'full':
+        cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+        spec = O.Spec(**cfg)
+        st = O.init_state(spec, seed=29)
+        x, _ = O.synthetic_batch(1, 68, 256, seed=30)
+    else:
+        g = Golden(tag)
+        cfg, st, x = g.cfg, g.group('state0'), g.t('x')
+    for k in st:                                       # wider BatchNorm outputs: plenty of activations beyond 1 (the STE mask acts)
+        if k.endswith('norm2.weight') or k.endswith('.norm.weight'):
+            st[k] = st[k] * 2.0
+    _check_all_nodes(cfg, st, x, quan_input_bits=8)
+
+
 def test_every_node_backward_full_width_bf16_activations():
     """The same node-by-node check with bf16 activation storage (FusedTrainer(bf16=True)): the backward kernels read x
     as bf16 and compute in fp32, so against torch autograd fed with the SAME bf16-rounded activations the fp32 tolerance
@@ -91,22 +111,24 @@ def test_every_node_backward_full_width_bf16_gradient_tensors():
     _check_all_nodes(cfg, st, x, bf16=2)
 
 
-def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False):
+def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0):
     """wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
     False: the planner is told to keep them on the per-wave atomic kernel (wgrad2), which stays the path of narrow heads,
     non-32-multiple concats and the stem and must remain covered at production widths."""
     from cu_net_amd._lib import set_planner_option
     set_planner_option('wgrad3_min_rows', 0 if wgrad3_all else 1 << 30)
     try:
-        _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all)
+        _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits)
     finally:
         set_planner_option('wgrad3_min_rows', 0)
 
 
-def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all):
+def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
+    if quan_input_bits:
+        net.set_quant_input(quan_input_bits, ())        # QuanInput2d sites on MFMA (weights are not ternary here)
     n, _, h, w = x.shape
     plan = net._get_plan(n, h, w, True, bf16=bf16)
     xd = x.cuda()
@@ -147,6 +169,9 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all):
                 wt = wt.bfloat16().float()              # the bf16-MFMA data gradient contracts with bf16-rounded weights
             wt.requires_grad_(True)
             act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
+            if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
+                from oracle.cunet_ref import _QuanInputFn       # QuanInput2d site: quantised forward, straight-through backward
+                act = _QuanInputFn.apply(act, quan_input_bits)
             if gb and nd.get('wg3', 0) > 0:
                 # the bf16-MFMA weight gradient contracts dY with the bf16-ROUNDED activation -- exactly the operand the bf16
                 # forward multiplied the weights with, i.e. the exact gradient of that forward (straight-through here)

@@ -185,3 +185,70 @@ def test_quantised_train_step_matches_oracle(bits_w):
     for n in convs[1:-1][:8]:
         lat = QR.quantization(st[n], bits_w, 8)[1]
         assert (sd[n].cpu() - lat).abs().max().item() <= 10 * 2.5e-4 * 1.01 + 1 / 128 + 1e-6
+
+
+def test_popcount_forward_is_the_mfma_forward():
+    """Quantised-input mode with ternary weights: the AND-popcount forward of the 3x3 / head convs against the SAME convs
+    on MFMA with the quantiser folded into the operand loads.  Every product is +-q/128 and every partial sum a multiple
+    of 2^-7 below 2^17, so both are exact: the first 3x3 conv's output is bit-identical; downstream tensors may differ in
+    the last bit only through the order of the fp64 statistics atomics of the fp32 nodes in between."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=33)
+    x, _ = O.synthetic_batch(2, 16, 256, seed=34)
+    outs, first = {}, {}
+    for mode in ('mfma', 'popcount'):
+        net = cu_net_amd.create_cu_net(**cfg)
+        net.load_state_dict(st)
+        net = net.cuda().train()
+        qop = QuanOp(net, bits_w=1, bits_i=8, bits_g=8)
+        qop.quantization()                                    # weights in {-1, 0, +1} from here on
+        net.set_quant_input(8, qop.target_names if mode == 'popcount' else ())
+        plan = net._get_plan(2, 256, 256, True)
+        assert plan.popcount_nodes == (2 * 9 + 1 if mode == 'popcount' else 0)      # every 3x3 conv + the first head (the last conv is not a QuanOp target)
+        with torch.no_grad():
+            outs[mode] = [o.cpu() for o in net(x.cuda())]
+        first[mode] = plan.debug_tensor('hg.down_blocks.0.layers.0.conv2').cpu()
+    assert torch.equal(first['mfma'], first['popcount'])
+    assert float(first['mfma'].abs().max()) > 1.0 and torch.equal(first['mfma'] * 128, torch.round(first['mfma'] * 128))
+    for a, b in zip(outs['mfma'], outs['popcount']):
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+
+
+@pytest.mark.parametrize('popcount', [False, True])
+def test_quantised_input_train_step_matches_oracle(popcount):
+    """cu-net-prev-version-wig.py:163-190 with the quantised model's QuanInput2d sites: QuanOp(bits_w=1) + QuanInput(8 bits)
+    in one fused step (popcount forward or MFMA forward) against the oracle's step with the same placement."""
+    from cu_net_amd.trainer import FusedTrainer
+    from oracle import cunet_ref as O
+    from tests._golden import Golden
+    g = Golden('G9_L2_o1_c32')
+    spec = O.Spec(**g.cfg)
+    st = g.group('state0')
+    for n in O.conv_weight_names(spec):
+        st[n] = st[n] * 8.0
+    x, target = g.t('x'), g.t('target')
+    net = cu_net_amd.create_cu_net(**g.cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    tr = FusedTrainer(net, quan_op=QuanOp(net, bits_w=1, bits_i=8, bits_g=8), quan_input_bits=8, popcount=popcount)
+    loss = tr.step(x.cuda(), target.cuda())
+    outs = tr.last_outputs(x.shape)
+    plan = net._get_plan(*[x.shape[0], x.shape[2], x.shape[3]], True)
+    assert (plan.popcount_nodes > 0) == popcount
+    ref_state = {k: v.clone() for k, v in st.items()}
+    ref_loss, ref_outs, ref_grads = O.train_step(spec, ref_state, x, target, quant=(1, 8), quan_input_bits=8)
+    # an activation within rounding of a quantiser step may land on the neighbouring level (1/128 of a +-1-weighted sum)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    for a, b in zip(outs, ref_outs):
+        assert ((a.cpu() - b).double().norm() / b.double().norm()).item() <= 2e-3
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    convs = O.conv_weight_names(spec)
+    num = den = 0.0
+    for n in convs[1:-1]:
+        o, nmel, shape = off[n]
+        got = net._grad_arena[o:o + nmel].view(shape).cpu()
+        assert torch.equal(got * 128, torch.round(got * 128))
+        num += float((got - ref_grads[n]).double().pow(2).sum()); den += float(ref_grads[n].double().pow(2).sum())
+    assert (num / den) ** 0.5 <= 0.25, (num / den) ** 0.5
