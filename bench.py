@@ -167,7 +167,8 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
 
     # ---- timed region: exactly `steps` steps; HIP events only around the dominant class, one event per step
     plan.handle.profile_reset()
-    plan.handle.profile_begin(2, plan.handle.profile_class_index(dominant))
+    if not os.environ.get('CUNET_BENCH_NO_CLASS_EVENTS'):      # (tools only: how much do the per-launch events cost?)
+        plan.handle.profile_begin(2, plan.handle.profile_class_index(dominant))
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     barrier()
     t0 = time.perf_counter()

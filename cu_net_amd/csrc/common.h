@@ -104,6 +104,7 @@ struct WgReduceEntry {     // grads[dst + i] = sum_s ws[part + s*numel + i]
     int64_t part;          // float offset in the workspace float region
     int64_t dst;           // float offset in the gradient arena
     int S, numel;
+    int taps, pad_;        // > 1: the partials are [taps][numel / taps] and the destination is torch's [numel / taps][taps]
 };
 
 constexpr int MAXGSRC = 8;  // conv consumers gathered per launch (more: further launches with accumulate = 1)

@@ -10,6 +10,8 @@ hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStr
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
 bool wgrad3_supported(const WgradArgs& a);
 hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
+bool wgrad3_3x3_supported(const WgradArgs& a);
+hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
 hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, const float* ws, float* grads, hipStream_t s);
 hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_bn_param_grad(const BnParamGradArgs& a, hipStream_t s);

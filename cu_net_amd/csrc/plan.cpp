@@ -403,15 +403,33 @@ void Plan::layout_workspace() {
         const PlannerOptions& po = planner_options();
         const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits));
         const int min_m = tune_int("CUNET_WG3_MIN_M", po.wgrad3_min_rows), enable = tune_int("CUNET_WG3", 1);
+        const int enable3 = tune_int("CUNET_WG3_3X3", 1), min_rows3 = std::max(1, tune_int("CUNET_WG3_3X3_ROWS", 6));     // image rows per workgroup
         const int nb = cfg.layer_num + 1;
         wgred_first.assign(nb, 0); wgred_count.assign(nb, 0); wgred_maxnumel.assign(nb, 0);
         n_wgred = 0;
         for (int b = 0; b < nb; ++b) {
             wgred_first[b] = n_wgred;
             for (auto& n : nodes) {
-                if (n.type != N_CONV || n.bucket != b || n.taps != 1 || !enable) continue;
+                if (n.type != N_CONV || n.bucket != b || !enable) continue;
                 const ConvInfo& c = convs[n.conv];
                 const TensorInfo& o = tensors[n.out];
+                if (n.taps == 9) {
+                    // 3x3: LDS ring of image rows (wgrad3_3x3_kernel); splits are ranges of image rows
+                    const TensorInfo& xi = tensors[n.segs[0].tensor];
+                    const bool ok3 = enable3 && c.Cout == 32 && o.ld == 32 && n.Ccat == 128 && n.segs.size() == 1 && !n.segs[0].ups &&
+                                     xi.C == 128 && xi.ld % 4 == 0 && o.W >= 2 && o.W <= 64 && o.W % 2 == 0 && o.rows() >= min_m;
+                    if (!ok3) continue;
+                    const int64_t NH = (int64_t)o.N * o.H;
+                    int64_t S = (NH + min_rows3 - 1) / min_rows3;
+                    if (S > smax) S = smax;
+                    if (S < 1) S = 1;
+                    const int64_t rows = (NH + S - 1) / S;
+                    S = (NH + rows - 1) / rows;
+                    n.wg3_S = (int)S; n.wg3_rows = (int)rows; n.wg3_entry = n_wgred++;
+                    wgred_count[b]++;
+                    wgred_maxnumel[b] = std::max(wgred_maxnumel[b], c.Cout * n.Ccat * 9);
+                    continue;
+                }
                 bool ok = c.Cout == 128 && o.ld == 128 && n.Ccat % 32 == 0 && n.Ccat >= 128 && o.rows() >= min_m;
                 for (auto& sr : n.segs) ok = ok && tensors[sr.tensor].C % 4 == 0 && tensors[sr.tensor].ld % 4 == 0;
                 if (!ok) continue;
@@ -429,7 +447,7 @@ void Plan::layout_workspace() {
         }
     }
     off_wgred_tab = off;
-    off += round_up64((int64_t)(n_wgred > 0 ? n_wgred : 1) * (int64_t)sizeof(WgReduceEntry), 256);
+    off += round_up64((int64_t)2 * (n_wgred > 0 ? n_wgred : 1) * (int64_t)sizeof(WgReduceEntry), 256);      // one copy per gradient-storage mode
     // QuanInput sites (3x3 convs and heads): bit-mask storage for the AND-popcount forward of the quantised-input mode
     {
         int64_t words = 0;
@@ -482,7 +500,7 @@ void Plan::layout_workspace() {
         for (int b = 0; b <= cfg.layer_num; ++b) {
             int64_t sum = 0;
             for (auto& n : nodes)
-                if (n.wg3_S > 0 && n.bucket == b) { n.wg3_part = sum; sum += round_up64((int64_t)n.wg3_S * convs[n.conv].Cout * n.Ccat, 64); }
+                if (n.wg3_S > 0 && n.bucket == b) { n.wg3_part = sum; sum += round_up64((int64_t)n.wg3_S * convs[n.conv].Cout * n.Ccat * n.taps, 64); }
             region = std::max(region, sum);
         }
         const int64_t base = take(region);

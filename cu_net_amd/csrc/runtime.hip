@@ -59,6 +59,19 @@ struct cunet_plan {
     long prof_count[CUNET_PROF_NCLS] = {0};
 };
 
+// Does node `n` take the LDS-staged partial-tile weight gradient in gradient-storage mode `xmode`?  (One predicate for the
+// dispatch in bwd_node and for the reduce tables built at bind.)
+static bool wg3_active(const Plan& P, const Node& n, int xmode) {
+    if (n.wg3_S <= 0) return false;
+    if (n.taps == 9) return xmode != 2;                          // the 3x3 ring kernel reads fp32 d(loss)/d(out)
+    if (xmode == 2) {                                            // bf16 MFMA variant: 16-byte pieces of 8 bf16 channels
+        if (n.wg3_rows % 64) return false;
+        for (auto& sr : n.segs)
+            if (P.tensors[sr.tensor].C % 8 || P.tensors[sr.tensor].ld % 8) return false;
+    }
+    return true;
+}
+
 static const char* kProfNames[CUNET_PROF_NCLS] = {
     "conv1x1_fwd", "conv3x3_fwd", "stem_conv_fwd", "conv1x1_bwd_data", "conv3x3_bwd_data", "conv1x1_bwd_weight",
     "conv3x3_bwd_weight", "stem_bwd_weight", "bn_bwd_apply", "pool_fwd", "pool_bwd", "stem_bnpool_fwd",
@@ -240,11 +253,18 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         }
     }
     if ((int)h->runstat.size() != P.n_runstat) return fail(CUNET_ERR_STATE, "internal: running-stat table size");
-    h->wgred.assign((size_t)(P.n_wgred > 0 ? P.n_wgred : 1), WgReduceEntry{});
+    // two copies of the reduce table: [0, n) for fp32 gradient tensors, [n, 2n) for bf16 gradient tensors, where the nodes
+    // that stay on the atomic kernels in that mode (3x3 convs) have S = 0 and are skipped by the reduce
+    const int nwg = P.n_wgred > 0 ? P.n_wgred : 1;
+    h->wgred.assign((size_t)2 * nwg, WgReduceEntry{});
     for (auto& n : P.nodes)
         if (n.wg3_S > 0) {
-            WgReduceEntry& e = h->wgred[n.wg3_entry];
-            e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.S = n.wg3_S; e.numel = P.convs[n.conv].Cout * n.Ccat;
+            for (int mode = 0; mode < 2; ++mode) {
+                WgReduceEntry& e = h->wgred[(size_t)mode * nwg + n.wg3_entry];
+                e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.numel = P.convs[n.conv].Cout * n.Ccat * n.taps;
+                e.taps = n.taps; e.pad_ = 0;
+                e.S = wg3_active(P, n, mode ? 2 : 0) ? n.wg3_S : 0;
+            }
         }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(h->ws + P.off_wgred_tab, h->wgred.data(), h->wgred.size() * sizeof(WgReduceEntry), hipMemcpyHostToDevice, s));
@@ -410,7 +430,8 @@ static int reduce_wgrad3(cunet_plan* h, int first, int count, int max_numel, hip
     Exec E(h);
     if (count <= 0) return CUNET_OK;
     Plan& P = h->plan;
-    const WgReduceEntry* tab = reinterpret_cast<const WgReduceEntry*>(h->ws + P.off_wgred_tab) + first;
+    const int nwg = P.n_wgred > 0 ? P.n_wgred : 1;
+    const WgReduceEntry* tab = reinterpret_cast<const WgReduceEntry*>(h->ws + P.off_wgred_tab) + (E.xmode == 2 ? nwg : 0) + first;
     PROF_ON(s, PC_MISC, 0.0, 0.0, launch_wgrad_reduce(tab, count, max_numel, E.wsf, h->grads, s));
     return CUNET_OK;
 }
@@ -475,7 +496,11 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             w.dw = h->grads + c.w;
             w.xbf16 = E.xmode;
             w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
-            if (n.wg3_S > 0 && wgrad3_supported(w) && (E.xmode != 2 || n.wg3_rows % 64 == 0)) {
+            if (c.taps == 9 && wg3_active(P, n, E.xmode) && wgrad3_3x3_supported(w)) {
+                // LDS ring of activated image rows, partial tiles [split][tap][n][c] (reduced + transposed per bucket)
+                PROF_ON(ws, PC_C3W, 2.0 * w.M * w.Cout * w.Ccat * 9, 4.0 * (double)w.M * (w.Cout + w.Ccat),
+                        launch_wgrad3_3x3(w, E.wsf + n.wg3_part, n.wg3_S, n.wg3_rows, ws));
+            } else if (c.taps == 1 && wg3_active(P, n, E.xmode) && wgrad3_supported(w)) {
                 // LDS-staged, atomics-free: partial tiles now, summed into the arena by the bucket's reduce (reduce_wgrad3)
                 PROF_ON(ws, E.xmode == 2 ? PC_C1W16 : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat, (E.xmode == 2 ? 2.0 : 4.0) * (double)w.M * (w.Cout + w.Ccat),
                         launch_wgrad3(w, E.wsf + n.wg3_part, n.wg3_S, n.wg3_rows, ws));
@@ -949,7 +974,7 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     const int rc = bwd_node(h, n, node, s);
     if (rc != CUNET_OK) return rc;
     if (n.wg3_S > 0) {
-        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, P.convs[n.conv].Cout * n.Ccat, (h->use_side && h->side) ? h->side : s);
+        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, P.convs[n.conv].Cout * n.Ccat * n.taps, (h->use_side && h->side) ? h->side : s);
         if (rcr != CUNET_OK) return rcr;
     }
     if (n.type == N_CONV) {                // this node's contribution to each of its inputs, and its BN parameter gradients
