@@ -48,10 +48,10 @@ def test_rmsprop_step_matches_torch(n, gscale):
         ulp = torch.finfo(torch.float32).eps
         dv = (v.cpu() - vref).abs()
         assert bool((dv <= 2 * ulp * vref.abs() + 1e-45).all()), float((dv / (vref.abs() + 1e-30)).max())
-        # p' = p - lr * g / (sqrt(v) + eps): 1 ulp of p + 8 ulp of every update applied so far (torch divides
+        # p' = p - lr * g / (sqrt(v) + eps): 1 ulp of p + 16 eps (2e-6 relative) of every update applied so far (torch divides
         # (lr * g) / (sqrt(v) + eps), the kernel multiplies lr * (g / (sqrt(v) + eps)); v itself is within 2 ulp)
         dp = (p.cpu() - ref.detach()).abs()
-        carried += 8 * ulp * lr * (gr * gscale).abs() / (vref.sqrt() + eps)
+        carried += 16 * ulp * lr * (gr * gscale).abs() / (vref.sqrt() + eps)
         bound = 1.0 * ulp * ref.detach().abs() + carried + 1e-45
         assert bool((dp <= bound).all()), float((dp / bound).max())
 
