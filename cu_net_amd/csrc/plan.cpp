@@ -404,6 +404,7 @@ void Plan::layout_workspace() {
         const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits));
         const int min_m = tune_int("CUNET_WG3_MIN_M", po.wgrad3_min_rows), enable = tune_int("CUNET_WG3", 1);
         const int enable3 = tune_int("CUNET_WG3_3X3", 1), min_rows3 = std::max(1, tune_int("CUNET_WG3_3X3_ROWS", 6));     // image rows per workgroup
+        const int min_w3 = tune_int("CUNET_WG3_3X3_MIN_W", 2);        // narrower levels keep the per-wave kernel
         const int nb = cfg.layer_num + 1;
         wgred_first.assign(nb, 0); wgred_count.assign(nb, 0); wgred_maxnumel.assign(nb, 0);
         n_wgred = 0;
@@ -417,7 +418,7 @@ void Plan::layout_workspace() {
                     // 3x3: LDS ring of image rows (wgrad3_3x3_kernel); splits are ranges of image rows
                     const TensorInfo& xi = tensors[n.segs[0].tensor];
                     const bool ok3 = enable3 && c.Cout == 32 && o.ld == 32 && n.Ccat == 128 && n.segs.size() == 1 && !n.segs[0].ups &&
-                                     xi.C == 128 && xi.ld % 4 == 0 && o.W >= 2 && o.W <= 64 && o.W % 2 == 0 && o.rows() >= min_m;
+                                     xi.C == 128 && xi.ld % 4 == 0 && o.W >= 2 && o.W >= min_w3 && o.W <= 64 && o.W % 2 == 0 && o.rows() >= min_m;
                     if (!ok3) continue;
                     const int64_t NH = (int64_t)o.N * o.H;
                     int64_t S = (NH + min_rows3 - 1) / min_rows3;
