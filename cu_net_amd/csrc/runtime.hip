@@ -63,7 +63,7 @@ struct cunet_plan {
 // dispatch in bwd_node and for the reduce tables built at bind.)
 static bool wg3_active(const Plan& P, const Node& n, int xmode) {
     if (n.wg3_S <= 0) return false;
-    if (n.taps == 9) return xmode != 2;                          // the 3x3 ring kernel reads fp32 d(loss)/d(out)
+    if (n.taps == 9) return true;                                // (bf16 x / dY are widened to fp32 on the way into LDS)
     if (xmode == 2) {                                            // bf16 MFMA variant: 16-byte pieces of 8 bf16 channels
         if (n.wg3_rows % 64) return false;
         for (auto& sr : n.segs)

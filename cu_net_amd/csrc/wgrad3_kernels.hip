@@ -609,8 +609,9 @@ hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, c
 // bucket's reduce kernel sums the splits and transposes into torch's [n][c][tap].
 constexpr int WG3C_C = 128, WG3C_N = 32;
 
-template <int XB>
+template <int XBG>      // 0: fp32 x and dY; 1: bf16 x; 2: bf16 x and bf16 dY (both widened to fp32 on the way into LDS; fp32 MFMA)
 __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_kernel(const Wg3Args q) {
+    constexpr int XB = XBG != 0, GB = XBG == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgradArgs& p = q.w;
     const int W = p.W, H = p.H;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_kernel(const Wg3Arg
     };
     auto issue_a = [&](int g) {
         arow_ok = g < g_end;
-        av = ldg4(p.dy + ((size_t)(arow_ok ? g : g_begin) * W) * p.lddy + (size_t)(aidx >> 3) * p.lddy + ((aidx & 7) << 2));
+        av = ldx4<GB>(p.dy, ((size_t)(arow_ok ? g : g_begin) * W + (aidx >> 3)) * p.lddy + ((aidx & 7) << 2));
     };
     auto commit_a = [&](int g) {
         if (!arow_ok) return;
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_kernel(const Wg3Arg
 }
 
 bool wgrad3_3x3_supported(const WgradArgs& a) {
-    if (a.taps != 9 || a.Cout != WG3C_N || a.lddy != WG3C_N || a.Ccat != WG3C_C || a.nseg != 1 || a.xbf16 == 2) return false;
+    if (a.taps != 9 || a.Cout != WG3C_N || a.lddy != WG3C_N || a.Ccat != WG3C_C || a.nseg != 1) return false;
     if (a.seg[0].ups || a.seg[0].C != WG3C_C || a.seg[0].ld % 4) return false;
     if (a.W < 2 || a.W > 64 || (a.W & 1) || a.M % a.W) return false;
     return true;
@@ -788,6 +789,7 @@ hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_pe
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -796,7 +798,8 @@ hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_pe
     q.part = part;
     q.rows_per_split = rows_per_split;
     const size_t smem = ((size_t)2 * WG3C_C + (size_t)4 * (a.W + 2) * WG3C_C + (size_t)2 * a.W * WG3C_N) * 4;
-    if (a.xbf16) hipLaunchKernelGGL(wgrad3_3x3_kernel<1>, dim3(S), dim3(WG3_THREADS), smem, s, q);
+    if (a.xbf16 == 2) hipLaunchKernelGGL(wgrad3_3x3_kernel<2>, dim3(S), dim3(WG3_THREADS), smem, s, q);
+    else if (a.xbf16) hipLaunchKernelGGL(wgrad3_3x3_kernel<1>, dim3(S), dim3(WG3_THREADS), smem, s, q);
     else hipLaunchKernelGGL(wgrad3_3x3_kernel<0>, dim3(S), dim3(WG3_THREADS), smem, s, q);
     return hipGetLastError();
 }
