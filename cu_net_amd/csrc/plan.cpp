@@ -404,9 +404,7 @@ void Plan::layout_workspace() {
         const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits));
         const int min_m = tune_int("CUNET_WG3_MIN_M", po.wgrad3_min_rows), enable = tune_int("CUNET_WG3", 1);
         const int enable3 = tune_int("CUNET_WG3_3X3", 1), min_rows3 = std::max(1, tune_int("CUNET_WG3_3X3_ROWS", 6));     // image rows per workgroup
-        // narrower levels keep the per-wave kernel: alone on the GPU the ring kernel takes 47 / 29 / 21 us at W = 32 / 16 / 8
-        // against 31 / 16 / 14 us (two barriers per image row of W/2 MFMA steps), at W = 64 it wins (88 vs 106 us)
-        const int min_w3 = tune_int("CUNET_WG3_3X3_MIN_W", 48);
+        const int min_w3 = tune_int("CUNET_WG3_3X3_MIN_W", 2);        // (narrower levels would keep the per-wave kernel)
         const int nb = cfg.layer_num + 1;
         wgred_first.assign(nb, 0); wgred_count.assign(nb, 0); wgred_maxnumel.assign(nb, 0);
         n_wgred = 0;

@@ -63,7 +63,11 @@ struct cunet_plan {
 // dispatch in bwd_node and for the reduce tables built at bind.)
 static bool wg3_active(const Plan& P, const Node& n, int xmode) {
     if (n.wg3_S <= 0) return false;
-    if (n.taps == 9) return true;                                // (bf16 x / dY are widened to fp32 on the way into LDS)
+    // 3x3 ring kernel (bf16 x / dY are widened to fp32 on the way into LDS).  Alone on the GPU it takes 47 / 29 / 21 us at
+    // W = 32 / 16 / 8 against 31 / 16 / 14 us of the per-wave kernel (two barriers per image row of W/2 MFMA steps) and wins
+    // at W = 64 (88 vs 106 us); next to the fp32 data-gradient chain it is ahead at every width (fewer atomics, one read
+    // of X: 3155 vs 3083 img/s), next to the much shorter bf16 chain only where it is also faster alone.
+    if (n.taps == 9) return xmode != 2 || P.tensors[n.out].W >= 48;
     if (xmode == 2) {                                            // bf16 MFMA variant: 16-byte pieces of 8 bf16 channels
         if (n.wg3_rows % 64) return false;
         for (auto& sr : n.segs)
