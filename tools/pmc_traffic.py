@@ -14,6 +14,9 @@ import sys
 import pandas as pd
 
 CLASSES = [
+    (r'wgrad3_3x3_kernel', 'conv3x3_bwd_weight'),
+    (r'wgrad3_kernel|wgrad3_bf16_kernel', 'conv1x1_bwd_weight'),
+    (r'wgrad_reduce_kernel', 'wgrad_partial_reduce'),
     (r'wgrad2_stem_kernel', 'stem_bwd_weight'),
     (r'wgrad2_kernel', 'conv1x1_bwd_weight'),
     (r'wgrad_kernel<\(?cunet::\)?1|wgrad_kernel<1,', 'conv3x3_bwd_weight'),
@@ -54,7 +57,9 @@ for cls in rd.index:
     w = float(wr.loc[cls, 'mean']) * 1024.0 if cls in wr.index else 0.0
     out[cls] = {'launches_sampled': int(rd.loc[cls, 'size']), 'fetch_bytes_per_launch': round(f),
                 'write_bytes_per_launch': round(w), 'hbm_bytes_per_launch': round(f + w)}
-json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE (KiB, x2 on gfx950) and --pmc WRITE_SIZE (KiB), separate passes, '
-                     'bench.py --steps 3 --warmup 2', 'classes': out}, open(sys.argv[3], 'w'), indent=1)
+meta = {'source': 'rocprofv3 --pmc FETCH_SIZE (KiB, x2 on gfx950) and --pmc WRITE_SIZE (KiB), separate passes, '
+                  'bench.py --steps 3 --warmup 2 --no-also', 'workload': sys.argv[4] if len(sys.argv) > 4 else '2,68,24,f32',
+        'commit': sys.argv[5] if len(sys.argv) > 5 else 'unknown', 'classes': out}
+json.dump(meta, open(sys.argv[3], 'w'), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch']):
     print(f"{k:22s} fetch {v['fetch_bytes_per_launch'] / 1e6:9.2f} MB  write {v['write_bytes_per_launch'] / 1e6:9.2f} MB  per launch ({v['launches_sampled']} launches)")
