@@ -197,6 +197,20 @@ struct TernArgs {
     double* ystats;          // [2][O] sum / sum of squares of the output (or null)
 };
 
+struct AugSample {           // one training sample of cunet_augment_batch (host-computed crop geometry, pylib/HumanAug.py:118-142)
+    const float* src;        // 3 x sh x sw fp32 CHW image in [0, 1]
+    int sh, sw;
+    int ulx, uly;            // upper-left corner of the (padded) window in the (pre-shrunk) image
+    int win_w, win_h;        // window size without the rotation padding: what is resized to res x res
+    int pad, k;              // rotation padding; k x k sub-samples per output pixel (pre-shrink factor >= 2)
+    int cw, ch;              // padded canvas size (rotation centre = its middle)
+    int flip, rotated;
+    double sf;               // pre-shrink factor of the reference (1 if scale * size / res < 2)
+    double cs, sn;           // cos / sin of PIL's destination -> source rotation angle (-rot degrees)
+    float gain[3];           // per-channel colour gain (clamped to [0, 1] afterwards)
+    float pad_;
+};
+
 struct TernPackEntry {       // one conv whose (ternary) weights are packed into AND-popcount bit masks
     int64_t src;             // float offset of the weight [O][C][taps] in the parameter arena
     int64_t dst;             // uint64 offset of wpos in the mask region; wneg follows at dst + taps*G*Opad

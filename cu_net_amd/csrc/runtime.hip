@@ -913,6 +913,12 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
     return CUNET_OK;
 }
 
+int cunet_augment_batch(const void* table, int n, float* out, int res, void* stream) {
+    if (!table || !out || n < 1 || res < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    HIPCHK(launch_augment(reinterpret_cast<const AugSample*>(table), n, out, res, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
 int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float* out, int n, int k, int hh, int w,
                      void* stream) {
     if (!a || !b || !perm || !out || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");

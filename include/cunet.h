@@ -225,6 +225,18 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 
+/* training-sample preparation on the device: replaces the per-sample CPU work of data/mpii_for_mpii_22.py:127-141 between the
+ * decoded image and the network input -- horizontal flip (pylib/HumanAug.py:267-271), per-channel colour gain with clamp
+ * to [0, 1], and HumanAug.crop (:115-172: window on a zero canvas, rotation about the canvas centre, resize to res x res).
+ *   table: DEVICE array of n records {const float* src (3 x sh x sw fp32 CHW in [0,1]); int32 sh, sw, ulx, uly, win_w,
+ *          win_h, pad, k, cw, ch, flip, rotated; double sf, cs, sn; float gain[3], pad} (96 bytes): the crop geometry
+ *          is computed by the caller exactly as the reference computes it (cu_net_amd/augment.py::_geometry)
+ *   out:   n x 3 x res x res fp32
+ * One bilinear sample (k x k when the reference would shrink the image first) per output pixel at the composed
+ * coordinate; the reference's own resamplers (scipy.misc.imresize / imrotate) are gone from scipy, so pixel values are
+ * defined by oracle/augment_ref.py, not by the reference (geometry, flip and colour ARE pinned to it). */
+int cunet_augment_batch(const void* table, int n, float* out, int res, void* stream);
+
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);
  * negative if unknown. Names are those listed by cunet_plan_describe. */

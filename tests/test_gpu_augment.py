@@ -1,0 +1,45 @@
+"""GPU (-m gpu): training-sample preparation on the device (cunet_augment_batch) against oracle/augment_ref.py, whose
+geometry is pinned to the executed reference (G15).  Samples of different sizes in one launch: flip, colour gain with
+clamp, windows hanging over the image border, rotation, the pre-shrink branch (scale * 200 / res >= 2)."""
+import numpy as np
+import pytest
+import torch
+
+import cu_net_amd
+from oracle import augment_ref as A
+
+pytestmark = pytest.mark.gpu
+
+
+def test_augment_batch_matches_oracle():
+    rng = np.random.RandomState(3)
+    res = 48
+    shapes = [(3, 60, 80), (3, 75, 64), (3, 120, 90), (3, 64, 64), (3, 50, 70)]
+    imgs = [rng.uniform(0, 1, size=s).astype(np.float32) for s in shapes]
+    centers = np.array([[40.0, 30.0], [5.0, 70.0], [45.0, 60.0], [32.0, 32.0], [60.0, 10.0]])
+    scales = np.array([0.3, 0.25, 0.62, 0.24, 0.2])          # 0.62 * 200 / 48 = 2.58: the pre-shrink branch (k = 2)
+    rots = np.array([0.0, 25.0, 0.0, -40.0, 0.0])
+    flips = np.array([False, True, False, True, True])
+    gains = rng.uniform(0.6, 1.4, size=(5, 3))
+    out = cu_net_amd.augment_batch([torch.from_numpy(i).cuda() for i in imgs], centers, scales, rots, flips, gains, res=res).cpu().numpy()
+    assert out.shape == (5, 3, res, res)
+    for i in range(5):
+        ref = A.augment_sample(imgs[i], centers[i], float(scales[i]), float(rots[i]), bool(flips[i]), gains[i], res=res)
+        assert np.abs(out[i] - ref).max() <= 2e-6, (i, np.abs(out[i] - ref).max())
+        assert out[i].max() <= 1.0 and out[i].min() >= 0.0
+    assert out[0].max() > 0.3 and (out[1] == 0).any()          # sample 1 hangs over the border: zero canvas shows
+
+
+def test_augment_identity_window_is_a_copy():
+    """A window of exactly res x res pixels without rotation or jitter: the output is the zero-padded window itself, bit for
+    bit (weights 1 / 0), mirrored when flipped."""
+    rng = np.random.RandomState(4)
+    img = rng.uniform(0, 1, size=(3, 40, 50)).astype(np.float32)
+    res = 32
+    c = np.array([[25.0, 20.0], [25.0, 20.0]])
+    s = np.array([res / 200.0, res / 200.0])
+    out = cu_net_amd.augment_batch([torch.from_numpy(img).cuda()] * 2, c, s, flips=[False, True], res=res).cpu().numpy()
+    canvas = A.crop_canvas(np.transpose(img.astype(np.float64), (1, 2, 0)), c[0], float(s[0]), 0, res, 200)
+    assert np.array_equal(out[0], np.transpose(canvas, (2, 0, 1)).astype(np.float32))
+    canvas_f = A.crop_canvas(np.transpose(img[:, :, ::-1].astype(np.float64), (1, 2, 0)), c[1], float(s[1]), 0, res, 200)
+    assert np.array_equal(out[1], np.transpose(canvas_f, (2, 0, 1)).astype(np.float32))

@@ -97,3 +97,33 @@ def test_binop_and_quaninput_match_executed_reference():
     y8 = QR.quan_input(x, 8)
     assert float(y8.max()) == 127 / 128 and float(y8.min()) == -127 / 128      # clamp +-(1 - 2^-7)
     assert float(QR.quan_input_backward(x, gy)[0, 0, 0, 0]) == 0.0 and float(QR.quan_input_backward(x, gy)[0, 0, 0, 1]) == 0.0   # |x| >= 1: no gradient
+
+
+def test_augment_geometry_matches_executed_reference():
+    """G15: transform matrices / points, left-right shuffling and the crop WINDOW of pylib/HumanAug.py (executed from its AST
+    by tools/gen_golden.py --only augment) -- for the oracle and for the host side of the product (cu_net_amd.augment)."""
+    from oracle import augment_ref as A
+    from cu_net_amd import augment as P
+    z = np.load(os.path.join(GOLDEN_DIR, 'G15_augment.npz'))
+    for i in range(len(z['tp/scale'])):
+        c, s, r, res, pts = z['tp/center'][i], float(z['tp/scale'][i]), float(z['tp/rot'][i]), int(z['tp/res'][i]), z['tp/pts'][i]
+        for fn in (A.transform_pts, P.transform_pts):
+            assert np.array_equal(fn(pts, c, s, r, res, 200), z['tp/fwd'][i])
+            assert np.array_equal(fn(pts, c, s, r, res, 200, invert=1), z['tp/inv'][i])
+    for fn in (A.shufflelr, P.shufflelr):
+        assert np.array_equal(fn(z['flip/pts'], 640), z['flip/shuffled'])
+    img = z['crop/img'].astype(np.float64)
+    for cx, cy, s, ulx, uly, brx, bry, h, w, total in z['crop/cases']:
+        ul, br, pad, sf = A.crop_geometry(np.array([cx, cy]), s, 0, 256, 200)
+        assert (ul[0], ul[1], br[0], br[1]) == (ulx, uly, brx, bry)
+        canvas = A.crop_canvas(img, np.array([cx, cy]), s, 0, 256, 200)
+        assert canvas.shape[:2] == (h, w) and abs(canvas.sum() - total) <= 1e-6 * total
+        ul2, br2, pad2, sf2, k2 = P._geometry(np.array([cx, cy]), s, 0, 256, 200)          # the product's host geometry
+        assert (ul2[0], ul2[1], br2[0], br2[1], k2) == (ulx, uly, brx, bry, 1)
+    # identity resample: a window of exactly res x res pixels, no rotation -> the canvas itself
+    small = np.random.RandomState(0).uniform(0, 1, size=(3, 40, 50))
+    out = A.augment_sample(small, center=(25.0, 20.0), scale=32 / 200.0, rot=0, res=32, size=200)
+    ul, br, _, _ = A.crop_geometry(np.array([25.0, 20.0]), 32 / 200.0, 0, 32, 200)
+    assert tuple(br - ul) == (32, 32)
+    canvas = A.crop_canvas(np.transpose(small, (1, 2, 0)), np.array([25.0, 20.0]), 32 / 200.0, 0, 32, 200)
+    assert np.allclose(out, np.transpose(canvas, (2, 0, 1)).astype(np.float32), atol=1e-7)

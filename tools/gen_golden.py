@@ -600,6 +600,76 @@ def big_configs(ref, rq=None):
                    batch_seed=24, rq=rq, bits_w=1)
 
 
+def augment_parity():
+    """G15: the training-sample geometry of the reference's loader.  pylib/HumanAug.py does not import (scipy.misc), so
+    GetTransform / TransformSinglePts / TransformPts / shufflelr / fliplr / crop are compiled from the file's AST.  `crop`
+    ends in scipy.misc.imresize (and imrotate when rot != 0), which no longer exist: for rot == 0 the call is intercepted
+    only to CAPTURE the zero-padded window the reference built (its argument) -- the resampled pixel values themselves
+    cannot be pinned (see oracle/augment_ref.py)."""
+    import ast, re
+    from oracle import augment_ref as A
+    src = open(os.path.join(REF, 'pylib', 'HumanAug.py')).read()
+    src = re.sub(r"(?m)^(\s*)print (.+)$", r"\1print(\2)", src)
+    tree = ast.parse(src)
+    want = ('GetTransform', 'TransformSinglePts', 'TransformPts', 'shufflelr', 'fliplr', 'crop')
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(keep) == len(want)
+    captured = {}
+
+    class _Misc:                                   # stands in for the two removed resamplers ONLY to observe their input
+        @staticmethod
+        def imresize(arr, size, interp='bilinear', mode=None):
+            captured['canvas'] = np.array(arr, copy=True)
+            captured['size'] = size
+            return arr
+    fake_scipy = types.ModuleType('scipy_misc_capture')
+    fake_scipy.misc = _Misc
+    ha = types.ModuleType('ref_humanaug_geometry')
+    ha.__dict__.update(np=np, torch=torch, scipy=fake_scipy)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), '<reference pylib/HumanAug.py geometry subset>', 'exec'), ha.__dict__)
+    rng = np.random.RandomState(15)
+    fx = {}
+    # --- transforms
+    cases = []
+    for i in range(12):
+        c = rng.uniform(100, 900, size=2); s = float(rng.uniform(0.6, 3.5)); r = float(rng.choice([0, 0, 17.5, -33.0, 41.25]))
+        res = int(rng.choice([64, 256])); pts = rng.uniform(0, 1000, size=(16, 2))
+        t_ref = ha.GetTransform(c, s, r, res, 200)
+        assert np.array_equal(t_ref, A.get_transform(c, s, r, res, 200)), 'GetTransform'
+        for inv in (0, 1):
+            p_ref = ha.TransformPts(pts, c, s, r, res, 200, invert=inv)
+            assert np.array_equal(p_ref, A.transform_pts(pts, c, s, r, res, 200, invert=inv)), 'TransformPts'
+            s_ref = ha.TransformSinglePts(pts[0], c, s, r, res, 200, invert=inv)
+            assert np.array_equal(s_ref, A.transform_single_pts(pts[0], c, s, r, res, 200, invert=inv)), 'TransformSinglePts'
+        cases.append((c, s, r, res, pts, ha.TransformPts(pts, c, s, r, res, 200), ha.TransformPts(pts, c, s, r, res, 200, invert=1)))
+    fx['tp/center'] = np.array([k[0] for k in cases]); fx['tp/scale'] = np.array([k[1] for k in cases])
+    fx['tp/rot'] = np.array([k[2] for k in cases]); fx['tp/res'] = np.array([k[3] for k in cases])
+    fx['tp/pts'] = np.array([k[4] for k in cases]); fx['tp/fwd'] = np.array([k[5] for k in cases]); fx['tp/inv'] = np.array([k[6] for k in cases])
+    # --- flips
+    pts = torch.from_numpy(rng.uniform(0, 640, size=(16, 2)))
+    sh_ref = ha.shufflelr(pts.clone(), width=640, dataset='mpii').numpy()
+    assert np.array_equal(sh_ref, A.shufflelr(pts.numpy(), 640)), 'shufflelr'
+    img = rng.uniform(0, 1, size=(3, 37, 53))
+    assert np.array_equal(ha.fliplr(img.copy()), A.fliplr(img)), 'fliplr'
+    fx['flip/pts'] = pts.numpy(); fx['flip/shuffled'] = sh_ref
+    # --- crop window (rot == 0, no pre-shrink): the canvas the reference hands to imresize
+    img_hwc = rng.uniform(0, 1, size=(240, 320, 3))
+    crops = []
+    for c, s in (((160.0, 120.0), 0.9), ((20.0, 30.0), 1.1), ((310.0, 230.0), 1.28), ((150.5, 99.25), 2.2)):
+        captured.clear()
+        ha.crop(img_hwc, np.array(c), np.array([s]), 0, 256, 200)
+        canvas = captured['canvas']
+        assert captured['size'] == (256, 256)
+        mine = A.crop_canvas(img_hwc, np.array(c), s, 0, 256, 200)
+        assert np.array_equal(canvas, mine), ('crop canvas', c, s)
+        ul, br, pad, sf = A.crop_geometry(np.array(c), s, 0, 256, 200)
+        crops.append((c[0], c[1], s, ul[0], ul[1], br[0], br[1], canvas.shape[0], canvas.shape[1], float(canvas.sum())))
+    fx['crop/img'] = img_hwc.astype(np.float32)
+    fx['crop/cases'] = np.array(crops)
+    np.savez_compressed(os.path.join(OUT, 'G15_augment.npz'), **fx)
+    print(f'G15: GetTransform / TransformPts ({len(cases)} cases), shufflelr, fliplr, crop windows ({len(crops)}): oracle == reference')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -608,7 +678,7 @@ def main():
             ref = load_reference_models()
             {'big': big_configs, 'binop': lambda r: binop_quaninput_parity(r, load_reference_quantize())}[sys.argv[2]](ref)
             return
-        {'decode': decode_parity, 'tta': tta_accuracy_parity, 'targets': target_synthesis_parity}[sys.argv[2]]()
+        {'decode': decode_parity, 'tta': tta_accuracy_parity, 'targets': target_synthesis_parity, 'augment': augment_parity}[sys.argv[2]]()
         return
     ref = load_reference_models()
     tiny = dict(neck_size=2, growth_rate=4, init_chan_num=8)
@@ -630,6 +700,7 @@ def main():
     decode_parity()
     tta_accuracy_parity()
     target_synthesis_parity()
+    augment_parity()
 
 
 if __name__ == '__main__':
