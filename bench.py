@@ -103,8 +103,10 @@ def load_traffic(cls, workload_key):
 
 
 def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0, forward_only=False, popcount=False,
-            profile_out='', seed=2):
-    """Time `steps` steps of one workload.  mode: 'fp32' | 'bf16' (activations) | 'bf16_grads' (+ gradient tensors)."""
+            profile_out='', seed=2, serial=False, force_class=None):
+    """Time `steps` steps of one workload.  mode: 'fp32' | 'bf16' (activations) | 'bf16_grads' (+ gradient tensors).
+    serial: build the plan with CUNET_NO_SIDE_STREAM (weight gradients on the caller's stream, so every kernel runs ALONE on
+    the GPU): the per-launch durations of a class are then the kernel's own, not its share of a GPU it co-occupies."""
     import cu_net_amd
     from cu_net_amd.trainer import FusedTrainer
     bf16 = mode != 'fp32'
@@ -141,7 +143,13 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     else:
         def one_step():
             return tr.step(x, t)
-    plan = net._get_plan(bs, 256, 256, not forward_only, bf16=bf16)
+    if serial:
+        os.environ['CUNET_NO_SIDE_STREAM'] = '1'       # read when the plan handle is created
+    try:
+        plan = net._get_plan(bs, 256, 256, not forward_only, bf16=bf16)
+    finally:
+        if serial:
+            del os.environ['CUNET_NO_SIDE_STREAM']
     # ---- warm-up; the last warm-up step is profiled per kernel class to pick the dominant one
     for i in range(max(warmup, 1)):
         if i == max(warmup, 1) - 1:
@@ -152,8 +160,8 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     prof_all = plan.handle.profile_collect()
     plan.handle.profile_begin(0)
     have_classes = any(v[0] for v in prof_all.values())
-    dominant = max(prof_all.items(), key=lambda kv: kv[1][1])[0]
-    if rank == 0 and have_classes:
+    dominant = force_class or max(prof_all.items(), key=lambda kv: kv[1][1])[0]
+    if rank == 0 and have_classes and not serial:
         tot = sum(v[1] for v in prof_all.values())
         lines = [f'per-class profile of one warm-up step, CU-Net-{L} K={K} {mode} bits_w={bits_w} (sum of kernel times {tot:.3f} ms):']
         for name, (cnt, ms, fl, by) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
@@ -294,7 +302,22 @@ def main():
     is_default = (L, K, bs, mode, args.bits_w, args.forward_only, args.popcount) == (2, 68, 24, 'fp32', 0, False, False)
     r = measure(dev, pg, rank, world, L, K, bs, args.steps, args.warmup, mode, args.bits_w, args.forward_only,
                 args.popcount, args.profile_out)
+    alone = None
+    if world == 1 and is_default and r['roofline'] and 'NO_SIDE_STREAM' not in ''.join(os.environ):
+        # the same class timed with nothing else on the GPU (outside the timed region; a separate plan without the side stream)
+        try:
+            a = measure(dev, None, 0, 1, L, K, bs, 8, 3, mode, args.bits_w, False, args.popcount, serial=True,
+                        force_class=r['roofline']['kernel'])
+            ar = a['roofline']
+            alone = {'avg_launch_us': ar['avg_launch_us'], 'achieved': ar['achieved'], 'frac': ar['frac'], 'launches': ar['launches'],
+                     'ms_per_step_serial': round(a['ms_per_step_median'], 3),
+                     'note': 'same kernels with the weight-gradient side stream off: every kernel alone on the GPU; roofline.achieved above '
+                             'is measured in the overlapped step, where this class shares the CUs with the data-gradient stream'}
+        except Exception as ex:
+            alone = {'error': repr(ex)}
     if rank == 0:
+        if alone is not None and r['roofline']:
+            r['roofline']['alone'] = alone
         out = {
             'metric': ('images/sec inference forward' if args.forward_only else 'images/sec train step')
                       + ', 256x256x3 -> 64x64xK heatmaps, CU-Net-%d' % L,
