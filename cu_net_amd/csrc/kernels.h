@@ -11,6 +11,7 @@ hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
 bool wgrad3_supported(const WgradArgs& a);
 hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
 bool wgrad3_3x3_supported(const WgradArgs& a);
+bool wgrad3_3x3_on_bf16_mfma(const WgradArgs& a);      // bf16 x and dY, W in {16, 32, 64}
 hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
 hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, const float* ws, float* grads, hipStream_t s);
 hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t s);

@@ -74,10 +74,11 @@ struct Node {
     // LDS-staged 1x1 weight gradient (wgrad3): pixel splits, rows per split, float offset of the [S][Cout][Ccat]
     // partial tiles inside the per-bucket partial region, index into the reduce table; wg3_S == 0: not eligible
     int wg3_S = 0, wg3_rows = 0, wg3_entry = -1;
+    int wg3_S16 = 0, wg3_rows16 = 0;      // the same with bf16 gradient tensors: those kernels are HBM-bound, fewer and longer splits (less partial traffic) win
     int64_t wg3_part = -1;
 };
 
-struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256; };
+struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 96; };
 PlannerOptions& planner_options();
 
 struct Plan {

@@ -11,7 +11,7 @@
 #include "plan.h"
 
 enum { PC_C1F = 0, PC_C3F, PC_STEMF, PC_C1D, PC_C3D, PC_C1W, PC_C3W, PC_STEMW, PC_APPLY, PC_POOLF, PC_POOLB,
-       PC_STEMBPF, PC_STEMBPB, PC_MISC, PC_C1F16, PC_C3F16, PC_C1D16, PC_C3D16, PC_C1W16, PC_TERN, CUNET_PROF_NCLS };
+       PC_STEMBPF, PC_STEMBPB, PC_MISC, PC_C1F16, PC_C3F16, PC_C1D16, PC_C3D16, PC_C1W16, PC_TERN, PC_C3W16, CUNET_PROF_NCLS };
 
 using namespace cunet;
 
@@ -67,9 +67,13 @@ static bool wg3_active(const Plan& P, const Node& n, int xmode) {
     // W = 32 / 16 / 8 against 31 / 16 / 14 us of the per-wave kernel (two barriers per image row of W/2 MFMA steps) and wins
     // at W = 64 (88 vs 106 us); next to the fp32 data-gradient chain it is ahead at every width (fewer atomics, one read
     // of X: 3155 vs 3083 img/s), next to the much shorter bf16 chain only where it is also faster alone.
-    if (n.taps == 9) return xmode != 2 || P.tensors[n.out].W >= 48;
+    // With bf16 x AND dY the contraction runs on bf16 MFMA (wgrad3_3x3_bf16_kernel, W = 16 / 32 / 64).
+    if (n.taps == 9) {
+        const int W = P.tensors[n.out].W;
+        return xmode != 2 || W == 64 || W == 32 || W == 16;
+    }
     if (xmode == 2) {                                            // bf16 MFMA variant: 16-byte pieces of 8 bf16 channels
-        if (n.wg3_rows % 64) return false;
+        if (n.wg3_rows16 % 64) return false;
         for (auto& sr : n.segs)
             if (P.tensors[sr.tensor].C % 8 || P.tensors[sr.tensor].ld % 8) return false;
     }
@@ -82,7 +86,7 @@ static const char* kProfNames[CUNET_PROF_NCLS] = {
     "stem_bnpool_bwd", "misc",
     // the same node classes when they run on bf16 MFMA (bf16 storage modes): priced against the bf16 peak
     "conv1x1_fwd_bf16", "conv3x3_fwd_bf16", "conv1x1_bwd_data_bf16", "conv3x3_bwd_data_bf16", "conv1x1_bwd_weight_bf16",
-    "conv_fwd_popcount"};
+    "conv_fwd_popcount", "conv3x3_bwd_weight_bf16"};
 
 static hipError_t prof_begin(cunet_plan* h, int cls, hipStream_t s, int& slot) {
     slot = -1;
@@ -135,6 +139,8 @@ int cunet_set_planner_option(const char* name, int value) {
     if (n == "wgrad3_min_rows") o.wgrad3_min_rows = value;
     else if (n == "wgrad3_min_chunks") o.wgrad3_min_chunks = value;
     else if (n == "wgrad3_max_splits") o.wgrad3_max_splits = value;
+    else if (n == "wgrad3_min_chunks_bf16") o.wgrad3_min_chunks_bf16 = value;
+    else if (n == "wgrad3_max_splits_bf16") o.wgrad3_max_splits_bf16 = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -267,7 +273,7 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
                 WgReduceEntry& e = h->wgred[(size_t)mode * nwg + n.wg3_entry];
                 e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.numel = P.convs[n.conv].Cout * n.Ccat * n.taps;
                 e.taps = n.taps; e.pad_ = 0;
-                e.S = wg3_active(P, n, mode ? 2 : 0) ? n.wg3_S : 0;
+                e.S = wg3_active(P, n, mode ? 2 : 0) ? (mode ? n.wg3_S16 : n.wg3_S) : 0;
             }
         }
     hipStream_t s = (hipStream_t)stream;
@@ -502,12 +508,13 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
             if (c.taps == 9 && wg3_active(P, n, E.xmode) && wgrad3_3x3_supported(w)) {
                 // LDS ring of activated image rows, partial tiles [split][tap][n][c] (reduced + transposed per bucket)
-                PROF_ON(ws, PC_C3W, 2.0 * w.M * w.Cout * w.Ccat * 9, 4.0 * (double)w.M * (w.Cout + w.Ccat),
-                        launch_wgrad3_3x3(w, E.wsf + n.wg3_part, n.wg3_S, n.wg3_rows, ws));
+                const bool on16 = wgrad3_3x3_on_bf16_mfma(w);
+                PROF_ON(ws, on16 ? PC_C3W16 : PC_C3W, 2.0 * w.M * w.Cout * w.Ccat * 9, (on16 ? 2.0 : 4.0) * (double)w.M * (w.Cout + w.Ccat),
+                        launch_wgrad3_3x3(w, E.wsf + n.wg3_part, E.xmode == 2 ? n.wg3_S16 : n.wg3_S, E.xmode == 2 ? n.wg3_rows16 : n.wg3_rows, ws));
             } else if (c.taps == 1 && wg3_active(P, n, E.xmode) && wgrad3_supported(w)) {
                 // LDS-staged, atomics-free: partial tiles now, summed into the arena by the bucket's reduce (reduce_wgrad3)
                 PROF_ON(ws, E.xmode == 2 ? PC_C1W16 : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat, (E.xmode == 2 ? 2.0 : 4.0) * (double)w.M * (w.Cout + w.Ccat),
-                        launch_wgrad3(w, E.wsf + n.wg3_part, n.wg3_S, n.wg3_rows, ws));
+                        launch_wgrad3(w, E.wsf + n.wg3_part, E.xmode == 2 ? n.wg3_S16 : n.wg3_S, E.xmode == 2 ? n.wg3_rows16 : n.wg3_rows, ws));
             } else {
                 PROF_ON(ws, c.taps == 9 ? PC_C3W : PC_C1W, 2.0 * w.M * w.Cout * w.Ccat * w.taps, 4.0 * (double)w.M * (w.Cout + w.Ccat),
                         launch_wgrad(w, c.taps == 9 ? WGL_3X3 : WGL_SEG, cus, ws));

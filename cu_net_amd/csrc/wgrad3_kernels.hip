@@ -16,6 +16,7 @@
 //     deterministic reduce kernel per gradient bucket sums the splits into the gradient arena (no atomics, bitwise
 //     reproducible dW).
 // Roofline: 2*128*CW flops per (128 + CW)*4 bytes = 45.7 flop/B at CW = 320 > the fp32 ridge (~25): MFMA-bound.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -775,11 +776,261 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_kernel(const Wg3Arg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 3x3 weight gradient on bf16 MFMA (bf16 x AND bf16 dY: FusedTrainer(bf16_grads=True)).  v_mfma_f32_32x32x16_bf16
+// contracts 16 PIXELS per instruction and wants a lane's 8 pixels contiguous, so the rows live in LDS channel-major:
+//     Xs[slot][c][W (+8 pad)]   activated (BatchNorm + ReLU in fp32, re-rounded: the operand the bf16 forward multiplied)
+//     dYs[buf][dx][n][W (+8)]   THREE copies of the dY row, shifted by dx = -1, 0, +1 pixels with zeros shifted in
+// so that   dW[dy][dx][n][c] = sum_q dYs[dx][n][q] * Xs[row y+dy][c][q]   is a contraction over ALIGNED 16-byte fragments for
+// every tap: the x-shift is paid once per dY row (32 channels, 16 lane shuffles) instead of per tap, the y-shift is a ring
+// slot, rows outside the image are an all-zero slot.  The transposition happens on the way into LDS exactly as in
+// wgrad3_bf16_kernel (a lane owns 4 pixels x 8 channels; v_cvt_pk_bf16_f32 of the same channel of two neighbouring pixels
+// is the pixel-major packing).  Ring of FOUR X slots: row g+2 is written while rows g-1, g, g+1 are read -> one barrier per
+// image row; global loads run two rows ahead of their LDS commit (two register sets).  Per image row a workgroup moves
+// 20 KB from HBM for 20 MFMAs of 32 cycles per wave: HBM-bound by a wide margin (AI = 230 flop/B at bf16 ridge ~310), the
+// fp32-MFMA ring it replaces in this mode is MFMA-bound at 1/16 of the rate.
+// Wave w: input-channel tile (w & 3), taps 0..4 (w < 4; rows y-1, y) or 5..8 (rows y, y+1).  Partials as above.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// The register sets of wgrad3_3x3_bf16_kernel are loaded with inline asm and retired with a COUNTED s_waitcnt: hipcc's own
+// waitcnt insertion gives up on this loop (per-role exec branches) and waits vmcnt(0) before every commit, i.e. also for the
+// set that was issued one row ago -- which halves the distance between a load and its use.
+__device__ __forceinline__ u32x4 gload16_asm(const unsigned short* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void vm_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int LOGQG>     // log2(W / 4): W = 16, 32, 64
+__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_bf16_kernel(const Wg3Args q) {
+    constexpr int QG = 1 << LOGQG;            // 4-pixel groups per image row
+    constexpr int W = 4 * QG;
+    constexpr int LDPX = W + 8;               // bf16 elements per LDS row: pitch W*2 + 16 bytes (conflict-free ds_read_b128)
+    constexpr int NXW = QG / 4 > 0 ? QG / 4 : 1;      // waves that stage an X row (a wave covers 64 / QG channel groups of 8)
+    constexpr int SLOT = WG3C_C * LDPX;       // elements per X slot
+    constexpr int DYB = 3 * WG3C_N * LDPX;    // elements per dY buffer (3 shifted copies)
+    constexpr int NK = W / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WgradArgs& p = q.w;
+    const int H = p.H;
+    float* sc = reinterpret_cast<float*>(smem);            // [128]
+    float* sh = sc + WG3C_C;
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(smem);
+    constexpr int RING0 = 2 * WG3C_C * 2;                  // element offset of slot 0 (after sc / sh: 1 KB)
+    constexpr int ZOFF = RING0 + 4 * SLOT;
+    constexpr int DYOFF = ZOFF + SLOT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const Seg& sg = p.seg[0];
+
+    for (int c = tid; c < WG3C_C; c += WG3_THREADS) {
+        const double sum = sg.stats[c], sq = sg.stats[sg.C + c];
+        const double mean = sum / sg.count;
+        double var = sq / sg.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+    }
+    for (int i = tid; i < SLOT / 8; i += WG3_THREADS)       // the zero slot
+        reinterpret_cast<uint4*>(lds16 + ZOFF)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    const int NH = p.M / W;                                // image rows in the batch
+    const int g_begin = blockIdx.x * q.rows_per_split;
+    int g_end = g_begin + q.rows_per_split;
+    if (g_end > NH) g_end = NH;
+
+    // ---- staging roles.  X: waves 0 .. NXW-1, lane = (pixel group q4, channel group); dY: wave NXW, channel groups 0..3
+    const int q4 = lane & (QG - 1);
+    const int cgl = lane >> LOGQG;                         // channel group inside the wave
+    const bool is_x = wave < NXW;
+    const int cgx = wave * (64 / QG) + cgl;                // 0 .. 15 (8 channels each)
+    const bool is_a = wave == NXW && cgl < 4;
+    const unsigned short* x16 = reinterpret_cast<const unsigned short*>(sg.x);
+    const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(p.dy);
+    float s8[8], h8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s8[e] = sc[(is_x ? cgx * 8 : 0) + e]; h8[e] = sh[(is_x ? cgx * 8 : 0) + e]; }
+
+    // two register sets (compile-time selected): loads run two rows ahead of their commit
+    u32x4 ld0[4], ld1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ld0[i] = u32x4{0u, 0u, 0u, 0u}; ld1[i] = ld0[i]; }
+    bool ok0 = false, ok1 = false;
+    // one load site for both roles (a pending-load state that differs between paths makes hipcc wait for the NEWER set too)
+    const bool stager = is_x || is_a;
+    const unsigned short* gsrc = is_x ? x16 + 8 * cgx : dy16 + 8 * cgl;
+    const size_t gld = is_x ? (size_t)sg.ld : (size_t)p.lddy;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto issue = [&](auto SET, int gx, int ga) {           // X row gx (waves < NXW) / dY row ga (wave NXW)
+        constexpr int ST = decltype(SET)::value;
+        u32x4 (&L)[4] = *(ST ? &ld1 : &ld0);
+        bool& okv = *(ST ? &ok1 : &ok0);
+        const int g = is_x ? gx : ga;
+        okv = is_x ? (gx >= 0 && gx < NH) : (is_a && ga < g_end);
+        if (stager) {
+            const unsigned short* src = gsrc + ((size_t)(okv ? g : g_begin) * W + 4 * q4) * gld;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) L[i] = gload16_asm(src + (size_t)i * gld);
+        }
+    };
+    auto commit = [&](auto SET, auto NEWER, int gx, int ga) {      // NEWER: loads issued after this set's that may stay in flight
+        constexpr int ST = decltype(SET)::value;
+        u32x4 (&L)[4] = *(ST ? &ld1 : &ld0);
+        const bool okv = ST ? ok1 : ok0;
+        if (!stager) return;
+        vm_wait4<decltype(NEWER)::value>(L[0], L[1], L[2], L[3]);
+        unsigned r[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[i][0] = L[i][0]; r[i][1] = L[i][1]; r[i][2] = L[i][2]; r[i][3] = L[i][3]; }
+        if (!okv) return;                                  // (after the registers were consumed: the loads are retired on every path)
+        if (is_x) {
+            uint2* dst = reinterpret_cast<uint2*>(lds16 + RING0 + (gx & 3) * SLOT + (8 * cgx) * LDPX + 4 * q4);
+            float v[8][4];                                 // [channel][pixel]
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * k][i] = fmaxf(fmaf(bf16_bits_lo(r[i][k]), s8[2 * k], h8[2 * k]), 0.f);
+                    v[2 * k + 1][i] = fmaxf(fmaf(bf16_bits_hi(r[i][k]), s8[2 * k + 1], h8[2 * k + 1]), 0.f);
+                }
+            if (p.qin_bits) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[e][i] = quan_input_act(v[e][i], p.qin_bits);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e * (LDPX / 4)] = make_uint2(cvt_pk_bf16(v[e][0], v[e][1]), cvt_pk_bf16(v[e][2], v[e][3]));
+        } else {
+            uint2* dst = reinterpret_cast<uint2*>(lds16 + DYOFF + (ga & 1) * DYB + (8 * cgl) * LDPX + 4 * q4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {        // channel 2k + par: pixels 0..3 as two dwords
+                    const unsigned a0 = par ? ((r[0][k] >> 16) | (r[1][k] & 0xffff0000u)) : ((r[0][k] & 0xffffu) | (r[1][k] << 16));
+                    const unsigned a1 = par ? ((r[2][k] >> 16) | (r[3][k] & 0xffff0000u)) : ((r[2][k] & 0xffffu) | (r[3][k] << 16));
+                    unsigned left = __shfl_up(a1, 1), right = __shfl_down(a0, 1);      // neighbouring pixel groups are neighbouring lanes
+                    if (q4 == 0) left = 0u;
+                    if (q4 == QG - 1) right = 0u;
+                    const int e = 2 * k + par;
+                    // copy dxi holds dY[q - dx], dx = dxi - 1
+                    dst[(0 * WG3C_N + e) * (LDPX / 4)] = make_uint2((a0 >> 16) | (a1 << 16), (a1 >> 16) | (right << 16));      // dx = -1: dY[q + 1]
+                    dst[(1 * WG3C_N + e) * (LDPX / 4)] = make_uint2(a0, a1);
+                    dst[(2 * WG3C_N + e) * (LDPX / 4)] = make_uint2((left >> 16) | (a0 << 16), (a0 >> 16) | (a1 << 16));        // dx = +1: dY[q - 1]
+                }
+            }
+        }
+    };
+
+    const int ctile = wave & 3;
+    const int half = wave >> 2;
+    constexpr int CTW = 5;
+    f32x16 acc[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- prologue: X rows g_begin-1 .. g_begin+1 and dY row g_begin committed; X row g_begin+2 / dY row g_begin+1 in set 1
+    issue(S0{}, g_begin - 1, g_begin);
+    issue(S1{}, g_begin, g_end);                           // (no dY row: ok = false)
+    using N0 = std::integral_constant<int, 0>;
+    using N4 = std::integral_constant<int, 4>;
+    commit(S0{}, N4{}, g_begin - 1, g_begin);
+    issue(S0{}, g_begin + 1, g_end);
+    commit(S1{}, N4{}, g_begin, 0);
+    commit(S0{}, N0{}, g_begin + 1, 0);
+    issue(S1{}, g_begin + 2, g_begin + 1);
+    __syncthreads();
+
+    const int frag = li * LDPX + 8 * hi;                   // this lane's fragment inside a [32][LDPX] tile
+    auto row = [&](auto HALF, int g) {
+        constexpr int HF = decltype(HALF)::value;
+        const int y = g % H;
+        const int abase = DYOFF + (g & 1) * DYB + frag;
+        // B rows this half needs: HF = 0 -> y-1 (or zero), y;  HF = 1 -> y, y+1 (or zero)
+        int b0, b1;
+        if (HF == 0) { b0 = (y > 0) ? RING0 + ((g - 1) & 3) * SLOT : ZOFF; b1 = RING0 + (g & 3) * SLOT; }
+        else { b0 = RING0 + (g & 3) * SLOT; b1 = (y < H - 1) ? RING0 + ((g + 1) & 3) * SLOT : ZOFF; }
+        b0 += ctile * 32 * LDPX + frag;
+        b1 += ctile * 32 * LDPX + frag;
+        bf16x8_t a[2][3], b[2][2];
+        auto fetch = [&](int st, int j) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a[st][d] = *reinterpret_cast<const bf16x8_t*>(lds16 + abase + d * WG3C_N * LDPX + 16 * j);
+            b[st][0] = *reinterpret_cast<const bf16x8_t*>(lds16 + b0 + 16 * j);
+            b[st][1] = *reinterpret_cast<const bf16x8_t*>(lds16 + b1 + 16 * j);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            if (j + 1 < NK) fetch((j + 1) & 1, j + 1);
+            const int st = j & 1;
+            if (HF == 0) {                                 // taps 0..4 = (dy -1: dx -1, 0, +1), (dy 0: dx -1, 0)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][0], b[st][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][1], b[st][0], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][2], b[st][0], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][0], b[st][1], acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][1], b[st][1], acc[4], 0, 0, 0);
+            } else {                                       // taps 5..8 = (dy 0: dx +1), (dy +1: dx -1, 0, +1)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][2], b[st][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][0], b[st][1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][1], b[st][1], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st][2], b[st][1], acc[3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, HF == 0 ? 5 : 4, 0);
+        }
+    };
+    auto step = [&](auto PAR, int g) {                     // PAR = g - g_begin parity: set PAR^1 holds X row g+2 / dY row g+1
+        using P1 = std::integral_constant<int, decltype(PAR)::value ^ 1>;
+        commit(P1{}, N4{}, g + 2, g + 1);                  // slot (g+2)&3 and dY buffer (g+1)&1 are not read during this row
+        issue(P1{}, g + 4, g + 3);
+        if (half == 0) row(S0{}, g);
+        else row(S1{}, g);
+        __syncthreads();
+    };
+    // register-set schedule: at row g (relative index i = g - g_begin) set (i&1)^1 holds (X g+2, dY g+1), set (i&1) holds (X g+3, dY g+2)
+    // after the prologue: set 1 = (X g_begin+2, dY g_begin+1); set 0 must get (X g_begin+3, dY g_begin+2)
+    issue(S0{}, g_begin + 3, g_begin + 2);
+    for (int g = g_begin; g < g_end; g += 2) {
+        step(S0{}, g);
+        step(S1{}, g + 1);                                 // (the launcher guarantees an even number of rows per workgroup)
+    }
+
+    // ---- partial tiles: part[split][tap][n][c]
+    float* out = q.part + (size_t)blockIdx.x * 9 * WG3C_N * WG3C_C;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        const int tap = half * 5 + t;
+        if (tap > 8) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[((size_t)tap * WG3C_N + n) * WG3C_C + ctile * 32 + li] = acc[t][r];
+        }
+    }
+}
+
 bool wgrad3_3x3_supported(const WgradArgs& a) {
     if (a.taps != 9 || a.Cout != WG3C_N || a.lddy != WG3C_N || a.Ccat != WG3C_C || a.nseg != 1) return false;
     if (a.seg[0].ups || a.seg[0].C != WG3C_C || a.seg[0].ld % 4) return false;
     if (a.W < 2 || a.W > 64 || (a.W & 1) || a.M % a.W) return false;
     return true;
+}
+
+// bf16 x and bf16 dY at W = 16 / 32 / 64: the contraction runs on bf16 MFMA (wgrad3_3x3_bf16_kernel)
+bool wgrad3_3x3_on_bf16_mfma(const WgradArgs& a) {
+    return wgrad3_3x3_supported(a) && a.xbf16 == 2 && (a.W == 16 || a.W == 32 || a.W == 64) && a.seg[0].ld % 8 == 0;
 }
 
 // part: [S][9][32][128] floats; rows_per_split counts image rows (N*H of them in total)
@@ -797,6 +1048,22 @@ hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_pe
     q.w = a;
     q.part = part;
     q.rows_per_split = rows_per_split;
+    if (wgrad3_3x3_on_bf16_mfma(a) && rows_per_split % 2 == 0 && (a.M / a.W) % 2 == 0) {
+        static bool attr16_done = false;
+        if (!attr16_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_3x3_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr16_done = true;
+        }
+        const size_t ldpx = a.W + 8;
+        const size_t smem16 = 1024 + (5 * WG3C_C * ldpx + 2 * 3 * WG3C_N * ldpx) * 2;
+        if (a.W == 64) hipLaunchKernelGGL(wgrad3_3x3_bf16_kernel<4>, dim3(S), dim3(WG3_THREADS), smem16, s, q);
+        else if (a.W == 32) hipLaunchKernelGGL(wgrad3_3x3_bf16_kernel<3>, dim3(S), dim3(WG3_THREADS), smem16, s, q);
+        else hipLaunchKernelGGL(wgrad3_3x3_bf16_kernel<2>, dim3(S), dim3(WG3_THREADS), smem16, s, q);
+        return hipGetLastError();
+    }
     const size_t smem = ((size_t)2 * WG3C_C + (size_t)4 * (a.W + 2) * WG3C_C + (size_t)2 * a.W * WG3C_N) * 4;
     if (a.xbf16 == 2) hipLaunchKernelGGL(wgrad3_3x3_kernel<2>, dim3(S), dim3(WG3_THREADS), smem, s, q);
     else if (a.xbf16) hipLaunchKernelGGL(wgrad3_3x3_kernel<1>, dim3(S), dim3(WG3_THREADS), smem, s, q);

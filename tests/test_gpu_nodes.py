@@ -172,9 +172,10 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0):
             if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
                 from oracle.cunet_ref import _QuanInputFn       # QuanInput2d site: quantised forward, straight-through backward
                 act = _QuanInputFn.apply(act, quan_input_bits)
-            if gb and nd.get('wg3', 0) > 0 and nd['taps'] == 1:
-                # the bf16-MFMA weight gradient contracts dY with the bf16-ROUNDED activation -- exactly the operand the bf16
-                # forward multiplied the weights with, i.e. the exact gradient of that forward (straight-through here)
+            if gb and nd.get('wg3', 0) > 0 and (nd['taps'] == 1 or T[nd['out']]['W'] in (16, 32, 64)):
+                # the bf16-MFMA weight gradient (1x1: wgrad3_bf16_kernel; 3x3 at W = 16 / 32 / 64: wgrad3_3x3_bf16_kernel) contracts
+                # dY with the bf16-ROUNDED activation -- exactly the operand the bf16 forward multiplied the weights with, i.e. the
+                # exact gradient of that forward (straight-through here)
                 act = act + (act.bfloat16().float() - act).detach()
             y = F.conv2d(act, wt, None, 1, 1 if nd['taps'] == 9 else 0)
             y.backward(dy)
