@@ -266,6 +266,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the extra CU-Net-8 bf16 / CU-Net-16 binary-weight lines')
     ap.add_argument('--also-steps', type=int, default=20)
+    ap.add_argument('--no-alone', action='store_true', help='skip the extra (untimed) pass that times the dominant class with the side stream off')
     ap.add_argument('--profile-out', default='')
     ap.add_argument('--forward-only', action='store_true', help='inference: eval-mode forward (running statistics), no loss / backward')
     ap.add_argument('--bf16', action='store_true', help='bf16 activation storage + bf16 MFMA forward (train step: gradients, weights, optimiser stay fp32; '
@@ -303,7 +304,7 @@ def main():
     r = measure(dev, pg, rank, world, L, K, bs, args.steps, args.warmup, mode, args.bits_w, args.forward_only,
                 args.popcount, args.profile_out)
     alone = None
-    if world == 1 and is_default and r['roofline'] and 'NO_SIDE_STREAM' not in ''.join(os.environ):
+    if world == 1 and is_default and r['roofline'] and not args.no_alone and 'CUNET_NO_SIDE_STREAM' not in os.environ:
         # the same class timed with nothing else on the GPU (outside the timed region; a separate plan without the side stream)
         try:
             a = measure(dev, None, 0, 1, L, K, bs, 8, 3, mode, args.bits_w, False, args.popcount, serial=True,
