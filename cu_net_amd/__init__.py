@@ -11,4 +11,4 @@ and the training-sample preparation (`cu_net_amd.augment`: flip, colour gain, cr
 from ._lib import CUNetError, LIB_PATH  # noqa: F401
 from .module import CUNet, create_cu_net  # noqa: F401
 from .trainer import FusedTrainer, accuracy, accuracy_origin_res, final_preds, flip_merge, get_preds, pts2heatmap  # noqa: F401
-from .augment import augment_batch, shufflelr, transform_pts  # noqa: F401
+from .augment import augment_batch, draw_train_params, prepare_batch, shufflelr, transform_pts  # noqa: F401

@@ -125,3 +125,68 @@ def augment_batch(images, centers, scales, rots=None, flips=None, gains=None, re
     check(lib().cunet_augment_batch(_ptr(tab), n, _ptr(out), int(res), _stream_ptr(dev)), 'cunet_augment_batch')
     out._cunet_keepalive = (keep, tab)          # the launch is asynchronous: inputs must outlive it
     return out
+
+
+# ---- the loader's per-sample recipe (data/mpii_for_mpii_22.py:86-145) for a whole batch -----------------------------------
+def sample_from_bounded_gaussian(x, rng=np.random):
+    """data/mpii_for_mpii_22.py:12-13."""
+    return max(-2 * x, min(2 * x, rng.randn() * x))
+
+
+def draw_train_params(scale_factor: float = 0.25, rot_factor: float = 30.0, rng=np.random):
+    """The random draws of one training sample in the reference's ORDER (data/mpii_for_mpii_22.py:122-136), so that the same
+    numpy seed gives the same augmentation: scale jitter 2**N(0, sf) (bounded at 2 sf), rotation N(0, rf) (bounded) zeroed
+    with probability 0.6, flip with probability 0.5, three colour gains U(0.6, 1.4)."""
+    s_mul = 2 ** sample_from_bounded_gaussian(scale_factor, rng)
+    r = sample_from_bounded_gaussian(rot_factor, rng)
+    if rng.uniform(0, 1, 1) <= 0.6:
+        r = 0
+    flip = bool(rng.random() <= 0.5) if hasattr(rng, 'random') else bool(rng.random_sample() <= 0.5)
+    gains = [rng.uniform(0.6, 1.4), rng.uniform(0.6, 1.4), rng.uniform(0.6, 1.4)]
+    return s_mul, r, flip, gains
+
+
+def mpii_center_scale(objpos, scale_provided, dataset: str = 'MPII'):
+    """data/mpii_for_mpii_22.py:99-110: person box -> crop centre / scale."""
+    c = np.array(objpos, dtype=np.float64, copy=True)
+    s = float(scale_provided)
+    if dataset == 'MPII':
+        c[1] = c[1] + 15 * s
+        s = s * 1.25
+    elif dataset == 'LEEDS':
+        s = s * 1.4375
+    else:
+        raise ValueError('no such dataset %s' % dataset)
+    return c, s
+
+
+def prepare_batch(samples, is_train: bool = True, inp_res: int = 256, out_res: int = 64, sigma: float = 1, scale_factor: float = 0.25,
+                  rot_factor: float = 30.0, std_size: float = 200.0, rng=np.random, params=None):
+    """`MPII.__getitem__` (data/mpii_for_mpii_22.py:86-145) for a batch, everything after the JPEG decode on the GPU.
+    samples: dicts with 'img' (3 x H x W fp32 GPU tensor in [0, 1]), 'joint_self' (K x >=2), 'objpos' (x, y), 'scale_provided',
+    optionally 'dataset'.  `params` (a list of (s_mul, r, flip, gains)) overrides the random draws.
+    Returns (inp N x 3 x inp_res^2, heatmap N x K x out_res^2, meta) with meta = dict(center, scale, rot, pts) as the reference
+    returns them per sample (pts AFTER the flip shuffle, centre / scale after jitter)."""
+    from .trainer import pts2heatmap
+    n = len(samples)
+    imgs, cs, ss, rs, fl, gs, pts_all, pts_aug = [], [], [], [], [], [], [], []
+    for i, a in enumerate(samples):
+        img = a['img']
+        pts = np.asarray(a['joint_self'], dtype=np.float64)[:, 0:2].copy()
+        c, s = mpii_center_scale(a['objpos'], a['scale_provided'], a.get('dataset', 'MPII'))
+        r, flip, gains = 0.0, False, [1.0, 1.0, 1.0]
+        if is_train:
+            s_mul, r, flip, gains = params[i] if params is not None else draw_train_params(scale_factor, rot_factor, rng)
+            s = s * s_mul
+            if flip:
+                width = img.shape[2]
+                pts = shufflelr(pts, width)
+                c[0] = width - c[0]
+        imgs.append(img); cs.append(c); ss.append(s); rs.append(float(r)); fl.append(bool(flip)); gs.append(gains)
+        pts_all.append(pts)
+        pts_aug.append(transform_pts(pts, c, s, r, out_res, std_size))
+    inp = augment_batch(imgs, np.stack(cs), np.asarray(ss), rs, fl, np.asarray(gs), res=inp_res, size=std_size)
+    pa = torch.from_numpy(np.stack(pts_aug).astype(np.float64)).to(inp.device)
+    heatmap = pts2heatmap(pa, (out_res, out_res), sigma)
+    meta = {'center': np.stack(cs), 'scale': np.asarray(ss), 'rot': np.asarray(rs), 'pts': np.stack(pts_all), 'pts_aug': np.stack(pts_aug)}
+    return inp, heatmap, meta

@@ -72,6 +72,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--bf16', type=_str2bool, default=False, help='bf16 activation storage + bf16 MFMA forward (gradients, weights, RMSprop fp32)')
     p.add_argument('--bf16_grads', type=_str2bool, default=False, help='with --bf16: gradient tensors of backward stored as bf16 too')
     p.add_argument('--synthetic', type=int, default=0, help='>0: that many synthetic batches per epoch instead of MPII')
+    p.add_argument('--augment', action='store_true', help='with --synthetic: raw variable-size samples prepared on the GPU '
+                   '(scale / rotation jitter, flip, colour, crop: data/mpii_for_mpii_22.py:120-145) instead of ready-made batches')
     return p
 
 
@@ -220,6 +222,47 @@ class SyntheticLoader:
             yield img.to(self.device), pts2heatmap(pts.to(self.device), (64, 64), 1)     # targets rendered on the GPU
 
 
+class SyntheticRawSource:
+    """Stand-in for the decoded MPII samples (`--synthetic N --augment`): `count` random images of varying size with an
+    annotation record each ('joint_self', 'objpos', 'scale_provided'), already on the GPU as a JPEG decoder would leave them."""
+
+    def __init__(self, count: int, class_num: int, device, seed: int = 0):
+        self.count, self.k, self.device, self.seed = count, class_num, device, seed
+
+    def __iter__(self):
+        import numpy as np
+        rng = np.random.RandomState(self.seed)
+        for _ in range(self.count):
+            h, w = int(rng.randint(300, 480)), int(rng.randint(300, 640))
+            img = torch.from_numpy(rng.uniform(0, 1, size=(3, h, w)).astype('float32')).to(self.device)
+            objpos = [w * rng.uniform(0.35, 0.65), h * rng.uniform(0.35, 0.65)]
+            scale = rng.uniform(0.9, 1.6)
+            joints = np.stack([objpos[0] + rng.uniform(-60, 60, self.k) * scale, objpos[1] + rng.uniform(-80, 80, self.k) * scale], 1)
+            yield {'img': img, 'joint_self': joints, 'objpos': objpos, 'scale_provided': scale, 'dataset': 'MPII'}
+
+
+class AugmentedLoader:
+    """Batches raw samples and prepares them on the GPU the way `MPII.__getitem__` does on the CPU
+    (data/mpii_for_mpii_22.py:86-145; cu_net_amd.augment.prepare_batch): yields (inp, heatmap, meta)."""
+
+    def __init__(self, source: Iterable, batch: int, is_train: bool = True, scale_factor: float = 0.25, rot_factor: float = 30.0, seed=None):
+        self.source, self.batch, self.is_train = source, batch, is_train
+        self.scale_factor, self.rot_factor = scale_factor, rot_factor
+        import numpy as np
+        self.rng = np.random.RandomState(seed) if seed is not None else np.random
+
+    def __iter__(self):
+        from .augment import prepare_batch
+        buf = []
+        for a in self.source:
+            buf.append(a)
+            if len(buf) == self.batch:
+                yield prepare_batch(buf, self.is_train, scale_factor=self.scale_factor, rot_factor=self.rot_factor, rng=self.rng)
+                buf = []
+        if buf:
+            yield prepare_batch(buf, self.is_train, scale_factor=self.scale_factor, rot_factor=self.rot_factor, rng=self.rng)
+
+
 # ---- loops ------------------------------------------------------------------------------------
 def train_epoch(loader: Iterable, trainer: FusedTrainer, epoch: int, opt, idx: List[int] = TRAIN_ACC_IDX, log=print):
     """cu-net.py:152-216: returns (mean loss, mean PCKh on heat-map resolution)."""
@@ -309,7 +352,11 @@ def main(argv=None, train_loader: Optional[Iterable] = None, val_loader: Optiona
     if train_loader is None:
         if opt.synthetic <= 0:
             raise SystemExit('no dataset in this repository: pass --synthetic N or call main(train_loader=..., val_loader=...)')
-        train_loader = SyntheticLoader(opt.synthetic, per_rank, opt.class_num, dev, seed=100 + rank)
+        if getattr(opt, 'augment', False):
+            train_loader = AugmentedLoader(SyntheticRawSource(opt.synthetic * per_rank, opt.class_num, dev, seed=100 + rank), per_rank,
+                                           is_train=True, seed=200 + rank)
+        else:
+            train_loader = SyntheticLoader(opt.synthetic, per_rank, opt.class_num, dev, seed=100 + rank)
         val_loader = SyntheticLoader(max(opt.synthetic // 4, 1), per_rank, opt.class_num, dev, seed=9000 + rank)
     log = print if rank == 0 else (lambda *a, **k: None)
     if not opt.is_train:

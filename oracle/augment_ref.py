@@ -159,3 +159,35 @@ def augment_sample(img_chw, center, scale, rot=0.0, flip=False, gain=(1.0, 1.0, 
                                 acc += wy * wx * img[:, yy, xx]
             out[:, oy, ox] = acc / (k * k)
     return out.astype(np.float32)
+
+
+# ---- the loader's per-sample recipe (data/mpii_for_mpii_22.py:86-145), one sample at a time on the CPU -------------------
+def sample_from_bounded_gaussian(x, rng):                               # data/mpii_for_mpii_22.py:12-13
+    return max(-2 * x, min(2 * x, rng.randn() * x))
+
+
+def getitem_train(img_chw, joint_self, objpos, scale_provided, rng, inp_res=256, out_res=64, scale_factor=0.25, rot_factor=30,
+                  std_size=200, is_train=True):
+    """Restates MPII.__getitem__ for dataset 'MPII' (data/mpii_for_mpii_22.py:86-145) with the draws taken from `rng` (a
+    numpy RandomState standing in for the module-level np.random) in the reference's order.  Returns
+    (inp 3 x res x res, pts_aug K x 2 int, c, s, r, pts)."""
+    pts = np.asarray(joint_self, dtype=np.float64)[:, 0:2].copy()      # :93-95
+    c = np.array(objpos, dtype=np.float64)                              # :98
+    s = float(scale_provided)                                           # :100
+    c[1] = c[1] + 15 * s                                                # :104
+    s = s * 1.25                                                        # :105
+    img = np.array(img_chw, dtype=np.float32, copy=True)
+    r, flip, gain = 0, False, (1.0, 1.0, 1.0)
+    if is_train:
+        s = s * (2 ** sample_from_bounded_gaussian(scale_factor, rng))  # :122
+        r = sample_from_bounded_gaussian(rot_factor, rng)               # :123
+        if rng.uniform(0, 1, 1) <= 0.6:                                 # :124-125
+            r = 0
+        if rng.random_sample() <= 0.5:                                  # :128-131
+            flip = True
+            pts = shufflelr(pts, width=img.shape[2])
+            c[0] = img.shape[2] - c[0]
+        gain = (rng.uniform(0.6, 1.4), rng.uniform(0.6, 1.4), rng.uniform(0.6, 1.4))      # :134-136
+    inp = augment_sample(img, c, s, r, flip, gain, res=inp_res, size=std_size)            # :139-141
+    pts_aug = transform_pts(pts, c, s, r, out_res, std_size)            # :143-144
+    return inp, pts_aug, c, s, r, pts

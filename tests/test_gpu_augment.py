@@ -43,3 +43,35 @@ def test_augment_identity_window_is_a_copy():
     assert np.array_equal(out[0], np.transpose(canvas, (2, 0, 1)).astype(np.float32))
     canvas_f = A.crop_canvas(np.transpose(img[:, :, ::-1].astype(np.float64), (1, 2, 0)), c[1], float(s[1]), 0, res, 200)
     assert np.array_equal(out[1], np.transpose(canvas_f, (2, 0, 1)).astype(np.float32))
+
+
+def test_prepare_batch_is_the_loaders_getitem():
+    """cu_net_amd.prepare_batch == oracle restatement of MPII.__getitem__ (data/mpii_for_mpii_22.py:86-145) sample by sample under the
+    same numpy seed: network input (bilinear resampler of oracle/augment_ref.py), target heat maps (bit-exact renderer), meta."""
+    from oracle import decode_ref as D
+    rng = np.random.RandomState(11)
+    samples, raw = [], []
+    for i in range(6):
+        h, w = int(rng.randint(120, 200)), int(rng.randint(120, 260))
+        img = rng.uniform(0, 1, size=(3, h, w)).astype(np.float32)
+        objpos = [w * rng.uniform(0.4, 0.6), h * rng.uniform(0.4, 0.6)]
+        scale = rng.uniform(0.3, 0.6)
+        joints = np.concatenate([np.stack([objpos[0] + rng.uniform(-40, 40, 16), objpos[1] + rng.uniform(-50, 50, 16)], 1), np.ones((16, 1))], 1)
+        raw.append((img, joints, objpos, scale))
+        samples.append({'img': torch.from_numpy(img).cuda(), 'joint_self': joints, 'objpos': objpos, 'scale_provided': scale})
+    inp, heat, meta = cu_net_amd.prepare_batch(samples, True, inp_res=64, out_res=16, rng=np.random.RandomState(77))
+    r2 = np.random.RandomState(77)
+    flips = 0
+    for i, (img, joints, objpos, scale) in enumerate(raw):
+        ref_inp, pts_aug, c, s, r, pts = A.getitem_train(img, joints, objpos, scale, r2, inp_res=64, out_res=16)
+        assert np.abs(inp[i].cpu().numpy() - ref_inp).max() <= 2e-6, i
+        assert np.array_equal(meta['pts_aug'][i], pts_aug) and np.array_equal(meta['pts'][i], pts)
+        assert meta['scale'][i] == s and meta['rot'][i] == r and np.array_equal(meta['center'][i], c)
+        ref_heat = D.pts2heatmap(pts_aug.astype(np.float64), (16, 16), 1)[0]
+        assert np.array_equal(heat[i].cpu().numpy(), ref_heat.astype(np.float32)), i
+        flips += int(not np.array_equal(pts, joints[:, :2]))
+    assert 0 < flips < 6                                     # both branches were taken
+    # validation samples: no jitter, no draws
+    inp_v, heat_v, meta_v = cu_net_amd.prepare_batch(samples[:2], False, inp_res=64, out_res=16)
+    ref_v = A.getitem_train(raw[0][0], raw[0][1], raw[0][2], raw[0][3], None, inp_res=64, out_res=16, is_train=False)
+    assert np.abs(inp_v[0].cpu().numpy() - ref_v[0]).max() <= 2e-6 and meta_v['rot'][0] == 0

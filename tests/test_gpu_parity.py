@@ -302,6 +302,16 @@ def test_driver_trains_validates_and_resumes(tmp_path):
     assert h2.loss[2]['train_loss'] < h.loss[0]['train_loss']
 
 
+def test_driver_with_device_side_sample_preparation(tmp_path):
+    """--augment: raw variable-size samples go through cu_net_amd.prepare_batch (jitter, flip, colour, crop, targets on the GPU)
+    inside the driver's loop."""
+    from cu_net_amd import driver as D
+    args = ['--exp_id', 'aug', '--exp_dir', str(tmp_path), '--layer_num', '2', '--order', '1', '--class_num', '16',
+            '--loss_num', '2', '--bs', '4', '--synthetic', '3', '--augment', '--print_freq', '100', '--lr', '1e-3', '--nEpochs', '1']
+    h = D.main(args)
+    assert [e['epoch'] for e in h.epoch] == [0] and h.loss[0]['train_loss'] > 0 and h.loss[0]['train_loss'] == h.loss[0]['train_loss']
+
+
 def test_target_synthesis_bit_exact():
     """Gaussian target maps rendered on the GPU vs the oracle (== the reference, G11): bit-exact, sigma 1 and 2."""
     import numpy as np

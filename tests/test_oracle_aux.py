@@ -127,3 +127,27 @@ def test_augment_geometry_matches_executed_reference():
     assert tuple(br - ul) == (32, 32)
     canvas = A.crop_canvas(np.transpose(small, (1, 2, 0)), np.array([25.0, 20.0]), 32 / 200.0, 0, 32, 200)
     assert np.allclose(out, np.transpose(canvas, (2, 0, 1)).astype(np.float32), atol=1e-7)
+
+
+def test_train_sample_draws_follow_the_reference_order():
+    """cu_net_amd.augment.draw_train_params / mpii_center_scale against the oracle's restatement of MPII.__getitem__
+    (data/mpii_for_mpii_22.py:99-136): same numpy seed -> same scale jitter, rotation, flip decision, colour gains."""
+    import numpy as np
+    from cu_net_amd import augment as G
+    from oracle import augment_ref as A
+    img = np.random.RandomState(0).uniform(0, 1, size=(3, 90, 120)).astype(np.float32)
+    joints = np.random.RandomState(1).uniform(10, 80, size=(16, 3))
+    for seed in range(12):
+        r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+        inp, pts_aug, c, s, r, pts = A.getitem_train(img, joints, [60.0, 40.0], 0.4, r1, inp_res=32, out_res=8)
+        c2, s2 = G.mpii_center_scale([60.0, 40.0], 0.4)
+        s_mul, rr, flip, gains = G.draw_train_params(0.25, 30.0, r2)
+        s2 = s2 * s_mul
+        p2 = joints[:, :2].copy()
+        if flip:
+            p2 = G.shufflelr(p2, 120)
+            c2[0] = 120 - c2[0]
+        assert r1.randn() == r2.randn()                      # both consumed exactly the same number of draws
+        assert s == s2 and r == rr and np.array_equal(c, c2) and np.array_equal(pts, p2)
+        assert np.array_equal(G.transform_pts(p2, c2, s2, rr, 8, 200), pts_aug)
+    assert abs(G.sample_from_bounded_gaussian(0.25, np.random.RandomState(5))) <= 0.5
