@@ -100,6 +100,13 @@ struct Wg3Args {
     int c0, CW;            // channel slice of this launch (CW <= 320, multiple of 32)
     int any_ups;
 };
+// LDS geometry of the stem weight gradient (wgrad3_stem_kernel): an input image row is stored as 3 channel rows of CP floats
+// (3 zero columns left and right), a ring row every RP floats; CP = 17 and RP = 7 (mod 32) put im2col column k = c*49 + ky*7 + kx
+// on bank k (mod 32): the 32 lanes of a ds_read_b32 group never collide.
+__host__ __device__ inline int stem_cp(int IW) { int cp = IW + 6; return cp + ((17 - cp % 32) + 32) % 32; }
+__host__ __device__ inline int stem_rp(int IW) { int rp = 3 * stem_cp(IW); return rp + ((7 - rp % 32) + 32) % 32; }
+constexpr int STEM_CHUNK = 64;          // output pixels per dY chunk
+constexpr int STEM_K = 147;             // 3 * 7 * 7
 struct WgReduceEntry {     // grads[dst + i] = sum_s ws[part + s*numel + i]
     int64_t part;          // float offset in the workspace float region
     int64_t dst;           // float offset in the gradient arena

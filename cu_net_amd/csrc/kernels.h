@@ -10,6 +10,9 @@ hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStr
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
 bool wgrad3_supported(const WgradArgs& a);
 hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
+size_t wgrad3_stem_lds_bytes(int IW, int rows);
+bool wgrad3_stem_supported(const WgradArgs& a, int rows);
+hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows, hipStream_t s);
 bool wgrad3_3x3_supported(const WgradArgs& a);
 bool wgrad3_3x3_on_bf16_mfma(const WgradArgs& a);      // bf16 x and dY, W in {16, 32, 64}
 hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);

@@ -413,6 +413,26 @@ void Plan::layout_workspace() {
         for (int b = 0; b < nb; ++b) {
             wgred_first[b] = n_wgred;
             for (auto& n : nodes) {
+                if (n.type == N_STEM_CONV && n.bucket == b && enable && po.wgrad3_stem) {
+                    // stem 7x7/2: a workgroup owns `rows` output rows of one image (wgrad3_stem_kernel); ~one workgroup per CU
+                    const ConvInfo& c = convs[n.conv];
+                    const TensorInfo& o = tensors[n.out];
+                    const int IW = cfg.width;
+                    const bool oks = c.Cout == 128 && o.ld == 128 && c.Cin == STEM_K && o.W % STEM_CHUNK == 0 && IW % 8 == 0 &&
+                                     cfg.width == 2 * o.W && cfg.height == 2 * o.H && o.rows() >= min_m;
+                    if (!oks) continue;
+                    int rows_max = 1;
+                    while (rows_max < o.H && (int64_t)((((2 * (rows_max + 1) + 6) * stem_rp(IW) + 3) & ~3) + STEM_CHUNK * 128) * 4 <= 160 * 1024 &&
+                           (int64_t)(2 * (rows_max + 1) + 5) * 3 * (IW / 4) <= 16 * 512) ++rows_max;
+                    int wpi = std::max(1, std::min(o.H, 256 / std::max(1, o.N)));        // 256 CUs
+                    int rows = (o.H + wpi - 1) / wpi;
+                    if (rows > rows_max) rows = rows_max;
+                    wpi = (o.H + rows - 1) / rows;
+                    n.wg3_S = n.wg3_S16 = o.N * wpi; n.wg3_rows = n.wg3_rows16 = rows; n.wg3_wpi = wpi; n.wg3_entry = n_wgred++;
+                    wgred_count[b]++;
+                    wgred_maxnumel[b] = std::max(wgred_maxnumel[b], c.Cout * c.Cin);
+                    continue;
+                }
                 if (n.type != N_CONV || n.bucket != b || !enable) continue;
                 const ConvInfo& c = convs[n.conv];
                 const TensorInfo& o = tensors[n.out];
@@ -516,7 +536,7 @@ void Plan::layout_workspace() {
         for (int b = 0; b <= cfg.layer_num; ++b) {
             int64_t sum = 0;
             for (auto& n : nodes)
-                if (n.wg3_S > 0 && n.bucket == b) { n.wg3_part = sum; sum += round_up64((int64_t)n.wg3_S * convs[n.conv].Cout * n.Ccat * n.taps, 64); }
+                if (n.wg3_S > 0 && n.bucket == b) { n.wg3_part = sum; sum += round_up64((int64_t)n.wg3_S * wg3_numel(n), 64); }
             region = std::max(region, sum);
         }
         const int64_t base = take(region);

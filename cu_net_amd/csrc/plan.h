@@ -74,15 +74,18 @@ struct Node {
     // LDS-staged 1x1 weight gradient (wgrad3): pixel splits, rows per split, float offset of the [S][Cout][Ccat]
     // partial tiles inside the per-bucket partial region, index into the reduce table; wg3_S == 0: not eligible
     int wg3_S = 0, wg3_rows = 0, wg3_entry = -1;
-    int wg3_S16 = 0, wg3_rows16 = 0;      // the same with bf16 gradient tensors: those kernels are HBM-bound, fewer and longer splits (less partial traffic) win
+    int wg3_S16 = 0, wg3_rows16 = 0;
+    int wg3_wpi = 0;                      // stem: workgroups per image (wg3_S = N * wg3_wpi, wg3_rows = output rows per workgroup)      // the same with bf16 gradient tensors: those kernels are HBM-bound, fewer and longer splits (less partial traffic) win
     int64_t wg3_part = -1;
 };
 
-struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 96; };
+struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 96, wgrad3_stem = 1; };
 PlannerOptions& planner_options();
 
 struct Plan {
     cunet_cfg cfg;
+    // elements of one wgrad3 partial tile == of the node's weight tensor
+    int64_t wg3_numel(const Node& n) const { return n.type == N_STEM_CONV ? (int64_t)convs[n.conv].Cout * convs[n.conv].Cin : (int64_t)convs[n.conv].Cout * n.Ccat * n.taps; }
     std::vector<int> anchors;
     std::vector<StateEntry> state;
     std::map<std::string, int> state_index;

@@ -63,6 +63,7 @@ struct cunet_plan {
 // dispatch in bwd_node and for the reduce tables built at bind.)
 static bool wg3_active(const Plan& P, const Node& n, int xmode) {
     if (n.wg3_S <= 0) return false;
+    if (n.type == N_STEM_CONV) return true;                      // (fp32 image and fp32 dY in every mode)
     // 3x3 ring kernel (bf16 x / dY are widened to fp32 on the way into LDS).  Alone on the GPU it takes 47 / 29 / 21 us at
     // W = 32 / 16 / 8 against 31 / 16 / 14 us of the per-wave kernel (two barriers per image row of W/2 MFMA steps) and wins
     // at W = 64 (88 vs 106 us); next to the fp32 data-gradient chain it is ahead at every width (fewer atomics, one read
@@ -141,6 +142,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "wgrad3_max_splits") o.wgrad3_max_splits = value;
     else if (n == "wgrad3_min_chunks_bf16") o.wgrad3_min_chunks_bf16 = value;
     else if (n == "wgrad3_max_splits_bf16") o.wgrad3_max_splits_bf16 = value;
+    else if (n == "wgrad3_stem") o.wgrad3_stem = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -271,8 +273,8 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         if (n.wg3_S > 0) {
             for (int mode = 0; mode < 2; ++mode) {
                 WgReduceEntry& e = h->wgred[(size_t)mode * nwg + n.wg3_entry];
-                e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.numel = P.convs[n.conv].Cout * n.Ccat * n.taps;
-                e.taps = n.taps; e.pad_ = 0;
+                e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.numel = (int)P.wg3_numel(n);
+                e.taps = n.type == N_STEM_CONV ? 1 : n.taps; e.pad_ = 0;
                 e.S = wg3_active(P, n, mode ? 2 : 0) ? (mode ? n.wg3_S16 : n.wg3_S) : 0;
             }
         }
@@ -294,7 +296,8 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
             else HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, mode == 1 ? least : greatest));
         }
         h->fork_ev.resize(P.nodes.size());
-        for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const unsigned fork_flags = hipEventDisableTiming | (tune_int("CUNET_FORK_FLAGS", 0) ? hipEventReleaseToDevice : 0);
+        for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, fork_flags));
         h->done_ev.resize(P.nodes.size());
         for (auto& e : h->done_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
@@ -451,9 +454,13 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
     Exec E(h);
     // weight gradients only read d(loss)/d(out) and activations and only write dW: they fork to the side stream
     hipStream_t ws = s;
-    if (h->use_side && h->side && (n.type == N_CONV || n.type == N_STEM_CONV)) {
-        HIPCHK(hipEventRecord(h->fork_ev[node_index], s));
-        HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[node_index], 0));
+    static const int fork_after = tune_int("CUNET_FORK_AFTER", 0);
+    const bool forks = h->use_side && h->side && (n.type == N_CONV || n.type == N_STEM_CONV);
+    if (forks) {
+        if (!(fork_after && n.type == N_CONV)) {
+            HIPCHK(hipEventRecord(h->fork_ev[node_index], s));
+            HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[node_index], 0));
+        }
         ws = h->side;
     }
     Plan& P = h->plan;
@@ -496,6 +503,10 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             if (!done)
                 PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
                      launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
+        }
+        if (forks && fork_after) {
+            HIPCHK(hipEventRecord(h->fork_ev[node_index], s));
+            HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[node_index], 0));
         }
         {   // weight gradient
             WgradArgs w{};
@@ -549,7 +560,12 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
         w.dw = h->grads + c.w;
         w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
-        PROF_ON(ws, PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout, launch_wgrad(w, WGL_STEM, cus, ws));
+        if (wg3_active(P, n, E.xmode)) {      // (an unsupported shape is an error here: the reduce table already expects partial tiles)
+            PROF_ON(ws, PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout,
+                    launch_wgrad3_stem(w, E.wsf + n.wg3_part, n.wg3_wpi, n.wg3_rows, ws));
+        } else {
+            PROF_ON(ws, PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout, launch_wgrad(w, WGL_STEM, cus, ws));
+        }
     }
     return CUNET_OK;
 }
@@ -991,7 +1007,7 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     const int rc = bwd_node(h, n, node, s);
     if (rc != CUNET_OK) return rc;
     if (n.wg3_S > 0) {
-        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, P.convs[n.conv].Cout * n.Ccat * n.taps, (h->use_side && h->side) ? h->side : s);
+        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, (int)P.wg3_numel(n), (h->use_side && h->side) ? h->side : s);
         if (rcr != CUNET_OK) return rcr;
     }
     if (n.type == N_CONV) {                // this node's contribution to each of its inputs, and its BN parameter gradients

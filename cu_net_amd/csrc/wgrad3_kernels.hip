@@ -1021,6 +1021,190 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_bf16_kernel(const W
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The stem's 7x7 / stride-2 weight gradient (autograd wgrad of models/cu_net.py:300; K = 3*7*7 = 147, Cout = 128):
+//     dW[n][c][ky][kx] = sum_{img,oy,ox} dY[img][oy][ox][n] * X[img][c][2 oy + ky - 3][2 ox + kx - 3]
+// It is the LAST kernel of a step and runs alone, so its duration is on the critical path.  wgrad2_stem_kernel gathers
+// the im2col operand per lane from the NCHW image (one 4-byte load per MFMA, dY read twice, atomic commit: 292 us,
+// 51 TFLOP/s).  Here a 512-thread workgroup owns `rows` consecutive output rows of ONE image: the 2 rows + 5 input rows
+// they touch are staged ONCE in LDS (zero borders written as zeros, so a tap is an LDS offset), dY is streamed through
+// LDS in chunks of 64 output pixels (next chunk's global loads in flight across the MFMAs), wave w owns output-channel tile
+// (w & 3) and k-tiles {0,1,2} (w < 4) or {3,4}; the im2col operand of lane k is ONE conflict-free ds_read_b32 (stem_cp /
+// stem_rp in common.h).  Partial tiles part[split][n][147], summed by the stem bucket's reduce: no atomics.
+template <int HF> struct StemTiles { static constexpr int N = HF == 0 ? 3 : 2; static constexpr int K0 = HF == 0 ? 0 : 3; };
+
+__global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const WgradArgs& p = q.w;
+    const int OH = p.H, OW = p.W, IH = p.IH, IW = p.IW;
+    const int CP = stem_cp(IW), RP = stem_rp(IW);
+    const int rows = q.rows_per_split;                     // output rows per workgroup
+    const int NR = 2 * rows + 5;                           // staged input rows; slot NR is all zeros (k >= 147 lanes)
+    const int DYOFF = (NR + 1) * RP;                       // [64][128] floats (16-byte aligned: rounded up below)
+    const int dyoff = (DYOFF + 3) & ~3;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int wpi = q.c0;                                  // workgroups per image
+    const int img = blockIdx.x / wpi;
+    const int r0 = (blockIdx.x - img * wpi) * rows;
+    int r1 = r0 + rows;
+    if (r1 > OH) r1 = OH;
+
+    // ---- input rows 2 r0 - 3 ... (zeros outside the image and in the 3 + 3 border columns).  All global loads of the
+    // prologue are issued before anything waits for one (a load-then-store loop pays the HBM latency per iteration).
+    typedef float f32x4n __attribute__((ext_vector_type(4)));      // (a native vector: arrays of HIP's float4 struct end up in scratch here)
+    constexpr int MAXIN = 16;                              // float4 per thread: (2*13+5) rows * 3 * 64 float4 / 512 threads = 11.6
+    const int per_row = 3 * (IW >> 2);                     // float4 per input row
+    const int total = NR * per_row;
+    f32x4n iv[MAXIN];
+    int idst[MAXIN];
+#pragma unroll
+    for (int u = 0; u < MAXIN; ++u) {
+        const int i = tid + WG3_THREADS * u;
+        idst[u] = -1;
+        iv[u] = f32x4n{0.f, 0.f, 0.f, 0.f};
+        if (i < total) {
+            const int j = i / per_row;
+            const int rem = i - j * per_row;
+            const int c = rem / (IW >> 2);
+            const int x4 = rem - c * (IW >> 2);
+            const int ir = 2 * r0 - 3 + j;
+            if (ir >= 0 && ir < IH) {
+                iv[u] = *reinterpret_cast<const f32x4n*>(p.img + (((size_t)img * 3 + c) * IH + ir) * IW + 4 * x4);
+                idst[u] = j * RP + c * CP + 3 + 4 * x4;
+            }
+        }
+    }
+    for (int i = tid; i < dyoff; i += WG3_THREADS) lds[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MAXIN; ++u)
+        if (idst[u] >= 0) {
+            float* d = lds + idst[u];
+            d[0] = iv[u][0]; d[1] = iv[u][1]; d[2] = iv[u][2]; d[3] = iv[u][3];
+        }
+
+    // ---- dY chunks: 64 pixels x 128 channels = 2048 float4, 4 per thread
+    const int cpr = OW / STEM_CHUNK;                       // chunks per output row
+    const int nchunks = (r1 - r0) * cpr;
+    f32x4n dv[4];
+    auto issue = [&](int ci) {
+        const int oy = r0 + ci / cpr;
+        const int x0 = STEM_CHUNK * (ci - (ci / cpr) * cpr);
+        const float* src = p.dy + (((size_t)img * OH + oy) * OW + x0) * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] = *reinterpret_cast<const f32x4n*>(src + 4 * (tid + WG3_THREADS * j));
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4n*>(lds + dyoff + 4 * (tid + WG3_THREADS * j)) = dv[j];
+    };
+
+    const int nt = wave & 3;
+    const int half = wave >> 2;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // this lane's im2col column per k-tile: offset inside the staged rows, and whether it exists (k < 147)
+    int koff[3], kmul[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = (half * 3 + t) * 32 + li;
+        const bool valid = k < STEM_K && (half == 0 || t < 2);
+        const int c = k / 49, rem = k - (k / 49) * 49;
+        const int ky = rem / 7, kx = rem - (rem / 7) * 7;
+        koff[t] = valid ? ky * RP + c * CP + kx : NR * RP;
+        kmul[t] = valid ? 1 : 0;
+    }
+
+    issue(0);
+    commit();
+    __syncthreads();
+    auto chunk_mma = [&](auto HF, int ci) {
+        constexpr int CT = StemTiles<decltype(HF)::value>::N;
+        const int oy = r0 + ci / cpr;
+        const int x0 = STEM_CHUNK * (ci - (ci / cpr) * cpr);
+        const int aoff = dyoff + hi * 128 + nt * 32 + li;
+        int boff[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) boff[t] = koff[t] + kmul[t] * (2 * (oy - r0)) * RP + 2 * (x0 + hi);
+        float a_cur = lds[aoff], b_cur[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) b_cur[t] = lds[boff[t]];
+#pragma unroll 4
+        for (int pp = 0; pp < STEM_CHUNK / 2; ++pp) {
+            const int pn = pp + 1 < STEM_CHUNK / 2 ? pp + 1 : pp;
+            const float a_nxt = lds[aoff + 2 * pn * 128];
+            float b_nxt[CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) b_nxt[t] = lds[boff[t] + 4 * pn];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + CT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) b_cur[t] = b_nxt[t];
+        }
+    };
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const bool more = ci + 1 < nchunks;
+        if (more) issue(ci + 1);
+        if (half == 0) chunk_mma(std::integral_constant<int, 0>{}, ci);
+        else chunk_mma(std::integral_constant<int, 1>{}, ci);
+        __syncthreads();
+        if (more) commit();
+        __syncthreads();
+    }
+
+    float* out = q.part + (size_t)blockIdx.x * 128 * STEM_K;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = (half * 3 + t) * 32 + li;
+        if (k >= STEM_K || (half == 1 && t == 2)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)n * STEM_K + k] = acc[t][r];
+        }
+    }
+}
+
+// rows: output rows per workgroup; wpi: workgroups per image (wpi * rows >= OH); part: [N * wpi][128][147]
+size_t wgrad3_stem_lds_bytes(int IW, int rows) {
+    return (size_t)((((2 * rows + 6) * stem_rp(IW) + 3) & ~3) + STEM_CHUNK * 128) * 4;
+}
+bool wgrad3_stem_supported(const WgradArgs& a, int rows) {
+    if (a.img == nullptr || a.Cout != 128 || a.lddy != 128 || a.Ccat != STEM_K) return false;
+    if (a.W % STEM_CHUNK || a.IW % 8 || a.IW != 2 * a.W || a.IH != 2 * a.H || rows < 1) return false;
+    if ((long)(2 * rows + 5) * 3 * (a.IW / 4) > 16 * WG3_THREADS) return false;      // prologue registers (MAXIN)
+    return wgrad3_stem_lds_bytes(a.IW, rows) <= 160 * 1024;
+}
+hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows, hipStream_t s) {
+    if (!wgrad3_stem_supported(a, rows) || wpi < 1 || (long)wpi * rows < a.H) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    Wg3Args q{};
+    q.w = a;
+    q.part = part;
+    q.rows_per_split = rows;
+    q.c0 = wpi;
+    const int N = a.M / (a.H * a.W);
+    hipLaunchKernelGGL(wgrad3_stem_kernel, dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+    return hipGetLastError();
+}
+
 bool wgrad3_3x3_supported(const WgradArgs& a) {
     if (a.taps != 9 || a.Cout != WG3C_N || a.lddy != WG3C_N || a.Ccat != WG3C_C || a.nseg != 1) return false;
     if (a.seg[0].ups || a.seg[0].C != WG3C_C || a.seg[0].ld % 4) return false;
