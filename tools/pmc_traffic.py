@@ -14,7 +14,8 @@ import sys
 import pandas as pd
 
 CLASSES = [
-    (r'wgrad3_3x3_kernel', 'conv3x3_bwd_weight'),
+    (r'wgrad3_stem_kernel', 'stem_bwd_weight'),
+    (r'wgrad3_3x3_kernel|wgrad3_3x3_bf16_kernel', 'conv3x3_bwd_weight'),
     (r'wgrad3_kernel|wgrad3_bf16_kernel', 'conv1x1_bwd_weight'),
     (r'wgrad_reduce_kernel', 'wgrad_partial_reduce'),
     (r'wgrad2_stem_kernel', 'stem_bwd_weight'),
