@@ -210,7 +210,11 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     peak_mfma = PEAK_BF16_MFMA_TFLOPS if dominant.endswith('_bf16') else PEAK_F32_MFMA_TFLOPS      # classes that run on bf16 MFMA carry the suffix
     roof = None
     if have_classes and ms > 0:
-        if fl > 0:
+        # the roof that bounds the class: arithmetic intensity of its algorithmic work against the ridge of ITS MFMA peak
+        # (fp32 1x1 weight gradient: 46 flop/B > 19.7 -> MFMA; the same contraction on bf16 MFMA: 91 flop/B < 312 -> HBM)
+        ai = fl / by if by > 0 else float('inf')
+        ridge = peak_mfma * 1e12 / (PEAK_HBM_GBS * 1e9)
+        if fl > 0 and ai >= ridge:
             achieved = fl / (ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 3), 'peak': peak_mfma,
                     'unit': 'TFLOP/s', 'frac': round(achieved / peak_mfma, 4), 'traffic': None,
@@ -221,6 +225,9 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
             roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS,
                     'unit': 'GB/s', 'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
                     'launches': cnt, 'avg_launch_us': round(1e3 * ms / max(cnt, 1), 2)}
+            if fl > 0:
+                roof['achieved_TFLOPs'] = round(fl / (ms * 1e-3) / 1e12, 2)
+                roof['arithmetic_intensity_flop_per_byte'] = round(ai, 1)
         tb, src = load_traffic(dominant, f'{L},{K},{bs},{"f32" if not bf16 else mode}')
         if tb is not None:
             roof['traffic'] = tb
