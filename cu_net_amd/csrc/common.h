@@ -66,6 +66,9 @@ struct ConvArgs {
     int qin_bits;          // > 0: QuanInput2d of that many bits sits between the ReLU and the conv (utils/quantize.py:47-73, placement
                            // models/cu_net_prev_version_wig.py:96-98,277-279): forward loaders quantise the activation,
                            // EP_BWD applies its straight-through mask (no gradient where the activation is >= 1)
+    int wshift, hwshift;   // log2(W), log2(H*W) when both are powers of two (every level of a 2^k x 2^k input), else -1: the kernels
+                           // split a row index with shifts instead of two emulated divisions per tile and per epilogue row group
+    int any_ups;           // some segment is read through the nearest-upsample map
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)

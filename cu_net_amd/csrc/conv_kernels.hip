@@ -94,10 +94,18 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
         const int m = tile * 32 + li;                // this lane's A row
         const int mc = m < p.M ? m : p.M - 1;
-        const int nimg = mc / HW;
-        const int rem = mc - nimg * HW;
-        const int py = rem / p.W;
-        const int px = rem - py * p.W;
+        int nimg, py, px;
+        if (p.wshift >= 0) {                         // power-of-two geometry (uniform): shifts instead of emulated divisions
+            nimg = mc >> p.hwshift;
+            const int rem = mc & (HW - 1);
+            py = rem >> p.wshift;
+            px = rem & (p.W - 1);
+        } else {
+            nimg = mc / HW;
+            const int rem = mc - nimg * HW;
+            py = rem / p.W;
+            px = rem - py * p.W;
+        }
         const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
 
         f32x16 acc[NT];
@@ -294,12 +302,20 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             for (int k = 0; k < 4; ++k) {
                 int m4 = mrow0 + 8 * k + 4 * hi;
                 int base = 0;
-                if (w4) {                         // rows 4k..4k+3 share an image row: one division per group (uniform branch)
+                if (w4 && p.any_ups) {            // rows 4k..4k+3 share an image row: one split per group (uniform branches)
                     const int mq = m4 < p.M ? m4 : p.M - 1;
-                    const int ni = mq / HW;
-                    const int rm = mq - ni * HW;
-                    const int yy = rm / p.W;
-                    const int xx = rm - yy * p.W;
+                    int ni, yy, xx;
+                    if (p.wshift >= 0) {
+                        ni = mq >> p.hwshift;
+                        const int rm = mq & (HW - 1);
+                        yy = rm >> p.wshift;
+                        xx = rm & (p.W - 1);
+                    } else {
+                        ni = mq / HW;
+                        const int rm = mq - ni * HW;
+                        yy = rm / p.W;
+                        xx = rm - yy * p.W;
+                    }
                     base = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
                 }
 #pragma unroll
@@ -307,7 +323,9 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                     int mm = m4 + j;
                     mm = (FAST || mm < p.M) ? mm : p.M - 1;
                     rowP[4 * k + j] = mm;
-                    if (w4) {
+                    if (!p.any_ups) {
+                        rowUp[4 * k + j] = mm;    // never read through the up-sample map
+                    } else if (w4) {
                         rowUp[4 * k + j] = base + (j >> 1);
                     } else {
                         const int ni = mm / HW;
@@ -610,6 +628,14 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: work-skipping timing experiments
     ConvArgs a = a_in;
     a.dbg = dbg;
+    {
+        auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (v > 0 && (1 << l) == v) ? l : -1; };
+        const int lw = lg2(a.W), lhw = lg2(a.H * a.W);
+        a.wshift = (lw >= 0 && lhw >= 0) ? lw : -1;
+        a.hwshift = (lw >= 0 && lhw >= 0) ? lhw : -1;
+        a.any_ups = 0;
+        for (int i = 0; i < a.nseg; ++i) a.any_ups |= a.seg[i].ups;
+    }
     const int ntiles = (a.M + 31) / 32;
     const int ncol32 = (a.Nout + 31) / 32;
     const long target = 2L * 4 * num_cus;              // wave-tiles wanted: 2 per SIMD
