@@ -638,7 +638,8 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     }
     const int ntiles = (a.M + 31) / 32;
     const int ncol32 = (a.Nout + 31) / 32;
-    const long target = 2L * 4 * num_cus;              // wave-tiles wanted: 2 per SIMD
+    static const int target_x10 = tune_int("CUNET_CONV_TARGET_X10", 20);      // (swept 7 ... 20: no change)
+    const long target = (long)target_x10 * 4 * num_cus / 10;      // wave-tiles wanted: 2 per SIMD
     // channel tiles per block.  Every slice of NT tiles re-reads (and re-activates) the A operand and the
     // last slice is padded with zero tiles, so the cost of a choice is slices * (NT + overhead) tile-times:
     // a 160-channel dgrad (5 tiles) runs 2 x 3 instead of 2 x 4, a 288-channel one 3 x 3 instead of 3 x 4.
