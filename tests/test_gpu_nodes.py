@@ -86,6 +86,22 @@ def test_every_node_backward_with_quan_input(tag):
     _check_all_nodes(cfg, st, x, quan_input_bits=8)
 
 
+@pytest.mark.parametrize('n,h,w', [(1, 256, 256), (3, 128, 256), (5, 256, 128), (30, 128, 128)])
+def test_stem_weight_gradient_shapes(n, h, w):
+    """The LDS-staged stem weight gradient (wgrad3_stem_kernel) over its planning range: one output row per workgroup (N = 1),
+    rectangular images (64 / 128 output columns: one / two dY chunks per row, ragged last workgroup of an image), many images
+    (several rows per workgroup, two rounds of workgroups) -- against autograd's conv2d weight gradient, and the per-wave
+    atomic kernel it replaces on the same inputs."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=33)
+    gen = torch.Generator().manual_seed(34)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    _check_all_nodes(cfg, st, x, wgrad3_all=True, only_ops=('stem_conv',))
+    _check_all_nodes(cfg, st, x, wgrad3_all=False, only_ops=('stem_conv',))
+
+
 def test_every_node_backward_full_width_bf16_activations():
     """The same node-by-node check with bf16 activation storage (FusedTrainer(bf16=True)): the backward kernels read x
     as bf16 and compute in fp32, so against torch autograd fed with the SAME bf16-rounded activations the fp32 tolerance
@@ -111,19 +127,19 @@ def test_every_node_backward_full_width_bf16_gradient_tensors():
     _check_all_nodes(cfg, st, x, bf16=2)
 
 
-def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0):
+def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0, only_ops=None):
     """wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
     False: the planner is told to keep them on the per-wave atomic kernel (wgrad2), which stays the path of narrow heads,
     non-32-multiple concats and the stem and must remain covered at production widths."""
     from cu_net_amd._lib import set_planner_option
     set_planner_option('wgrad3_min_rows', 0 if wgrad3_all else 1 << 30)
     try:
-        _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits)
+        _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops)
     finally:
         set_planner_option('wgrad3_min_rows', 0)
 
 
-def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0):
+def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_ops=None):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
@@ -143,6 +159,10 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0):
     T = desc['tensors']
     if wgrad3_all:
         assert sum(1 for nd in desc['nodes'] if nd.get('wg3', 0) > 0) >= 20 * cfg['layer_num'], 'the planner did not select wgrad3'
+        if only_ops and 'stem_conv' in only_ops:
+            assert desc['nodes'][0]['op'] == 'stem_conv' and desc['nodes'][0]['wg3'] > 0, 'the planner did not select the LDS-staged stem kernel'
+    elif only_ops and 'stem_conv' in only_ops:
+        assert desc['nodes'][0]['wg3'] == 0
     acts = {t['name']: plan.debug_tensor(t['name']).cpu() for t in T}
     off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
 
@@ -152,6 +172,8 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0):
 
     bad = []
     for k, nd in enumerate(desc['nodes']):
+        if only_ops is not None and nd['op'] not in only_ops:
+            continue
         gen = torch.Generator().manual_seed(1000 + k)
         oname = T[nd['out']]['name']
         dy = torch.randn(acts[oname].shape, generator=gen)
