@@ -86,6 +86,20 @@ def test_every_node_backward_with_quan_input(tag):
     _check_all_nodes(cfg, st, x, quan_input_bits=8)
 
 
+@pytest.mark.parametrize('mode', [False, 2])
+def test_every_node_backward_rectangular_full_width(mode):
+    """A 128 x 256 input at production widths, N = 4: image rows of 64 / 32 / 16 / 8 / 4 pixels with half as many rows per image
+    as a square input has -- the row-walking weight-gradient kernels (3x3 ring in fp32 and on bf16 MFMA, stem) cross image
+    boundaries at other places, the last workgroup of a range is ragged."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=35)
+    gen = torch.Generator().manual_seed(36)
+    x = torch.rand(4, 3, 128, 256, generator=gen)
+    _check_all_nodes(cfg, st, x, bf16=mode, wgrad3_all=True)
+
+
 @pytest.mark.parametrize('n,h,w', [(1, 256, 256), (3, 128, 256), (5, 256, 128), (30, 128, 128)])
 def test_stem_weight_gradient_shapes(n, h, w):
     """The LDS-staged stem weight gradient (wgrad3_stem_kernel) over its planning range: one output row per workgroup (N = 1),
@@ -194,7 +208,11 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
             if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
                 from oracle.cunet_ref import _QuanInputFn       # QuanInput2d site: quantised forward, straight-through backward
                 act = _QuanInputFn.apply(act, quan_input_bits)
+            dw_tol = {}
             if gb and nd.get('wg3', 0) > 0 and (nd['taps'] == 1 or T[nd['out']]['W'] in (16, 32, 64)):
+                # (an activation whose fp32 value sits within an ulp of a bf16 rounding boundary rounds the other way in the kernel:
+                # one bf16 step of one activation, 4e-3 * |act * dy|, in a sum over a few hundred rows is above 2e-4 of max|dW|)
+                dw_tol = dict(rtol=1e-3)
                 # the bf16-MFMA weight gradient (1x1: wgrad3_bf16_kernel; 3x3 at W = 16 / 32 / 64: wgrad3_3x3_bf16_kernel) contracts
                 # dY with the bf16-ROUNDED activation -- exactly the operand the bf16 forward multiplied the weights with, i.e. the
                 # exact gradient of that forward (straight-through here)
@@ -207,7 +225,7 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
             for l, s in zip(leaves, nd['segs']):
                 nm = T[s['t']]['name']
                 _close(f'{nd["name"]} dX[{nm}]', plan.debug_tensor(nm, grad=True), l.grad, bad, **dx_tol)
-            _close(f'{nd["name"]} dW', pgrad(nd['conv'] + '.weight'), wt.grad, bad)
+            _close(f'{nd["name"]} dW', pgrad(nd['conv'] + '.weight'), wt.grad, bad, **dw_tol)
             _close(f'{nd["name"]} dgamma', pgrad(nd['bn'] + '.weight'), gamma.grad, bad)
             _close(f'{nd["name"]} dbeta', pgrad(nd['bn'] + '.bias'), beta.grad, bad)
         elif op == 'pool':
