@@ -91,10 +91,15 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
     if (!CUNET_DBG(p, 128))
-    for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
-        const int m = tile * 32 + li;                // this lane's A row
-        const int mc = m < p.M ? m : p.M - 1;
-        int nimg, py, px;
+    {
+    // Loader state of the tile whose A operand is being REQUESTED.  On the fast path the next tile's first chunk is requested
+    // before the current tile's epilogue: vmcnt counts loads and stores in one in-order queue, so a load issued after the
+    // epilogue's 16 (x NT) stores can only be waited for together with them -- every tile of a multi-tile wave paid the
+    // store-acknowledge latency before its first MFMA.
+    int mc = 0, nimg = 0, py = 0, px = 0, rowU = 0;
+    auto set_tile = [&](int t) {
+        const int m = t * 32 + li;                   // this lane's A row
+        mc = m < p.M ? m : p.M - 1;
         if (p.wshift >= 0) {                         // power-of-two geometry (uniform): shifts instead of emulated divisions
             nimg = mc >> p.hwshift;
             const int rem = mc & (HW - 1);
@@ -106,7 +111,60 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             py = rem / p.W;
             px = rem - py * p.W;
         }
-        const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+        rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+    };
+    // ---- loaders -------------------------------------------------------------------
+    auto tap_row = [&](int t, bool& valid) -> int {
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        const int yy = py + dy, xx = px + dx;
+        valid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+        return valid ? mc + dy * p.W + dx : mc;
+    };
+    // fast-path loader state (see below)
+    int sidx = 0, cl = 0, ncs = 0, tap = 0;          // uniform loop state
+    const float* rowptr = nullptr;                    // per lane: &X[row][4*hi] of the current segment/tap
+    bool tvalid = true;
+    auto enter = [&]() {                              // (re)compute rowptr for (sidx | tap)
+        if (LD == LD_SEG) {
+            const Seg sg = p.seg[sidx];
+            rowptr = sg.x + (size_t)(sg.ups ? rowU : mc) * sg.ld + 4 * hi;
+            ncs = sg.C >> 5;
+        } else if (LD == LD_3X3 || LD == LD_PLAIN3) {
+            const int row = tap_row(tap, tvalid);
+            const float* base = (LD == LD_3X3) ? p.seg[0].x : p.a;
+            const int ld = (LD == LD_3X3) ? p.seg[0].ld : p.lda;
+            rowptr = xadv<GB>(base, (size_t)row * ld + 4 * hi);
+            ncs = nck;
+        } else {
+            rowptr = xadv<GB>(p.a, (size_t)mc * p.lda + 4 * hi);
+            ncs = nck;
+        }
+        cl = 0;
+    };
+    auto fetch = [&](float4 (&a)[4]) {                // loads chunk (sidx|tap, cl)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = ldx4<GB>(rowptr, cl * 32 + q * 8);
+        if (LD == LD_PLAIN3 && !tvalid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 anext[4];
+    bool vcur = true;
+    auto begin_tile = [&](int t) {                    // geometry of tile t, its first chunk on the way
+        set_tile(t);
+        sidx = 0; tap = 0;
+        enter();
+        vcur = tvalid;
+        fetch(anext);
+    };
+    constexpr bool EARLY_NEXT = NT <= 2;              // (NT = 4 holds 64 accumulators: 16 more live registers across its epilogue spill)
+    const int tstride = gridDim.x * nwaves;
+    int tile = blockIdx.x * nwaves + wave;
+    if (FAST && EARLY_NEXT && tile < ntiles) begin_tile(tile);
+    for (; tile < ntiles; tile += tstride) {
+        if (!FAST) set_tile(tile);
+        if (FAST && !EARLY_NEXT) begin_tile(tile);
 
         f32x16 acc[NT];
 #pragma unroll
@@ -114,13 +172,6 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-        // ---- loaders -------------------------------------------------------------------
-        auto tap_row = [&](int t, bool& valid) -> int {
-            const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
-            const int yy = py + dy, xx = px + dx;
-            valid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-            return valid ? mc + dy * p.W + dx : mc;
-        };
         auto load_a = [&](int ch, float4 (&a)[4]) {
             const int t = ch / nck;
             const int c = ch - t * nck;
@@ -212,38 +263,6 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             // chunk never straddles a segment and nothing is predicated: straight-line code, the
             // segment descriptor is wave-uniform (scalar loads from the kernarg), the per-lane row
             // pointer is recomputed only when the segment (or tap) changes, loads take immediates.
-            int sidx = 0, cl = 0, ncs = 0, tap = 0;          // uniform loop state
-            const float* rowptr = nullptr;                    // per lane: &X[row][4*hi] of the current segment/tap
-            bool tvalid = true;
-            auto enter = [&]() {                              // (re)compute rowptr for (sidx | tap)
-                if (LD == LD_SEG) {
-                    const Seg sg = p.seg[sidx];
-                    rowptr = sg.x + (size_t)(sg.ups ? rowU : mc) * sg.ld + 4 * hi;
-                    ncs = sg.C >> 5;
-                } else if (LD == LD_3X3 || LD == LD_PLAIN3) {
-                    const int row = tap_row(tap, tvalid);
-                    const float* base = (LD == LD_3X3) ? p.seg[0].x : p.a;
-                    const int ld = (LD == LD_3X3) ? p.seg[0].ld : p.lda;
-                    rowptr = xadv<GB>(base, (size_t)row * ld + 4 * hi);
-                    ncs = nck;
-                } else {
-                    rowptr = xadv<GB>(p.a, (size_t)mc * p.lda + 4 * hi);
-                    ncs = nck;
-                }
-                cl = 0;
-            };
-            auto fetch = [&](float4 (&a)[4]) {                // loads chunk (sidx|tap, cl) and advances
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = ldx4<GB>(rowptr, cl * 32 + q * 8);
-                if (LD == LD_PLAIN3 && !tvalid) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            };
-            enter();
-            float4 anext[4];
-            bool vcur = tvalid;
-            fetch(anext);
             for (int ch = 0; ch < nchunks; ++ch) {
                 float4 acur[4];
 #pragma unroll
@@ -275,9 +294,9 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                 }
                 mfma_chunk(ch, acur);
             }
+            if (EARLY_NEXT && tile + tstride < ntiles) begin_tile(tile + tstride);      // before this tile's epilogue (see above)
         } else {
             // ---- generic path: per-group table look-ups and predicates (odd channel counts, ragged M)
-            float4 anext[4];
             load_a(0, anext);
             for (int ch = 0; ch < nchunks; ++ch) {
                 float4 acur[4];
@@ -393,6 +412,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             dsum[nt] += (double)s1;
             dsq[nt] += (double)s2;
         }
+    }
     }
 
     // ---- per-channel reductions: lanes (l, l+32) -> waves (serialised through LDS) -> one fp64
