@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_common.h"
 
 namespace cunet {
 
@@ -500,38 +501,58 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
-    for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
-        const int m = tile * 32 + li;
-        const int nimg = m / HW;
-        const int rem = m - nimg * HW;
-        const int py = rem / p.W;
-        const int px = rem - py * p.W;
-
+    // Loader state of the tile whose A operand is being requested: the next tile's first chunk goes out BEFORE the current tile's
+    // epilogue stores (vmcnt orders a later load behind them; see conv_kernel).
+    int m = 0, py = 0, px = 0;
+    auto set_tile = [&](int t) {
+        m = t * 32 + li;
+        if (TAPS == 9) {
+            if (p.wshift >= 0) {
+                const int rem = m & (HW - 1);
+                py = rem >> p.wshift;
+                px = rem & (p.W - 1);
+            } else {
+                const int nimg = m / HW;
+                const int rem = m - nimg * HW;
+                py = rem / p.W;
+                px = rem - py * p.W;
+            }
+        }
+    };
+    int cl = 0, tap = 0;
+    const u16* rowptr = nullptr;
+    bool tvalid = true;
+    auto enter = [&]() {
+        if (TAPS == 1) {
+            rowptr = dY + (size_t)m * p.lda + 8 * hi;
+        } else {
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int yy = py + dy, xx = px + dx;
+            tvalid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+            rowptr = dY + (size_t)(tvalid ? m + dy * p.W + dx : m) * p.lda + 8 * hi;
+        }
+        cl = 0;
+    };
+    uint4 anext[2];
+    bool vcur = true;
+    auto begin_tile = [&](int t) {
+        set_tile(t);
+        tap = 0;
+        enter();
+        vcur = tvalid;
+        anext[0] = ldg16(rowptr);
+        anext[1] = ldg16(rowptr + 16);
+    };
+    const int tstride = gridDim.x * nwaves;
+    int tile = blockIdx.x * nwaves + wave;
+    if (tile < ntiles) begin_tile(tile);
+    for (; tile < ntiles; tile += tstride) {
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-        int cl = 0, tap = 0;
-        const u16* rowptr = nullptr;
-        bool tvalid = true;
-        auto enter = [&]() {
-            if (TAPS == 1) {
-                rowptr = dY + (size_t)m * p.lda + 8 * hi;
-            } else {
-                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-                const int yy = py + dy, xx = px + dx;
-                tvalid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-                rowptr = dY + (size_t)(tvalid ? m + dy * p.W + dx : m) * p.lda + 8 * hi;
-            }
-            cl = 0;
-        };
-        enter();
-        uint4 anext[2];
-        bool vcur = tvalid;
-        anext[0] = ldg16(rowptr);
-        anext[1] = ldg16(rowptr + 16);
         for (int ch = 0; ch < nchunks; ++ch) {
             uint4 acur[2] = {anext[0], anext[1]};
             const bool vthis = vcur;
@@ -555,6 +576,8 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
             }
         }
 
+        if (tile + tstride < ntiles) begin_tile(tile + tstride);
+
         // ---- epilogue.  Rows of this lane's 16 accumulator registers, plain and through the up-sample map (W % 4 == 0:
         //      registers 4k..4k+3 lie in one image row, one division per group)
         const int mrow0 = tile * 32;
@@ -562,11 +585,22 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int m4 = mrow0 + 8 * k + 4 * hi;
-            const int ni = m4 / HW;
-            const int rm = m4 - ni * HW;
-            const int yy = rm / p.W;
-            const int xx = rm - yy * p.W;
-            const int base = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            int base = 0;
+            if (p.any_ups) {
+                int ni, yy, xx;
+                if (p.wshift >= 0) {
+                    ni = m4 >> p.hwshift;
+                    const int rm = m4 & (HW - 1);
+                    yy = rm >> p.wshift;
+                    xx = rm & (p.W - 1);
+                } else {
+                    ni = m4 / HW;
+                    const int rm = m4 - ni * HW;
+                    yy = rm / p.W;
+                    xx = rm - yy * p.W;
+                }
+                base = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { rowP[4 * k + j] = m4 + j; rowUp[4 * k + j] = base + (j >> 1); }
         }
@@ -673,8 +707,10 @@ hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
     if (gx < 1) gx = 1;
     const dim3 grid(gx, gy);
     const int threads = (waves < 4 ? 4 : waves) * 64;
-    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(a, grid, threads, smem, s) : launch_dg16_inst<1, 1>(a, grid, threads, smem, s);
-    return NT == 2 ? launch_dg16_inst<9, 2>(a, grid, threads, smem, s) : launch_dg16_inst<9, 1>(a, grid, threads, smem, s);
+    ConvArgs b = a;
+    set_geometry_shifts(b);
+    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(b, grid, threads, smem, s) : launch_dg16_inst<1, 1>(b, grid, threads, smem, s);
+    return NT == 2 ? launch_dg16_inst<9, 2>(b, grid, threads, smem, s) : launch_dg16_inst<9, 1>(b, grid, threads, smem, s);
 }
 
 static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {

@@ -6,6 +6,17 @@
 
 namespace cunet {
 
+// host: log2 of W and H*W when both are powers of two (ConvArgs::wshift / hwshift), and whether any segment is up-sampled
+inline void set_geometry_shifts(ConvArgs& a) {
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (v > 0 && (1 << l) == v) ? l : -1; };
+    const int lw = lg2(a.W), lhw = lg2(a.H * a.W);
+    a.wshift = (lw >= 0 && lhw >= 0) ? lw : -1;
+    a.hwshift = (lw >= 0 && lhw >= 0) ? lhw : -1;
+    a.any_ups = 0;
+    for (int i = 0; i < a.nseg; ++i) a.any_ups |= a.seg[i].ups;
+}
+
+
 struct GrpEnt {            // one 4-channel group of the concat
     const float* ptr;      // segment base + local channel
     int ld;

@@ -648,14 +648,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: work-skipping timing experiments
     ConvArgs a = a_in;
     a.dbg = dbg;
-    {
-        auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (v > 0 && (1 << l) == v) ? l : -1; };
-        const int lw = lg2(a.W), lhw = lg2(a.H * a.W);
-        a.wshift = (lw >= 0 && lhw >= 0) ? lw : -1;
-        a.hwshift = (lw >= 0 && lhw >= 0) ? lhw : -1;
-        a.any_ups = 0;
-        for (int i = 0; i < a.nseg; ++i) a.any_ups |= a.seg[i].ups;
-    }
+    set_geometry_shifts(a);
     const int ntiles = (a.M + 31) / 32;
     const int ncol32 = (a.Nout + 31) / 32;
     static const int target_x10 = tune_int("CUNET_CONV_TARGET_X10", 20);      // (swept 7 ... 20: no change)
