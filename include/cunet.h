@@ -222,6 +222,10 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        measured best on MI355X; tests also run with a large value to keep the other kernel covered)
  *   "wgrad3_min_chunks"  at least this many 32-pixel chunks per workgroup of that kernel (default 2)
  *   "wgrad3_max_splits"  at most this many workgroups (= partial tiles) per launch (default 256)
+ *   "wgrad3_min_chunks_bf16", "wgrad3_max_splits_bf16"   the same two with bf16 gradient tensors, where these kernels are
+ *                        HBM-bound and fewer, longer splits win (defaults 4 and 96)
+ *   "wgrad3_stem"        1 (default): the stem's 7x7 weight gradient on the LDS-staged atomics-free kernel where the shape
+ *                        allows (128 output channels, output width a multiple of 64); 0: per-wave atomic kernel
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 
