@@ -69,6 +69,8 @@ struct ConvArgs {
     int wshift, hwshift;   // log2(W), log2(H*W) when both are powers of two (every level of a 2^k x 2^k input), else -1: the kernels
                            // split a row index with shifts instead of two emulated divisions per tile and per epilogue row group
     int any_ups;           // some segment is read through the nearest-upsample map
+    int xcd_gx, xcd_gy;    // > 0: the grid is 1-D (8 * ceil(gx / 8) * gy blocks) and decoded so that the gy column-slice blocks of a row
+                           // block are consecutive workgroups of ONE XCD (round-robin dispatch: id % 8): they share A through its L2
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)

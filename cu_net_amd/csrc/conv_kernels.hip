@@ -50,7 +50,16 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
-    const int n0 = blockIdx.y * NB;
+    // block -> (row block bx of gxd, column slice by).  With xcd_gx > 0 the launch is 1-D and the slices of a row block sit on one XCD.
+    int bx = blockIdx.x, by = blockIdx.y, gxd = gridDim.x;
+    if (p.xcd_gx > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        by = slot % p.xcd_gy;
+        bx = (slot / p.xcd_gy) * 8 + xcd;
+        gxd = p.xcd_gx;
+        if (bx >= gxd) return;                         // (padding blocks of the last group of eight; before any barrier)
+    }
+    const int n0 = by * NB;
 
     // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
     if (!CUNET_DBG(p, 32)) {
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         fetch(anext);
     };
     constexpr bool EARLY_NEXT = NT <= 2;              // (NT = 4 holds 64 accumulators: 16 more live registers across its epilogue spill)
-    const int tstride = gridDim.x * nwaves;
-    int tile = blockIdx.x * nwaves + wave;
+    const int tstride = gxd * nwaves;
+    int tile = bx * nwaves + wave;
     if (FAST && EARLY_NEXT && tile < ntiles) begin_tile(tile);
     for (; tile < ntiles; tile += tstride) {
         if (!FAST) set_tile(tile);
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = up ? rowUp[r] : rowP[r];
+                if (CUNET_DBG(p, 8)) { xo[r] = 1.f; continue; }      // (tuning builds: timing without the x loads)
                 xo[r] = ldx1<XB>(g.ptr, xoff0 + (size_t)row * g.ld);
             }
         };
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                         // ReLU mask; with a QuanInput behind the ReLU also its straight-through mask (utils/quantize.py:58-63:
                         // no gradient where the activation is >= 1, i.e. z >= 1)
                         const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[nt][r] : 0.f;
-                        stx1<GB>(p.y, (size_t)mm * p.ldy + col, dz);
+                        if (!CUNET_DBG(p, 2)) stx1<GB>(p.y, (size_t)mm * p.ldy + col, dz);      // (tuning builds: timing without the dz stores)
                         s1 += dz;
                         s2 = fmaf(dz, (xv - cmu) * cis, s2);
                     }
@@ -687,7 +697,13 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     int gx = (ntiles + waves - 1) / waves;
     if (gx > max_blocks_x) gx = max_blocks_x;
     if (gx < 1) gx = 1;
-    const dim3 grid(gx, gy);
+    dim3 grid(gx, gy);
+    static const int xcd_remap = tune_int("CUNET_CONV_XCD", 1);
+    a.xcd_gx = a.xcd_gy = 0;
+    if (xcd_remap && gy > 1 && epi == EP_BWD) {        // column slices of a row block re-read the same A rows: keep them on one XCD
+        a.xcd_gx = gx; a.xcd_gy = gy;
+        grid = dim3(8 * ((gx + 7) / 8) * gy, 1);
+    }
     // fast path: nothing ragged (see the kernel)
     bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !tune_int("CUNET_CONV_GENERIC", 0);
     if (load == LD_SEG) {
