@@ -443,7 +443,15 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
-    const int n0 = blockIdx.y * NB;
+    int bx = blockIdx.x, by = blockIdx.y, gxd = gridDim.x;      // see conv_kernel: column slices of a row block on one XCD
+    if (p.xcd_gx > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        by = slot % p.xcd_gy;
+        bx = (slot / p.xcd_gy) * 8 + xcd;
+        gxd = p.xcd_gx;
+        if (bx >= gxd) return;
+    }
+    const int n0 = by * NB;
     const u16* wB = reinterpret_cast<const u16*>(p.wB);
     const u16* dY = reinterpret_cast<const u16*>(p.a);
 
@@ -543,8 +551,8 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
         anext[0] = ldg16(rowptr);
         anext[1] = ldg16(rowptr + 16);
     };
-    const int tstride = gridDim.x * nwaves;
-    int tile = blockIdx.x * nwaves + wave;
+    const int tstride = gxd * nwaves;
+    int tile = bx * nwaves + wave;
     if (tile < ntiles) begin_tile(tile);
     for (; tile < ntiles; tile += tstride) {
         f32x16 acc[NT];
@@ -709,8 +717,11 @@ hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
     const int threads = (waves < 4 ? 4 : waves) * 64;
     ConvArgs b = a;
     set_geometry_shifts(b);
-    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(b, grid, threads, smem, s) : launch_dg16_inst<1, 1>(b, grid, threads, smem, s);
-    return NT == 2 ? launch_dg16_inst<9, 2>(b, grid, threads, smem, s) : launch_dg16_inst<9, 1>(b, grid, threads, smem, s);
+    dim3 grid1 = grid;
+    b.xcd_gx = b.xcd_gy = 0;
+    if (gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid1 = dim3(8 * ((gx + 7) / 8) * gy, 1); }
+    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(b, grid1, threads, smem, s) : launch_dg16_inst<1, 1>(b, grid1, threads, smem, s);
+    return NT == 2 ? launch_dg16_inst<9, 2>(b, grid1, threads, smem, s) : launch_dg16_inst<9, 1>(b, grid1, threads, smem, s);
 }
 
 static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
