@@ -237,7 +237,15 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
-    const int n0 = blockIdx.y * NB;
+    int bx = blockIdx.x, by = blockIdx.y, gxd = gridDim.x;      // see conv_kernel: column slices of a row block on one XCD
+    if (p.xcd_gx > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        by = slot % p.xcd_gy;
+        bx = (slot / p.xcd_gy) * 8 + xcd;
+        gxd = p.xcd_gx;
+        if (bx >= gxd) return;
+    }
+    const int n0 = by * NB;
     const u16* wB = reinterpret_cast<const u16*>(p.wB);
 
     {   // B operand -> LDS (8 loads in flight per thread)
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dsum[nt] = 0.0; dsq[nt] = 0.0; }
 
-    for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    for (int tile = bx * nwaves + wave; tile < ntiles; tile += gxd * nwaves) {
         const int m = tile * 32 + li;
         const int nimg = m / HW;
         const int rem = m - nimg * HW;
@@ -769,10 +777,14 @@ hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStre
     int gx = (ntiles + waves - 1) / waves;
     if (gx > max_blocks_x) gx = max_blocks_x;
     if (gx < 1) gx = 1;
-    const dim3 grid(gx, gy);
+    dim3 grid(gx, gy);
+    ConvArgs b = a;
+    static const int xcd_fwd = tune_int("CUNET_CONV_XCD_FWD", 1);
+    b.xcd_gx = b.xcd_gy = 0;
+    if (xcd_fwd && gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid = dim3(8 * ((gx + 7) / 8) * gy, 1); }
     const int threads = (waves < 4 ? 4 : waves) * 64;
 #define CUNET_B16(T, N) \
-    if (a.taps == T && NT == N) return out_f32 ? launch_b16_inst<T, N, 1>(a, grid, threads, smem, s) : launch_b16_inst<T, N, 0>(a, grid, threads, smem, s);
+    if (a.taps == T && NT == N) return out_f32 ? launch_b16_inst<T, N, 1>(b, grid, threads, smem, s) : launch_b16_inst<T, N, 0>(b, grid, threads, smem, s);
     CUNET_B16(1, 1) CUNET_B16(1, 2) CUNET_B16(1, 4) CUNET_B16(9, 1) CUNET_B16(9, 2) CUNET_B16(9, 4)
 #undef CUNET_B16
     return hipErrorInvalidValue;

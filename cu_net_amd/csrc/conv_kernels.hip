@@ -700,7 +700,8 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     dim3 grid(gx, gy);
     static const int xcd_remap = tune_int("CUNET_CONV_XCD", 1);
     a.xcd_gx = a.xcd_gy = 0;
-    if (xcd_remap && gy > 1 && epi == EP_BWD) {        // column slices of a row block re-read the same A rows: keep them on one XCD
+    static const int xcd_fwd = tune_int("CUNET_CONV_XCD_FWD", 1);
+    if (xcd_remap && gy > 1 && (epi == EP_BWD || xcd_fwd)) {        // column slices of a row block re-read the same A rows: keep them on one XCD
         a.xcd_gx = gx; a.xcd_gy = gy;
         grid = dim3(8 * ((gx + 7) / 8) * gy, 1);
     }
