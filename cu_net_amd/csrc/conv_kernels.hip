@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "conv_common.h"
+#include "plan.h"
 
 namespace cunet {
 
@@ -595,6 +596,201 @@ static hipError_t launch_conv3x3_tapsplit(const ConvArgs& a, int num_cus, hipStr
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 forward on a ring of activated image rows (same nodes as above at 64x64 / 32x32: 128 -> 32 channels).
+// The weight-stationary kernel reads every input row through nine shifted taps from L2; at 64x64 the rows a CU touches
+// between two taps of the same line (6 rows x 32 KB per block, 32 blocks per XCD) do not stay in the 4 MB L2: the counters
+// show 4.7x the algorithmic fetch (79.6 MB per launch, profiles/r02_traffic.txt).  Here an 8-wave workgroup walks image ROWS:
+// BatchNorm + ReLU is applied ONCE per element on the way into an LDS ring of three rows [W+2 pixels][132 floats] (zero border
+// columns; pixel pitch 132 makes the 16-byte fragment reads conflict-free), wave t owns tap t (and an eighth of tap 8) with its
+// weights in registers, its A fragments are ds_read_b128 of the row (y + dy) shifted by dx, the eight partial tiles meet in LDS,
+// where all threads add them, store the tile and keep the output statistics.  Row g+2 is requested from HBM before the MFMAs of row g.
+constexpr int R3_PITCH = 132;           // floats per pixel in the ring
+constexpr int R3_THREADS = 512;         // 8 waves: wave w owns tap w and the k-slice [16w, 16w + 16) of tap 8 -- two waves per SIMD with
+                                        // 72 MFMAs each per tile (nine one-tap waves would put 3 + 2 + 2 + 2 on the four SIMDs)
+
+__global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_kernel(const ConvArgs p, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 128;
+    const int W = p.W, H = p.H;
+    const int SLOT = (W + 2) * R3_PITCH;                          // floats per ring slot
+    float* sc = reinterpret_cast<float*>(smem);                   // [K]
+    float* sh = sc + K;                                           // [K]
+    double* redbuf = reinterpret_cast<double*>(sh + K);           // [32][2]
+    float* part = reinterpret_cast<float*>(redbuf + 64);          // [8][1024] partial tiles
+    float* ring = part + 8 * 1024;                                // 3 slots
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int tap = tid >> 6;                                     // 0 .. 7
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const Seg sg = p.seg[0];
+
+    for (int c = tid; c < K; c += R3_THREADS) {
+        double mean, istd;
+        if (p.training) {
+            mean = sg.stats[c] / sg.count;
+            double var = sg.stats[sg.C + c] / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            istd = 1.0 / sqrt(var + (double)BN_EPS);
+        } else {
+            mean = (double)p.rmean[c];
+            istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+        }
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+    }
+    if (tid < 64) redbuf[tid] = 0.0;
+    for (int i = tid; i < 3 * SLOT / 4; i += R3_THREADS)          // border columns stay zero for the whole launch
+        reinterpret_cast<float4*>(ring)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // packed weights [tap][K/4][Npad][4]: bw[q] = (tap, k = 8q + 4hi + 0..3, n = li); bx[q] = (tap 8, k = 16 tap + 8q + 4hi + 0..3)
+    float4 bw[16], bx[2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bw[q] = ldg4(p.wB + ((size_t)(tap * (K / 4) + 2 * q + hi) * p.Npad + li) * 4);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bx[q] = ldg4(p.wB + ((size_t)(8 * (K / 4) + 4 * tap + 2 * q + hi) * p.Npad + li) * 4);
+    __syncthreads();
+
+    const int NH = p.M / W;                                       // image rows in the batch
+    const int g_begin = blockIdx.x * rows_per_wg;
+    int g_end = g_begin + rows_per_wg;
+    if (g_end > NH) g_end = NH;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+
+    // staging plan: a row is W * 32 float4; thread t takes float4 t, t + 512, ... : its channel group never changes
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    const int nx4 = W * 32;
+    const int c4 = (tid & 31) << 2;
+    const float4 s4 = *reinterpret_cast<const float4*>(sc + c4);
+    const float4 h4 = *reinterpret_cast<const float4*>(sh + c4);
+    f32x4n xv[4];
+    bool xok = false;
+    auto issue_x = [&](int g) {
+        xok = g >= 0 && g < NH;
+        const size_t base = (size_t)(xok ? g : 0) * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = tid + R3_THREADS * j;
+            if (idx >= nx4) idx = nx4 - 1;
+            xv[j] = *reinterpret_cast<const f32x4n*>(sg.x + (base + (idx >> 5)) * sg.ld + c4);
+        }
+    };
+    auto commit_x = [&](int g) {
+        if (!xok) return;
+        float* slot = ring + (size_t)(((g % 3) + 3) % 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + R3_THREADS * j;
+            if (idx >= nx4) break;
+            f32x4n v;
+            v[0] = fmaxf(fmaf(xv[j][0], s4.x, h4.x), 0.f);
+            v[1] = fmaxf(fmaf(xv[j][1], s4.y, h4.y), 0.f);
+            v[2] = fmaxf(fmaf(xv[j][2], s4.z, h4.z), 0.f);
+            v[3] = fmaxf(fmaf(xv[j][3], s4.w, h4.w), 0.f);
+            if (p.qin_bits) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quan_input_act(v[e], p.qin_bits);
+            }
+            *reinterpret_cast<f32x4n*>(slot + ((idx >> 5) + 1) * R3_PITCH + c4) = v;
+        }
+    };
+
+    for (int g = g_begin - 1; g <= g_begin + 1; ++g) { issue_x(g); commit_x(g); }
+    __syncthreads();
+
+    double dsum = 0.0, dsq = 0.0;
+    const int ntile = W >> 5;
+    for (int g = g_begin; g < g_end; ++g) {
+        const int y = g % H;
+        issue_x(g + 2);                                           // in flight across this row's MFMAs
+        const bool rvalid = (y + dy >= 0) && (y + dy < H);
+        const bool xvalid = y + 1 < H;                            // tap 8 = (dy, dx) = (+1, +1)
+        const int sl = (g + dy + 3) % 3, slx = (g + 1) % 3;
+        for (int t = 0; t < ntile; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (rvalid) {
+                const float* ap = ring + (size_t)sl * SLOT + (t * 32 + li + dx + 1) * R3_PITCH + 4 * hi;
+                f32x4n a_cur = *reinterpret_cast<const f32x4n*>(ap);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4n a_nxt = *reinterpret_cast<const f32x4n*>(ap + 8 * (q + 1 < 16 ? q + 1 : q));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], bw[q].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], bw[q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], bw[q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], bw[q].w, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    a_cur = a_nxt;
+                }
+            }
+            if (xvalid) {
+                const float* ap = ring + (size_t)slx * SLOT + (t * 32 + li + 2) * R3_PITCH + 16 * tap + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4n a4 = *reinterpret_cast<const f32x4n*>(ap + 8 * q);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], bx[q].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], bx[q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], bx[q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], bx[q].w, acc, 0, 0, 0);
+                }
+            }
+            if (t > 0) __syncthreads();                           // the previous tile's sums have been read
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[tap * 1024 + r * 64 + lane] = acc[r];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + R3_THREADS * u;
+                float vsum = part[e];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) vsum += part[w * 1024 + e];
+                const int r = e >> 6, l = e & 63;                 // C layout: col = l & 31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                p.y[((size_t)g * W + t * 32 + row) * p.ldy + (l & 31)] = vsum;
+                dsum += (double)vsum;
+                dsq += (double)vsum * (double)vsum;
+            }
+        }
+        __syncthreads();                                          // everyone is done with row g-1's slot and with `part`
+        commit_x(g + 2);
+        __syncthreads();
+    }
+    if (p.ystats != nullptr) {                                    // a thread's column is tid & 31 in both passes (512 = 16 * 32)
+        atomicAdd(&redbuf[(tid & 31) * 2 + 0], dsum);
+        atomicAdd(&redbuf[(tid & 31) * 2 + 1], dsq);
+        __syncthreads();
+        if (tid < 32 && tid < p.Nout) {
+            atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
+            atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
+        }
+    }
+}
+
+static bool conv3x3_ring_supported(const ConvArgs& a) {
+    return a.nseg == 1 && a.K == 128 && a.Kpad == 128 && a.Nout == 32 && a.Npad == 32 && !a.seg[0].ups && a.seg[0].ld % 4 == 0 &&
+           a.seg[0].C == 128 && (a.W == 64 || a.W == 32) && a.M % a.W == 0 && a.ldy >= 32;
+}
+
+static hipError_t launch_conv3x3_ring(const ConvArgs& a, int num_cus, hipStream_t s) {
+    const int NH = a.M / a.W;
+    int rows = (NH + num_cus - 1) / num_cus;
+    if (rows < 2) rows = 2;
+    const int grid = (NH + rows - 1) / rows;
+    const size_t smem = (size_t)2 * 128 * 4 + 64 * 8 + (size_t)8 * 1024 * 4 + (size_t)3 * (a.W + 2) * R3_PITCH * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_ring_kernel, dim3(grid), dim3(R3_THREADS), smem, s, a, rows);
+    return hipGetLastError();
+}
+
 static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
     size_t b = (size_t)taps * (Kpad / 4) * NT * 32 * 16;   // resident B operand
     b += (size_t)(Ccat / 4) * sizeof(GrpEnt);              // group table
@@ -650,6 +846,9 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
 // and its weights fit the LDS, fewer when there are too few 32-row tiles to fill the chip), the
 // waves per block and the grid.
 hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
+    static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 64);      // 3x3 forward on the LDS row ring at this width and above
+    if (load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= planner_options().conv3x3_ring_min_rows)
+        return launch_conv3x3_ring(a_in, num_cus, s);
     static const int use_ts = tune_int("CUNET_CONV_TS", 1);
     if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
         a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups &&

@@ -143,6 +143,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "wgrad3_min_chunks_bf16") o.wgrad3_min_chunks_bf16 = value;
     else if (n == "wgrad3_max_splits_bf16") o.wgrad3_max_splits_bf16 = value;
     else if (n == "wgrad3_stem") o.wgrad3_stem = value;
+    else if (n == "conv3x3_ring_min_rows") o.conv3x3_ring_min_rows = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }

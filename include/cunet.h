@@ -226,6 +226,8 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        HBM-bound and fewer, longer splits win (defaults 4 and 96)
  *   "wgrad3_stem"        1 (default): the stem's 7x7 weight gradient on the LDS-staged atomics-free kernel where the shape
  *                        allows (128 output channels, output width a multiple of 64); 0: per-wave atomic kernel
+ *   "conv3x3_ring_min_rows"  the 3x3 forward of 64-pixel-wide levels runs on the LDS row ring when the batch has at least this many
+ *                        image rows N*H (default 512 = two per CU; tests lower it to cover the kernel at small batches)
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 

@@ -202,6 +202,55 @@ def test_full_width_matches_reference():
         assert abs(got - nrm) <= 5e-2 * nrm + 1e-9, (k, got, nrm)   # whole-net fp32 gradients: sanity bound only
 
 
+@pytest.fixture
+def ring_3x3_everywhere():
+    """The LDS row-ring 3x3 forward is planned for batches with >= 512 image rows; force it onto small batches."""
+    from cu_net_amd._lib import set_planner_option
+    set_planner_option('conv3x3_ring_min_rows', 2)
+    try:
+        yield
+    finally:
+        set_planner_option('conv3x3_ring_min_rows', 512)
+
+
+def test_full_width_matches_reference_on_the_3x3_row_ring(ring_3x3_everywhere):
+    """The same reference vectors with the 64x64 3x3 convolutions on conv3x3_ring_kernel (train-mode forward: batch-statistic
+    BatchNorm on the way into the ring, output statistics, heat maps and loss against the reference)."""
+    test_full_width_matches_reference()
+
+
+def test_3x3_row_ring_agrees_with_the_weight_stationary_kernel(ring_3x3_everywhere):
+    """Eval- and train-mode forward of a full-width net, N = 3 (ragged last workgroup: 192 image rows in ranges of 2), on the ring
+    kernel against the weight-stationary kernel on the same state: the two differ in summation order only."""
+    from cu_net_amd._lib import set_planner_option
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=51)
+    x, _ = O.synthetic_batch(3, 16, 256, seed=52)
+    outs = {}
+    for mode in ('ring', 'plain'):
+        set_planner_option('conv3x3_ring_min_rows', 2 if mode == 'ring' else 1 << 30)
+        net = cu_net_amd.create_cu_net(**cfg)
+        net.load_state_dict(st)
+        net.cuda().eval()
+        with torch.no_grad():
+            ev = [o.cpu() for o in net(x.cuda())]
+        net.train()
+        plan = net._get_plan(3, 256, 256, True)
+        plan.forward(x.cuda(), True, want_outputs=False)
+        torch.cuda.synchronize()
+        desc = plan.handle.describe()
+        first3 = [n for n in desc['nodes'] if n['op'] == 'conv' and n['taps'] == 9 and desc['tensors'][n['out']]['W'] == 64][0]
+        tr = plan.debug_tensor(desc['tensors'][first3['out']]['name']).cpu()
+        outs[mode] = (ev, tr, {k: v.clone().cpu() for k, v in net.state_dict().items() if 'running' in k})
+    for a, b in zip(outs['ring'][0], outs['plain'][0]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-7
+    a, b = outs['ring'][1], outs['plain'][1]
+    assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()          # one node, identical inputs
+    for k, v in outs['plain'][2].items():
+        assert torch.allclose(outs['ring'][2][k], v, rtol=1e-4, atol=1e-6), k
+
+
 def test_full_width_eval_forward_matches_oracle():
     """Inference path at full width (running statistics, every full-width kernel variant incl. the tap-split 3x3):
     HIP eval forward vs the oracle's eval forward on the same state, after one training step moved the
