@@ -219,8 +219,10 @@ def test_full_width_matches_reference_on_the_3x3_row_ring(ring_3x3_everywhere):
     test_full_width_matches_reference()
 
 
-def test_3x3_row_ring_agrees_with_the_weight_stationary_kernel(ring_3x3_everywhere):
-    """Eval- and train-mode forward of a full-width net, N = 3 (ragged last workgroup: 192 image rows in ranges of 2), on the ring
+@pytest.mark.parametrize('qin', [0, 8])
+def test_3x3_row_ring_agrees_with_the_weight_stationary_kernel(ring_3x3_everywhere, qin):
+    """(qin = 8: with the QuanInput2d quantiser in front of the 3x3 convolutions, applied on the way into the ring.)
+    Eval- and train-mode forward of a full-width net, N = 3 (ragged last workgroup: 192 image rows in ranges of 2), on the ring
     kernel against the weight-stationary kernel on the same state: the two differ in summation order only."""
     from cu_net_amd._lib import set_planner_option
     cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
@@ -233,6 +235,8 @@ def test_3x3_row_ring_agrees_with_the_weight_stationary_kernel(ring_3x3_everywhe
         net = cu_net_amd.create_cu_net(**cfg)
         net.load_state_dict(st)
         net.cuda().eval()
+        if qin:
+            net.set_quant_input(qin, ())
         with torch.no_grad():
             ev = [o.cpu() for o in net(x.cuda())]
         net.train()
@@ -244,11 +248,15 @@ def test_3x3_row_ring_agrees_with_the_weight_stationary_kernel(ring_3x3_everywhe
         tr = plan.debug_tensor(desc['tensors'][first3['out']]['name']).cpu()
         outs[mode] = (ev, tr, {k: v.clone().cpu() for k, v in net.state_dict().items() if 'running' in k})
     for a, b in zip(outs['ring'][0], outs['plain'][0]):
-        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-7
+        # (quantised activations: a BatchNorm output within rounding of a quantiser step may land on either side downstream)
+        assert (a - b).abs().max().item() <= (2e-3 if qin else 2e-5) * b.abs().max().item() + 1e-7
     a, b = outs['ring'][1], outs['plain'][1]
     assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()          # one node, identical inputs
     for k, v in outs['plain'][2].items():
-        assert torch.allclose(outs['ring'][2][k], v, rtol=1e-4, atol=1e-6), k
+        if qin:      # flipped quantiser steps propagate through the later BatchNorms: aggregate bound only
+            assert float((outs['ring'][2][k] - v).norm() / (v.norm() + 1e-12)) <= 2e-2, k
+        else:
+            assert torch.allclose(outs['ring'][2][k], v, rtol=1e-4, atol=1e-6), k
 
 
 def test_full_width_eval_forward_matches_oracle():
