@@ -574,7 +574,9 @@ void Plan::describe() {
         o << (i ? "," : "") << "{\"op\":\"" << tn[n.type] << "\",\"name\":\"" << n.name << "\",\"out\":" << n.out;
         if (n.bn >= 0) o << ",\"bn\":\"" << bns[n.bn].name << "\",\"ckpt\":" << (bns[n.bn].ckpt ? 1 : 0);
         if (n.conv >= 0) o << ",\"conv\":\"" << convs[n.conv].name << "\",\"taps\":" << n.taps;
-        o << ",\"head\":" << n.head << ",\"wg3\":" << n.wg3_S << ",\"segs\":[";
+        o << ",\"head\":" << n.head << ",\"wg3\":" << n.wg3_S << ",\"wg3_rows\":" << n.wg3_rows << ",\"wg3_bf16\":" << n.wg3_S16
+          << ",\"wg3_rows_bf16\":" << n.wg3_rows16 << ",\"wg3_wpi\":" << n.wg3_wpi << ",\"wg3_part\":" << n.wg3_part
+          << ",\"wg3_numel\":" << (n.wg3_S > 0 ? wg3_numel(n) : 0) << ",\"bucket\":" << n.bucket << ",\"segs\":[";
         for (size_t s = 0; s < n.segs.size(); ++s)
             o << (s ? "," : "") << "{\"t\":" << n.segs[s].tensor << ",\"ups\":" << n.segs[s].ups
               << "}";

@@ -57,3 +57,56 @@ def test_plan_errors():
         PlanHandle(4, 32, 128, 16, 2, 1, 2, 1, 200, 256)     # H not a multiple of 64
     with pytest.raises(CUNetError):
         PlanHandle(4, 6, 128, 16, 2, 1, 2, 1, 256, 256)      # growth not a multiple of 4
+
+
+@pytest.mark.parametrize('cfg,n,h,w', [
+    (dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2), 24, 256, 256),
+    (dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=8, order=1, loss_num=8), 24, 256, 256),
+    (dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2), 5, 256, 128),
+    (dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2), 1, 256, 256),
+])
+def test_weight_gradient_partial_tile_plan(cfg, n, h, w):
+    """Host-side invariants of the partial-tile weight gradients (wgrad3 family, plan.cpp): every split count covers the node's rows,
+    the bf16 split policy never needs more partials than the fp32 one (they share the region), 1x1 ranges are whole chunks of both
+    kernels, the bf16 3x3 ring walks rows in pairs, the stem's workgroups cover every output row of an image and fit the LDS, and the
+    partial regions of a gradient bucket do not overlap (the region itself is reused bucket after bucket)."""
+    from cu_net_amd._lib import PlanHandle
+    ph = PlanHandle(cfg['neck_size'], cfg['growth_rate'], cfg['init_chan_num'], cfg['class_num'], cfg['layer_num'], cfg['order'],
+                    cfg['loss_num'], n, h, w)
+    d = ph.describe()
+    T = d['tensors']
+    per_bucket = {}
+    seen = 0
+    for nd in d['nodes']:
+        if nd.get('wg3', 0) <= 0:
+            continue
+        seen += 1
+        o = T[nd['out']]
+        S, rows, S16, rows16 = nd['wg3'], nd['wg3_rows'], nd['wg3_bf16'], nd['wg3_rows_bf16']
+        assert 1 <= S16 <= S
+        if nd['op'] == 'stem_conv':
+            wpi = nd['wg3_wpi']
+            assert S == o['N'] * wpi and wpi * rows >= o['H'] and (wpi - 1) * rows < o['H']
+            cp = w + 6
+            cp += (17 - cp % 32 + 32) % 32
+            rp = 3 * cp
+            rp += (7 - rp % 32 + 32) % 32
+            assert (((2 * rows + 6) * rp + 3) // 4 * 4 + 64 * 128) * 4 <= 160 * 1024      # wgrad3_stem_lds_bytes
+            assert nd['wg3_numel'] == 128 * 147
+        elif nd['taps'] == 9:
+            nh = o['N'] * o['H']
+            assert S * rows >= nh and (S - 1) * rows < nh
+            assert S16 * rows16 >= nh and (S16 - 1) * rows16 < nh and rows16 % 2 == 0
+            assert nd['wg3_numel'] == 32 * 128 * 9
+        else:
+            m = o['N'] * o['H'] * o['W']
+            assert rows % 64 == 0 and rows16 % 64 == 0
+            assert S * rows >= m and (S - 1) * rows < m
+            assert S16 * rows16 >= m and (S16 - 1) * rows16 < m
+            assert S <= 256 and S16 <= 96
+        per_bucket.setdefault(nd['bucket'], []).append((nd['wg3_part'], nd['wg3_part'] + S * nd['wg3_numel']))
+    assert seen >= 20 * cfg['layer_num']
+    for b, spans in per_bucket.items():
+        spans.sort()
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 <= b0, (b, a0, a1, b0, b1)
