@@ -791,6 +791,153 @@ static hipError_t launch_conv3x3_ring(const ConvArgs& a, int num_cus, hipStream_
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 forward at the low levels (16x16 and below at batch 24: at most ~3 blocks per CU), split-K.  The weight-stationary
+// kernel gives each wave a whole tile: 10 dependent load -> MFMA chunks for a 320-channel concat behind a 40 KB operand copy,
+// 12-13 us per launch whatever the size (these launches are on the forward's critical path: nothing runs beside them).  Here a
+// 4-wave block owns ONE 32 x 32 output tile: wave w takes chunks w, w+4, w+8 of K, requests all of its A pieces AND its B
+// fragments (straight from L2, full lines: no operand copy) before the block builds the BatchNorm tables, contracts them in
+// <= 48 MFMAs, and the four partial tiles meet in LDS, where wave 0 adds them, stores the tile and the output statistics.
+constexpr int SK_MAXCH = 3;             // chunks per wave: K <= 384
+
+__global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);                 // [3][1024]
+    float* sc = part + 3 * 1024;                                  // [Ccat]
+    float* sh = sc + p.Ccat;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_gx > 0) {                                           // column slices of a row tile on one XCD (see conv_kernel)
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        by = slot % p.xcd_gy;
+        bx = (slot / p.xcd_gy) * 8 + xcd;
+        if (bx >= p.xcd_gx) return;
+    }
+    const int n0 = by * 32;
+    const int HW = p.H * p.W;
+    const int nchunks = p.K >> 5;
+    const int m = bx * 32 + li;                                   // this lane's A row (M % 32 == 0)
+    int rowU;
+    {
+        int nimg, py, px;
+        if (p.wshift >= 0) { nimg = m >> p.hwshift; const int rem = m & (HW - 1); py = rem >> p.wshift; px = rem & (p.W - 1); }
+        else { nimg = m / HW; const int rem = m - nimg * HW; py = rem / p.W; px = rem - py * p.W; }
+        rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+    }
+    // ---- all requests of this wave first
+    float4 a[SK_MAXCH][4], b[SK_MAXCH][4];
+#pragma unroll
+    for (int u = 0; u < SK_MAXCH; ++u) {
+        const int ch = wave + 4 * u;
+        if (ch < nchunks) {                                       // wave-uniform
+            int c = ch, s = 0;
+            while (c >= (p.seg[s].C >> 5)) { c -= p.seg[s].C >> 5; ++s; }
+            const Seg sg = p.seg[s];
+            const float* src = sg.x + (size_t)(sg.ups ? rowU : m) * sg.ld + c * 32 + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[u][q] = ldg4(src + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[u][q] = ldg4(p.wB + ((size_t)(ch * 8 + 2 * q + hi) * p.Npad + n0 + li) * 4);
+        }
+    }
+    // ---- BatchNorm scale / shift of the concat (every wave needs only its chunks, the block builds all: K <= 384 channels)
+    for (int s = 0; s < p.nseg; ++s) {
+        const Seg sg = p.seg[s];
+        for (int lc = tid; lc < sg.C; lc += 256) {
+            const int c = sg.choff + lc;
+            double mean, istd;
+            if (p.training) {
+                mean = sg.stats[lc] / sg.count;
+                double var = sg.stats[sg.C + lc] / sg.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                istd = 1.0 / sqrt(var + (double)BN_EPS);
+            } else {
+                mean = (double)p.rmean[c];
+                istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+            }
+            const double scale = (double)p.gamma[c] * istd;
+            sc[c] = (float)scale;
+            sh[c] = (float)((double)p.beta[c] - mean * scale);
+        }
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < SK_MAXCH; ++u) {
+        const int ch = wave + 4 * u;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sc + ch * 32 + 8 * q + 4 * hi);
+                const float4 h4 = *reinterpret_cast<const float4*>(sh + ch * 32 + 8 * q + 4 * hi);
+                float4 t = a[u][q];
+                t.x = fmaxf(fmaf(t.x, s4.x, h4.x), 0.f);
+                t.y = fmaxf(fmaf(t.y, s4.y, h4.y), 0.f);
+                t.z = fmaxf(fmaf(t.z, s4.z, h4.z), 0.f);
+                t.w = fmaxf(fmaf(t.w, s4.w, h4.w), 0.f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, b[u][q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, b[u][q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.z, b[u][q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.w, b[u][q].w, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int col = n0 + li;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = ((acc[r] + part[r * 64 + lane]) + part[1024 + r * 64 + lane]) + part[2048 + r * 64 + lane];
+            const int mm = bx * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            if (col < p.Nout) {
+                p.y[(size_t)mm * p.ldy + col] = v;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+        if (p.ystats != nullptr) {
+            double d1 = (double)s1, d2 = (double)s2;
+            d1 += shfl_xor_d(d1, 32);
+            d2 += shfl_xor_d(d2, 32);
+            if (hi == 0 && col < p.Nout) {
+                atomic_add_f64(p.ystats + col, d1);
+                atomic_add_f64(p.ystats + p.Nout + col, d2);
+            }
+        }
+    }
+}
+
+static bool conv1x1_splitk_supported(const ConvArgs& a, int num_cus) {
+    if (a.taps != 1 || a.K % 32 || a.K != a.Kpad || a.K < 128 || a.K > 32 * 4 * SK_MAXCH || a.M % 32 || a.qin_bits || a.xbf16) return false;
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % 32 || a.seg[i].ld % 4) return false;
+    const long blocks = (long)(a.M / 32) * ((a.Nout + 31) / 32);
+    return blocks <= 3L * num_cus;                                // everything resident at once: the launch is one round of blocks
+}
+
+static hipError_t launch_conv1x1_splitk(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    set_geometry_shifts(a);
+    const int gx = a.M / 32, gy = (a.Nout + 31) / 32;
+    dim3 grid(gx, gy);
+    a.xcd_gx = a.xcd_gy = 0;
+    if (gy > 1) { a.xcd_gx = gx; a.xcd_gy = gy; grid = dim3(8 * ((gx + 7) / 8) * gy, 1); }
+    const size_t smem = (size_t)3 * 1024 * 4 + (size_t)a.Ccat * 8;
+    hipLaunchKernelGGL(conv1x1_splitk_kernel, grid, dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
 static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
     size_t b = (size_t)taps * (Kpad / 4) * NT * 32 * 16;   // resident B operand
     b += (size_t)(Ccat / 4) * sizeof(GrpEnt);              // group table
@@ -849,6 +996,8 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 32);      // 3x3 forward on the LDS row ring at this width and above (64 and 32: +0.4 % over 64 only)
     if (load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= planner_options().conv3x3_ring_min_rows)
         return launch_conv3x3_ring(a_in, num_cus, s);
+    static const int use_sk = tune_int("CUNET_CONV_SPLITK", 1);
+    if (use_sk && load == LD_SEG && epi == EP_FWD && conv1x1_splitk_supported(a_in, num_cus)) return launch_conv1x1_splitk(a_in, s);
     static const int use_ts = tune_int("CUNET_CONV_TS", 1);
     if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
         a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups &&

@@ -23,7 +23,7 @@ CLASSES = [
     (r'wgrad_kernel<\(?cunet::\)?1|wgrad_kernel<1,', 'conv3x3_bwd_weight'),
     (r'wgrad_kernel<2,', 'stem_bwd_weight'),
     (r'conv3x3_tapsplit_kernel|conv3x3_ring_kernel', 'conv3x3_fwd'),
-    (r'conv_kernel<0, 0,', 'conv1x1_fwd'),
+    (r'conv_kernel<0, 0,|conv1x1_splitk_kernel', 'conv1x1_fwd'),
     (r'conv_kernel<1, 0,', 'conv3x3_fwd'),
     (r'conv_kernel<4, 0,', 'stem_conv_fwd'),
     (r'conv_kernel<2, 1,', 'conv1x1_bwd_data'),
