@@ -281,13 +281,34 @@ def main():
     ap.add_argument('--bf16-grads', action='store_true', help='with --bf16: the gradient tensors of backward (dY, dz, dX) stored as bf16 too')
     ap.add_argument('--bits-w', type=int, default=0, help='>0: quantised-weight train step (QuanOp, utils/quantize.py), e.g. 1 = BASELINE config 5')
     ap.add_argument('--popcount', action='store_true', help='with --bits-w 1/2: forward convs of the quantised layers on the AND-popcount kernel')
+    ap.add_argument('--planner-opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='cunet_set_planner_option(NAME, VALUE) before any plan is created (kernel-selection sweeps); repeatable')
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start the N ranks ourselves (one process per GPU, RCCL), exactly as the driver's
+    #      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` would
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log('bench.py: --gpus %d without WORLD_SIZE: re-launching as  %s' % (args.gpus, ' '.join(cmd)))
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if os.environ.get('CUNET_LIB_PATH'):
+        raise SystemExit('bench.py measures the shipped library (cu_net_amd/libcunet_hip.so): unset CUNET_LIB_PATH '
+                         '(the -DCUNET_TUNING build is for tools/ only)')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        log(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE')
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         '(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N) or run without a launcher')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -305,6 +326,11 @@ def main():
         ranks_seen = int(one.item())
 
     import cu_net_amd
+    for po in args.planner_opt:
+        name, _, val = po.partition('=')
+        cu_net_amd._lib.check(cu_net_amd._lib.lib().cunet_set_planner_option(name.encode(), int(val)), 'cunet_set_planner_option')
+    if rank == 0:
+        log('library: %s  (%s)' % (cu_net_amd._lib.LIB_PATH, cu_net_amd._lib.lib().cunet_version().decode()))
     L, K, bs = args.layers, args.class_num, args.bs
     mode = 'bf16_grads' if args.bf16_grads else ('bf16' if args.bf16 else 'fp32')
     is_default = (L, K, bs, mode, args.bits_w, args.forward_only, args.popcount) == (2, 68, 24, 'fp32', 0, False, False)
@@ -338,27 +364,29 @@ def main():
             'value_at_median': round(bs * world / r['ms_per_step_median'] * 1e3, 2),
             'ranks_seen_by_rccl': ranks_seen,
             'library': cu_net_amd._lib.lib().cunet_version().decode(),
+            'library_path': os.path.relpath(cu_net_amd._lib.LIB_PATH, ROOT),
             'roofline': r['roofline'],
             'final_loss': r['final_loss'],
         }
         for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
             if k in r:
                 out[k] = r[k]
-    # ---- the other single-GPU headline configurations (BASELINE.json configs[2] and configs[4]), N=1 only
-    if world == 1 and is_default and not args.no_also:
+    # ---- the other headline configurations of BASELINE.json, attached as `also`:
+    #      N = 1: configs[2] (CU-Net-8, bf16 storage), configs[4] (CU-Net-16, binary weights; MFMA and AND-popcount forward) and
+    #             the forward-only (inference) rates of the bench workload (SURVEY 8d "also forward-only img/s");
+    #      N > 1: configs[3] (CU-Net-8, K = 16, 24 images per rank, bucketed RCCL all-reduce) -- every rank takes part.
+    if is_default and not args.no_also:
         also = []
-        extra = [(8, 68, 'bf16_grads', 0, False), (16, 16, 'fp32', 1, False)]
-        try:
-            from cu_net_amd import trainer as _T
-            import inspect
-            if 'popcount' in inspect.signature(_T.FusedTrainer.__init__).parameters:
-                extra.append((16, 16, 'fp32', 1, True))
-        except Exception:
-            pass
-        for (l2, k2, m2, bw, pc) in extra:
+        if world == 1:
+            extra = [(8, 68, 'bf16_grads', 0, False, False), (16, 16, 'fp32', 1, False, False), (16, 16, 'fp32', 1, True, False),
+                     (2, 68, 'fp32', 0, False, True), (2, 68, 'bf16', 0, False, True)]
+        else:
+            extra = [(8, 16, 'bf16_grads', 0, False, False), (8, 16, 'fp32', 0, False, False)]
+        for (l2, k2, m2, bw, pc, fwd) in extra:
+            name2 = workload_name(l2, k2, bs, m2, bw, fwd, world, pc)
             try:
-                e = measure(dev, None, 0, 1, l2, k2, bs, args.also_steps, max(3, args.warmup), m2, bw, False, pc, args.profile_out)
-                ent = {'workload': workload_name(l2, k2, bs, m2, bw, False, 1, pc), 'value': round(e['value'], 2), 'unit': 'images/sec',
+                e = measure(dev, pg, rank, world, l2, k2, bs, args.also_steps, max(3, args.warmup), m2, bw, fwd, pc, args.profile_out)
+                ent = {'workload': name2, 'value': round(e['value'], 2), 'unit': 'images/sec', 'n_gpus': world,
                        'steps': args.also_steps, 'ms_per_step': round(e['ms_per_step'], 3), 'ms_per_step_median': round(e['ms_per_step_median'], 3),
                        'dtype': 'bf16' if m2 != 'fp32' else 'f32', 'roofline': e['roofline'], 'final_loss': e['final_loss']}
                 for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
@@ -366,8 +394,11 @@ def main():
                         ent[k] = e[k]
                 also.append(ent)
             except Exception as ex:      # an extra line must never take the headline measurement down
-                also.append({'workload': workload_name(l2, k2, bs, m2, bw, False, 1, pc), 'error': repr(ex)})
-        out['also'] = also
+                if world > 1:
+                    raise                # (a rank that drops out of a collective would hang the others)
+                also.append({'workload': name2, 'error': repr(ex)})
+        if rank == 0:
+            out['also'] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out['cpu_baseline'] = cpu_baseline(L, K, args.cpu_steps)

@@ -61,6 +61,7 @@ def lib():
         'cunet_plan_describe': (C.c_char_p, [vp]),
         'cunet_bind': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
         'cunet_set_quant_input': (i32, [vp, i32, C.POINTER(C.c_char_p), i32]),
+        'cunet_set_popcount_live': (i32, [vp, i32]),
         'cunet_forward': (i32, [vp, vp, C.POINTER(vp), i32, vp]),
         'cunet_loss_mse': (i32, [vp, vp, vp, vp]),
         'cunet_backward': (i32, [vp, C.POINTER(vp), vp]),
@@ -101,7 +102,7 @@ def lib():
 
 EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set_planner_option', 'cunet_plan_destroy', 'cunet_state_count',
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
-            'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind', 'cunet_set_quant_input',
+            'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind', 'cunet_set_quant_input', 'cunet_set_popcount_live',
             'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_flip_merge', 'cunet_augment_batch', 'cunet_render_targets',
             'cunet_debug_tensor_offset', 'cunet_quant_prepare', 'cunet_quant_restore', 'cunet_quant_grad',

@@ -71,6 +71,8 @@ struct ConvArgs {
     int any_ups;           // some segment is read through the nearest-upsample map
     int xcd_gx, xcd_gy;    // > 0: the grid is 1-D (8 * ceil(gx / 8) * gy blocks) and decoded so that the gy column-slice blocks of a row
                            // block are consecutive workgroups of ONE XCD (round-robin dispatch: id % 8): they share A through its L2
+    int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
+                           // planner option conv3x3_ring_min_rows; 0 = the default 512)
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)

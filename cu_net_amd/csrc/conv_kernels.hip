@@ -994,7 +994,7 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
 // waves per block and the grid.
 hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
     static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 32);      // 3x3 forward on the LDS row ring at this width and above (64 and 32: +0.4 % over 64 only)
-    if (load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= planner_options().conv3x3_ring_min_rows)
+    if (load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= (a_in.ring_min_rows > 0 ? a_in.ring_min_rows : 512))
         return launch_conv3x3_ring(a_in, num_cus, s);
     static const int use_sk = tune_int("CUNET_CONV_SPLITK", 1);
     if (use_sk && load == LD_SEG && epi == EP_FWD && conv1x1_splitk_supported(a_in, num_cus)) return launch_conv1x1_splitk(a_in, s);

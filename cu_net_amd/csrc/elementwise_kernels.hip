@@ -656,33 +656,45 @@ hipError_t launch_repack(const RepackEntry* tab, int n, const float* params, flo
 // Fused RMSprop over the flat arena (torch.optim.RMSprop, momentum 0, centered False; cu-net.py:60-61):
 //   v = alpha*v + (1-alpha)*g*g ;  p -= lr * g / (sqrt(v) + eps)
 // torch's op order (torch/optim/rmsprop.py: v.mul_(alpha).addcmul_(g, g, value=1-alpha); p.addcdiv_(g, sqrt(v)+eps, value=-lr)),
-// each operation rounded separately (no fma contraction), `oma` = (float)(1 - alpha) formed in double on the host.
+// each operation rounded separately: `#pragma clang fp contract(off)` keeps hipcc (default -ffp-contract=fast) from fusing
+// the multiplies into the adds (it did: `v_fma_f32 p, -lr, q, p`), plain `/` and sqrtf are the correctly rounded forms under
+// hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt (v_sqrt_f32 + fix-up, v_div_scale / v_div_fmas / v_div_fixup;
+// __fsqrt_rn is the 1-ulp v_sqrt_f32).  `oma` = (float)(1 - alpha) is formed in double on the host.
+__device__ __forceinline__ void rmsprop_elem(float& p, float g, float& v, float lr, float alpha, float oma, float eps) {
+#pragma clang fp contract(off)
+    const float t0 = alpha * v;
+    const float t1 = oma * g;
+    const float t2 = t1 * g;
+    v = t0 + t2;
+    const float d = sqrtf(v) + eps;
+    const float q = g / d;
+    const float u = lr * q;
+    p = p - u;
+}
+
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ v, long n, float lr, float alpha, float oma,
                                                       float eps, float gscale) {
+#pragma clang fp contract(off)
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
-        vv.x = __fadd_rn(__fmul_rn(alpha, vv.x), __fmul_rn(__fmul_rn(oma, gg.x), gg.x));
-        vv.y = __fadd_rn(__fmul_rn(alpha, vv.y), __fmul_rn(__fmul_rn(oma, gg.y), gg.y));
-        vv.z = __fadd_rn(__fmul_rn(alpha, vv.z), __fmul_rn(__fmul_rn(oma, gg.z), gg.z));
-        vv.w = __fadd_rn(__fmul_rn(alpha, vv.w), __fmul_rn(__fmul_rn(oma, gg.w), gg.w));
-        pp.x = __fadd_rn(pp.x, -__fmul_rn(lr, __fdiv_rn(gg.x, __fadd_rn(__fsqrt_rn(vv.x), eps))));
-        pp.y = __fadd_rn(pp.y, -__fmul_rn(lr, __fdiv_rn(gg.y, __fadd_rn(__fsqrt_rn(vv.y), eps))));
-        pp.z = __fadd_rn(pp.z, -__fmul_rn(lr, __fdiv_rn(gg.z, __fadd_rn(__fsqrt_rn(vv.z), eps))));
-        pp.w = __fadd_rn(pp.w, -__fmul_rn(lr, __fdiv_rn(gg.w, __fadd_rn(__fsqrt_rn(vv.w), eps))));
+        rmsprop_elem(pp.x, gg.x, vv.x, lr, alpha, oma, eps);
+        rmsprop_elem(pp.y, gg.y, vv.y, lr, alpha, oma, eps);
+        rmsprop_elem(pp.z, gg.z, vv.z, lr, alpha, oma, eps);
+        rmsprop_elem(pp.w, gg.w, vv.w, lr, alpha, oma, eps);
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(v)[i] = vv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = (n4 << 2) + threadIdx.x;
-        const float gg = g[i] * gscale;
-        const float vv = __fadd_rn(__fmul_rn(alpha, v[i]), __fmul_rn(__fmul_rn(oma, gg), gg));
+        float pp = p[i], vv = v[i];
+        rmsprop_elem(pp, g[i] * gscale, vv, lr, alpha, oma, eps);
         v[i] = vv;
-        p[i] = __fadd_rn(p[i], -__fmul_rn(lr, __fdiv_rn(gg, __fadd_rn(__fsqrt_rn(vv), eps))));
+        p[i] = pp;
     }
 }
 

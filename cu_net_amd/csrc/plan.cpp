@@ -210,6 +210,7 @@ int Plan::conv_node(const std::string& name, const std::string& bn_path, const s
 
 bool Plan::build(const cunet_cfg& c) {
     cfg = c;
+    opts = planner_options();
     error.clear();
     // ---- validation (models/cu_net.py:274-287, with exit() turned into an error)
     if (c.layer_num < 1 || c.loss_num < 1 || c.loss_num > c.layer_num) { error = "need 1 <= loss_num <= layer_num"; return false; }
@@ -400,7 +401,7 @@ void Plan::layout_workspace() {
     // Nodes are visited bucket by bucket so that a bucket's entries are contiguous in the reduce table.
     {
         const int P = 32;
-        const PlannerOptions& po = planner_options();
+        const PlannerOptions& po = opts;
         const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits));
         const int min_m = tune_int("CUNET_WG3_MIN_M", po.wgrad3_min_rows), enable = tune_int("CUNET_WG3", 1);
         // bf16 gradient tensors (measured on CU-Net-8: 1340 img/s at 256 splits / 2 chunks, 1387 at 96 / 4, 1110 at 32)
@@ -420,7 +421,11 @@ void Plan::layout_workspace() {
                     const int IW = cfg.width;
                     const bool oks = c.Cout == 128 && o.ld == 128 && c.Cin == STEM_K && o.W % STEM_CHUNK == 0 && IW % 8 == 0 &&
                                      cfg.width == 2 * o.W && cfg.height == 2 * o.H && o.rows() >= min_m;
-                    if (!oks) continue;
+                    // one output row per workgroup must fit the kernel's LDS ring and its staging registers (wide inputs, IW >= 1664,
+                    // do not: they keep the per-wave atomic kernel, wg3_S = 0)
+                    const bool fits1 = (int64_t)((((2 * 1 + 6) * stem_rp(IW) + 3) & ~3) + STEM_CHUNK * 128) * 4 <= 160 * 1024 &&
+                                       (int64_t)(2 * 1 + 5) * 3 * (IW / 4) <= 16 * 512;
+                    if (!oks || !fits1) continue;
                     int rows_max = 1;
                     while (rows_max < o.H && (int64_t)((((2 * (rows_max + 1) + 6) * stem_rp(IW) + 3) & ~3) + STEM_CHUNK * 128) * 4 <= 160 * 1024 &&
                            (int64_t)(2 * (rows_max + 1) + 5) * 3 * (IW / 4) <= 16 * 512) ++rows_max;

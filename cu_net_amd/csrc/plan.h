@@ -84,6 +84,8 @@ PlannerOptions& planner_options();
 
 struct Plan {
     cunet_cfg cfg;
+    PlannerOptions opts;      // snapshot of the process-wide options taken when the plan was created (cunet_set_planner_option later
+                              // does not change kernel selection of a live plan)
     // elements of one wgrad3 partial tile == of the node's weight tensor
     int64_t wg3_numel(const Node& n) const { return n.type == N_STEM_CONV ? (int64_t)convs[n.conv].Cout * convs[n.conv].Cin : (int64_t)convs[n.conv].Cout * n.Ccat * n.taps; }
     std::vector<int> anchors;

@@ -36,6 +36,7 @@ struct cunet_plan {
     std::vector<int> node_qin, node_tern;
     std::vector<TernPackEntry> ternpack;
     int ternpack_dirty = 0;
+    int tern_live = 0;               // cunet_set_popcount_live: the caller vouches that those convs' weights ARE ternary right now
     // call-order state
     int fwd_training_done = 0;
     int loss_done = 0;
@@ -337,6 +338,12 @@ int cunet_set_quant_input(cunet_plan_t* h, int bits_i, const char* const* ternar
     return count;
 }
 
+int cunet_set_popcount_live(cunet_plan_t* h, int live) {
+    if (!h) return fail(CUNET_ERR_INVALID, "null argument");
+    h->tern_live = live ? 1 : 0;
+    return CUNET_OK;
+}
+
 }  // extern "C"
 
 // ---- executor helpers -----------------------------------------------------------------------
@@ -583,7 +590,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     const int cus = h->num_cus;
     HIPCHK(hipMemsetAsync(h->ws + P.off_zero, 0, (size_t)P.zero_bytes, s));
     HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
-    if (h->qin_bits && !h->ternpack.empty()) {          // bit masks of the convs that run on AND-popcount this pass
+    if (h->qin_bits && h->tern_live && !h->ternpack.empty()) {          // bit masks of the convs that run on AND-popcount this pass
         if (h->ternpack_dirty) {
             HIPCHK(hipMemcpyAsync(h->ws + P.off_ternpack_tab, h->ternpack.data(), h->ternpack.size() * sizeof(TernPackEntry), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));             // (the host vector may change before an async copy has read it)
@@ -648,7 +655,8 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             a.qin_bits = h->qin_bits ? h->node_qin[ni] : 0;
-            if (a.qin_bits && h->node_tern[ni]) {
+            a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
+            if (a.qin_bits && h->node_tern[ni] && h->tern_live) {
                 // ternary weights x quantised activations: multiplier-free AND-popcount forward (one input tensor: the
                 // bottleneck output for a 3x3 conv, the U-Net output for a head)
                 const TensorInfo& ti = P.tensors[n.segs[0].tensor];

@@ -283,13 +283,27 @@ def train_epoch(loader: Iterable, trainer: FusedTrainer, epoch: int, opt, idx: L
     return losses.avg, pckhs.avg
 
 
-def validate(loader: Iterable, net: CUNet, idx: List[int] = TRAIN_ACC_IDX, flip_index=JOINT_FLIP_INDEX, process_group=None):
+def validate(loader: Iterable, net: CUNet, idx: List[int] = TRAIN_ACC_IDX, flip_index=JOINT_FLIP_INDEX, process_group=None,
+             quan_op=None):
     """cu-net.py:219-258 with flip test-time augmentation; returns (mean loss, mean PCKh, predictions N x K x 2).
-    With a process group the two means cover every rank's shard of the validation set (predictions stay per rank)."""
-    from .trainer import get_preds
+    With a process group the two means cover every rank's shard of the validation set (predictions stay per rank).
+    `quan_op`: the quantised drivers validate on QUANTISED weights -- quantization() before the loop, restore() after it
+    (cu-net-prev-version-wig.py:230,285)."""
     net.eval()
     losses, pckhs = AverageMeter(), AverageMeter()
     preds = []
+    if quan_op is not None:
+        quan_op.quantization()
+    try:
+        _validate_batches(loader, net, idx, flip_index, losses, pckhs, preds)
+    finally:
+        if quan_op is not None:
+            quan_op.restore()
+    return _validate_finish(net, losses, pckhs, preds, process_group)
+
+
+def _validate_batches(loader, net, idx, flip_index, losses, pckhs, preds):
+    from .trainer import get_preds
     with torch.no_grad():
         for batch in loader:
             img, heatmap = batch[0], batch[1]
@@ -304,6 +318,9 @@ def validate(loader: Iterable, net: CUNet, idx: List[int] = TRAIN_ACC_IDX, flip_
             losses.update(float(loss))      # cu-net.py:256,265: n = 1
             pckhs.update(float(acc[0]))
             preds.append(get_preds(out).cpu())
+
+
+def _validate_finish(net, losses, pckhs, preds, process_group):
     loss_avg, pckh_avg = losses.avg, pckhs.avg
     if process_group is not None:
         # every rank validated its own shard of the loader: the reference validates the WHOLE set, so the means are
@@ -360,7 +377,7 @@ def main(argv=None, train_loader: Optional[Iterable] = None, val_loader: Optiona
         val_loader = SyntheticLoader(max(opt.synthetic // 4, 1), per_rank, opt.class_num, dev, seed=9000 + rank)
     log = print if rank == 0 else (lambda *a, **k: None)
     if not opt.is_train:
-        val_loss, val_pckh, _ = validate(val_loader, net, process_group=pg)
+        val_loss, val_pckh, _ = validate(val_loader, net, process_group=pg, quan_op=quan)
         log('val loss %.6f  pckh %.4f' % (val_loss, val_pckh))
         return history
     return fit(opt, trainer, history, train_loader, val_loader, start_epoch, rank=rank, process_group=pg,
@@ -378,7 +395,8 @@ def fit(opt, trainer: FusedTrainer, history: TrainHistory, train_loader, val_loa
         if not opt.no_lr_schedule:          # cu-net.py:125 calls adjust_lr on every epoch, whatever --adjust_lr says
             adjust_lr(opt, trainer, epoch)
         train_loss, train_pckh = train_fn(train_loader, trainer, epoch, opt, log=log)
-        val_loss, val_pckh, _ = validate_fn(val_loader, net, process_group=process_group)
+        vkw = {'quan_op': trainer.quan_op} if getattr(trainer, 'quan_op', None) is not None else {}
+        val_loss, val_pckh, _ = validate_fn(val_loader, net, process_group=process_group, **vkw)
         history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', trainer.lr)]),
                        OrderedDict([('train_loss', train_loss), ('val_loss', val_loss)]), OrderedDict([('val_pckh', val_pckh)]))
         if rank == 0 and save_prefix is not None:

@@ -56,6 +56,8 @@ class _BoundPlan:
                                _ptr(net._buffer_arena), _ptr(net._counter_arena), _ptr(self.workspace), nbytes,
                                1 if training_ws else 0, _stream_ptr(dev)), 'cunet_bind')
         self._cb_keepalive = None
+        import weakref
+        self._net = weakref.ref(net)
         self.popcount_nodes = 0
         if net._quant_input[0] and not bf16:
             self.popcount_nodes = self.handle.set_quant_input(*net._quant_input)
@@ -70,6 +72,12 @@ class _BoundPlan:
                 o = torch.empty((n, k, self.hw_out[0], self.hw_out[1]), dtype=torch.float32, device=x.device)
                 outs.append(o)
                 arr[i] = o.data_ptr()
+        if self.popcount_nodes:
+            # the AND-popcount forward is only correct on ternary weights: it runs while a QuanOp holds the module's
+            # weights quantised (between quantization() and restore()), the MFMA path with the same quantiser otherwise
+            net = self._net()
+            live = 1 if (net is not None and net._weights_ternary) else 0
+            check(lib().cunet_set_popcount_live(self.handle.h, live), 'cunet_set_popcount_live')
         check(lib().cunet_forward(self.handle.h, _ptr(x), arr if want_outputs else None, 1 if training else 0,
                                   _stream_ptr(x.device)), 'cunet_forward')
         self.generation += 1
@@ -217,6 +225,7 @@ class CUNet(nn.Module):
         self._reference_init()
         self._plans: Dict[Tuple[int, int, int], _BoundPlan] = {}
         self._quant_input = (0, ())        # (bits_i, ternary conv names): see set_quant_input
+        self._weights_ternary = False      # set by QuanOp.quantization() (bits_w 1 / 2, scale dropped), cleared by restore()
         self._param_arena = None
         self._flatten(torch.device('cpu'))
 

@@ -68,9 +68,12 @@ class QuanOp:
         check(lib().cunet_quant_prepare(_ptr(net._param_arena), _ptr(self.saved), _ptr(self._tab), self.num_of_params,
                                         self.max_o, self.max_n, self.bits_w, self.bits_g, 1 if self.keep_scale else 0,
                                         _stream_ptr(dev)), 'cunet_quant_prepare')
+        # from here to restore() the target convs hold {-1, 0, +1}: the plan may run them on AND-popcount (module.py)
+        net._weights_ternary = self.bits_w in (1, 2) and not self.keep_scale
 
     def restore(self):
         net, dev = self._device_state()
+        net._weights_ternary = False
         check(lib().cunet_quant_restore(_ptr(net._param_arena), _ptr(self.saved), _ptr(self._tab), self.num_of_params,
                                         _stream_ptr(dev)), 'cunet_quant_restore')
 

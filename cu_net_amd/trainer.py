@@ -75,16 +75,28 @@ class FusedTrainer:
         plan = net._get_plan(n, h, w, True, bf16=self.bf16)
         if self.quan_op is not None:
             self.quan_op.quantization()
-        if self.bf16:
-            plan.forward_bf16(img, 2 if self.bf16_grads else 1, want_outputs=False)
-        else:
-            plan.forward(img, True, want_outputs=False)
-        loss = plan.loss_mse(heatmap)
-        if self.pg is None:
-            plan.backward(None)
-        else:
-            self.reducer.begin_step()
-            plan.backward(None, on_bucket=lambda b: self.reducer.reduce_bucket(net._grad_arena, b, plan.side_stream_join))
+        reducing = False
+        try:
+            if self.bf16:
+                plan.forward_bf16(img, 2 if self.bf16_grads else 1, want_outputs=False)
+            else:
+                plan.forward(img, True, want_outputs=False)
+            loss = plan.loss_mse(heatmap)
+            if self.pg is None:
+                plan.backward(None)
+            else:
+                self.reducer.begin_step()
+                reducing = True
+                plan.backward(None, on_bucket=lambda b: self.reducer.reduce_bucket(net._grad_arena, b, plan.side_stream_join))
+        except BaseException:
+            # a failed forward / backward (e.g. a bucket callback that could not issue its collective) must not leave the
+            # QUANTISED weights in the arena -- the latent fp32 weights would be lost -- nor the communication stream unjoined
+            if self.quan_op is not None:
+                self.quan_op.restore()
+            if reducing:
+                self.reducer.finish(net._grad_arena)
+            raise
+        if reducing:
             self.reducer.finish(net._grad_arena)
         gscale = 1.0 / self.world
         if self.quan_op is not None:

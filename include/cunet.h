@@ -169,6 +169,12 @@ int cunet_quant_grad(const float* params, float* grads, const void* table, int n
  * multiple of 2^-(bits_i-1).  Other quantised-input convs (e.g. the last head, which QuanOp leaves alone) stay on MFMA
  * with the quantiser folded into their operand loads.  fp32 plans only.  Returns the number of popcount nodes (>= 0). */
 int cunet_set_quant_input(cunet_plan_t* plan, int bits_i, const char* const* ternary_convs, int n_ternary);
+/* The AND-popcount forward packs only the SIGN planes of a weight: on weights that are not ternary it would silently compute a
+ * sign(w) convolution.  It therefore runs only while the caller declares the listed convs' weights ternary: live = 1 between
+ * QuanOp.quantization() and restore() (cu-net-prev-version-wig.py:165,189 in training, :230,285 around validation), live = 0
+ * (the default after cunet_set_quant_input) otherwise -- those convs then take the MFMA path with the quantiser in their loads,
+ * which is correct for any weights.  Host only; takes effect at the next cunet_forward. */
+int cunet_set_popcount_live(cunet_plan_t* plan, int live);
 
 /* ---- multiplier-free ternary convolution (AND + popcount over activation bit-planes): the non-MFMA
  * alternative for conv weights in {-1,0,+1} on bits_i-bit activations (QuanInput2d placement,
@@ -215,7 +221,8 @@ int cunet_flip_merge(const float* a, const float* b, const int32_t* perm, float*
  *   out:   N*K x H x W fp32, fully written */
 int cunet_render_targets(const double* pts, const float* patch, int half, float* out, int nk, int hh, int w, void* stream);
 
-/* Planner options (host only, process-wide, read when a plan is CREATED).  They select between equivalent kernels and
+/* Planner options (host only, process-wide; a plan takes a SNAPSHOT of them when it is created: later changes do not
+ * alter the kernel selection of live plans).  They select between equivalent kernels and
  * never change results beyond summation order:
  *   "wgrad3_min_rows"    1x1 weight gradients of nodes with at least this many output rows (N*H*W) use the LDS-staged
  *                        atomics-free kernel, smaller ones the per-wave atomic kernel (default 0: every eligible node --

@@ -140,11 +140,45 @@ def init_state(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
 
 class _Ctx:
     """Per-forward bookkeeping: which BNs the reference would re-run in backward."""
-    def __init__(self, state, training, quan_input_bits=0):
+    def __init__(self, state, training, quan_input_bits=0, storage='fp32'):
         self.state = state
         self.training = training
         self.recomputed: List[Tuple[str, torch.Tensor]] = []
         self.quan_input_bits = quan_input_bits
+        assert storage in ('fp32', 'bf16', 'bf16_grads')
+        self.storage = storage
+
+
+# ---- bf16 storage modes (BASELINE config 3; NOT a reference feature -- the reference is fp32).  The HIP path with bf16
+# storage (cunet_forward_bf16, include/cunet.h) rounds to bf16, round-to-nearest-even, at these points and computes in fp32
+# everywhere else; `storage='bf16'` / `'bf16_grads'` restates exactly those points so that a whole-step comparison has an
+# oracle that is rounded where the kernels round:
+#   * every tensor a node STORES (stem BN-ReLU-pool output, every conv output except the heads, pooled tensors -- a max of
+#     bf16 values is exact) -- and therefore the batch statistics every consumer BatchNorm derives from it;
+#   * the activated operand relu(bn(x)) on its way into the contraction, and the forward conv weights (bf16 MFMA operands);
+#   * 'bf16_grads' only: every gradient TENSOR of backward -- d(loss)/d(stored tensor) (heads included) and dz, the
+#     gradient at a BatchNorm output -- as tensor hooks that round the accumulated gradient once, as the per-tensor
+#     gather / data-gradient kernels store it; parameter gradients stay fp32; d(loss)/d(stem conv output) stays fp32.
+# Rounding is straight-through for autograd (the kernels differentiate the fp32 expression at the rounded values).
+def _round_bf16(t: torch.Tensor) -> torch.Tensor:
+    return t + (t.detach().bfloat16().float() - t.detach())
+
+
+def _grad_bf16(t: torch.Tensor) -> torch.Tensor:
+    if t.requires_grad:
+        t.register_hook(lambda g: g.bfloat16().float())
+    return t
+
+
+def _stored(ctx: "_Ctx", t: torch.Tensor, is_head: bool = False) -> torch.Tensor:
+    """What a node writes to memory in the context's storage mode."""
+    if ctx.storage == 'fp32':
+        return t
+    if not is_head:
+        t = _round_bf16(t)
+    if ctx.storage == 'bf16_grads':
+        t = _grad_bf16(t)
+    return t
 
 
 class _QuanInputFn(torch.autograd.Function):
@@ -166,7 +200,7 @@ class _QuanInputFn(torch.autograd.Function):
 
 
 def _bn_relu_conv(ctx: _Ctx, inputs: List[torch.Tensor], bn: str, conv: str, pad: int,
-                  checkpointed: bool, quan_site: bool = False) -> torch.Tensor:
+                  checkpointed: bool, quan_site: bool = False, is_head: bool = False) -> torch.Tensor:
     """cat -> BN -> ReLU -> conv  (models/cu_net.py:11-17).  `quan_site`: one of the places where the reference's
     quantised model puts a QuanInput2d between the ReLU and the conv (models/cu_net_prev_version_wig.py:96-98 the 3x3
     convs, :277-279 the heads); active when the forward was asked for quantised inputs."""
@@ -178,10 +212,17 @@ def _bn_relu_conv(ctx: _Ctx, inputs: List[torch.Tensor], bn: str, conv: str, pad
         st[bn + '.num_batches_tracked'] += 1
     y = F.batch_norm(x, st[bn + '.running_mean'], st[bn + '.running_var'],
                      st[bn + '.weight'], st[bn + '.bias'], ctx.training, BN_MOMENTUM, BN_EPS)
+    w = st[conv + '.weight']
+    if ctx.storage != 'fp32':
+        if ctx.storage == 'bf16_grads':
+            y = _grad_bf16(y)                    # dz is stored as bf16
+        y = _round_bf16(F.relu(y))               # the activated bf16 MFMA operand
+        w = _round_bf16(w)                       # the bf16 weight operand
+        return _stored(ctx, F.conv2d(y, w, None, 1, pad), is_head)
     y = F.relu(y)
     if quan_site and ctx.quan_input_bits:
         y = _QuanInputFn.apply(y, ctx.quan_input_bits)
-    return F.conv2d(y, st[conv + '.weight'], None, 1, pad)
+    return F.conv2d(y, w, None, 1, pad)
 
 
 def _dense_block(ctx: _Ctx, prefix: str, xs: List[torch.Tensor], i: int, saved: List[torch.Tensor],
@@ -207,14 +248,17 @@ def _dense_block(ctx: _Ctx, prefix: str, xs: List[torch.Tensor], i: int, saved: 
 
 
 def forward(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor,
-            training: bool = True, ctx_out: list | None = None, quan_input_bits: int = 0) -> List[torch.Tensor]:
+            training: bool = True, ctx_out: list | None = None, quan_input_bits: int = 0,
+            storage: str = 'fp32') -> List[torch.Tensor]:
     """`_CU_Net_Wrapper.forward` (models/cu_net.py:336-360).
 
     In training mode BN running statistics in `state` are updated in place exactly once per
     BN (the effect of the reference's *forward*); `finish_backward_stat_updates` applies the
     extra update the reference's checkpoint recompute performs during `backward()`.
     """
-    ctx = _Ctx(state, training, quan_input_bits)
+    ctx = _Ctx(state, training, quan_input_bits, storage)
+    if storage != 'fp32' and quan_input_bits:
+        raise ValueError('the quantised-input mode is fp32 only')
     st = state
     # stem, :299-304
     y = F.conv2d(x, st['features.conv0.weight'], None, 2, 3)
@@ -223,7 +267,7 @@ def forward(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor,
     y = F.batch_norm(y, st['features.norm0.running_mean'], st['features.norm0.running_var'],
                      st['features.norm0.weight'], st['features.norm0.bias'], training,
                      BN_MOMENTUM, BN_EPS)
-    y = F.max_pool2d(F.relu(y), 2, 2)
+    y = _stored(ctx, F.max_pool2d(F.relu(y), 2, 2))      # (the stem itself runs in fp32 in every storage mode)
 
     K = spec.order
     saved_blocks: Dict[str, List[torch.Tensor]] = {}
@@ -252,6 +296,8 @@ def forward(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor,
             name = f'hg.down_blocks.{j}'
             h, skips[j] = _dense_block(ctx, name, [h], i, saved_blocks.setdefault(name, []), K, True)
             h = F.max_pool2d(h, 2, 2)
+            if ctx.storage == 'bf16_grads':
+                h = _grad_bf16(h)                # (the pooled values are exact; its gradient tensor is stored as bf16)
         name = 'hg.neck_block'
         h, _ = _dense_block(ctx, name, [h], i, saved_blocks.setdefault(name, []), K, False)
         for j in reversed(range(NUM_BLOCKS)):
@@ -261,7 +307,7 @@ def forward(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor,
         cur = h
         if (i + 1) in spec.loss_anchors:                                   # :353-356
             p = f'linears.{i}'
-            outs.append(_bn_relu_conv(ctx, [cur], f'{p}.norm', f'{p}.conv', 0, False, quan_site=True))
+            outs.append(_bn_relu_conv(ctx, [cur], f'{p}.norm', f'{p}.conv', 0, False, quan_site=True, is_head=True))
     if ctx_out is not None:
         ctx_out.append(ctx)
     return outs
@@ -300,11 +346,13 @@ def conv_weight_names(spec: Spec) -> List[str]:
 
 def train_step(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor, target: torch.Tensor,
                opt_state: Dict[str, torch.Tensor] | None = None, lr: float = 2.5e-4,
-               alpha: float = 0.99, eps: float = 1e-8, apply_update: bool = True, quant=None, quan_input_bits: int = 0):
+               alpha: float = 0.99, eps: float = 1e-8, apply_update: bool = True, quant=None, quan_input_bits: int = 0,
+               storage: str = 'fp32'):
     """One optimisation step (cu-net.py:171-183) with RMSprop(lr, alpha, eps) (cu-net.py:60-61).
 
     `quant=(bits_w, bits_g)` wraps the step in QuanOp.quantization / restore / updateQuanGradWeight
     (utils/quantize.py:104-175, loop placement cu-net-prev-version-wig.py:163-190).
+    `storage` = 'bf16' / 'bf16_grads': the bf16 storage points of the HIP path (see `_stored`).
     Returns (loss, outputs, grads dict).  `state` is updated in place (running stats always,
     parameters when `apply_update`).  Parameters whose gradient is None (non-anchor heads)
     are skipped by the optimiser, as torch.optim.RMSprop does.
@@ -325,7 +373,7 @@ def train_step(spec: Spec, state: Dict[str, torch.Tensor], x: torch.Tensor, targ
         state[n].requires_grad_(True)
         state[n].grad = None
     ctxs: list = []
-    outs = forward(spec, state, x, True, ctxs, quan_input_bits=quan_input_bits)
+    outs = forward(spec, state, x, True, ctxs, quan_input_bits=quan_input_bits, storage=storage)
     loss = mse_loss(outs, target)
     loss.backward()
     finish_backward_stat_updates(ctxs[0])

@@ -17,11 +17,13 @@ therefore not a property ANY fp32 implementation can have beyond the first heads
   fp32        per head: relL2(hip, f64) <= 3 * relL2(ref32, f64) + 2e-5; heads where the reference itself is beyond 0.3
               are checked for finiteness and magnitude only.  loss, gradient norms, running-statistic sums: the same
               3x rule against the fp64 values (plus 5e-2 / 2e-3 floors; <= 1 % of the parameters may exceed it).
-  bf16        storage rounds every activation to 8 mantissa bits (rms relative error 1.1e-3 per stored tensor; ~18
-              stored tensors in sequence per U-Net; the same amplification inside the first U-Net as between U-Nets,
-              ~3.5x): first head ~2.5e-2 (measured 5.0e-2 = 2x that), then the network's own amplification
-              A_i = e_ref(i) / e_ref(0):  relL2 <= min(1.5, 3 * 2.5e-2 * A_i)  (1.5: two unrelated fields).  Loss within
-              5e-2.  Node-level bf16 exactness lives in tests/test_gpu_nodes.py.
+  bf16        storage rounds every activation to 8 mantissa bits, and the net amplifies that like any other perturbation
+              (head 0 is already 5e-2 from fp64).  The yardstick is the oracle ROUNDED AT THE SAME STORAGE POINTS
+              (oracle/cunet_ref.py storage='bf16' / 'bf16_grads', run here on the host): per head
+              relL2(hip, f64) <= 3 * relL2(rounded oracle, f64) while the rounded oracle is itself within 0.5 of fp64
+              (sanity beyond), the first two heads additionally within HALF that error of the rounded oracle itself
+              (same rounding points, only the fp32 summation order differs), loss by the same 3x rule, parameter
+              gradients against the rounded oracle's per U-Net.  Node-level bf16 exactness lives in tests/test_gpu_nodes.py.
   bits_w = 1  the reference's binarised net has +-1 weights without scale (utils/quantize.py:148-149): the same rules
               against its own fp64 evaluation (fp32 QuanOp decisions on a latent within rounding of 0 flip weights: the
               quantiser test allows 1e-3 of them), gradient norms on the 8-bit grid at 0.15.
@@ -38,6 +40,10 @@ from oracle import cunet_ref as O
 from tests._golden import Golden
 
 pytestmark = pytest.mark.gpu
+# bf16 modes: relative L2 between the HIP parameter gradients of the LAST U-Net (the shortest backward chain: head -> one U-Net) and
+# the bf16-rounded oracle's.  Forward activations of the last U-Net already differ by the chaos of the seven before it, so this is
+# a bound on correlation, not on rounding
+GRAD_VS_ROUNDED_ORACLE_LAST_UNET = 1.0
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -81,8 +87,18 @@ def _check_step(tag, mode, quan_bits=0):
     loss32, loss64 = float(g.z['loss']), float(g.z['loss64'])
     e_ref = [_rel2(g.t(f'out_sub/{i}'), g.t(f'out64_sub/{i}')) for i in range(spec.loss_num)]
     fp32 = mode == 'fp32'
+    orc = e_orc = orc_loss = orc_grads = None
+    if not fp32:
+        # the oracle ROUNDED WHERE THE KERNELS ROUND (oracle/cunet_ref.py `storage`): its own distance from the fp64 evaluation
+        # is what bf16 storage costs on this network, head by head
+        st16 = O.init_state(spec, seed=int(g.z['init_seed']))
+        orc_loss, orc_outs, orc_grads = O.train_step(spec, st16, x, target, apply_update=False, storage=mode)
+        orc = [o[:, ::4, ::4, ::4] for o in orc_outs]
+        e_orc = [_rel2(orc[i], g.t(f'out64_sub/{i}')) for i in range(spec.loss_num)]
     dl = abs(float(loss) - loss64) / abs(loss64)
-    bl = (3 * abs(loss32 - loss64) / abs(loss64) + 1e-4) if fp32 else 5e-2
+    bl = (3 * abs(loss32 - loss64) / abs(loss64) + 1e-4) if fp32 else max(3 * abs(float(orc_loss) - loss64) / abs(loss64), 2e-3)
+    if not fp32:
+        lines.append(f'bf16-rounded oracle: loss {float(orc_loss):.7g}; its heads vs f64: ' + ' '.join(f'{e:.2e}' for e in e_orc))
     lines.append(f'loss hip={float(loss):.7g} ref32={loss32:.7g} ref64={loss64:.7g}: |hip-f64|/f64={dl:.2e} (bound {bl:.1e})')
     if not dl <= bl:
         bad.append('loss')
@@ -93,15 +109,27 @@ def _check_step(tag, mode, quan_bits=0):
         e = _rel2(got, r64)
         if fp32:
             bound = 3 * e_ref[i] + 2e-5
+            chaotic = e_ref[i] > 0.3
         else:
-            bound = min(1.5, 3 * 2.5e-2 * e_ref[i] / e_ref[0])
-        if e_ref[i] > 0.3 or bound >= 1.5:          # the reference itself is decorrelated from fp64 here: sanity only
+            # the same storage points must cost the kernels what they cost the rounded oracle (3x: the rule of the fp32 modes);
+            # where the rounded oracle itself is decorrelated from fp64 (>= 0.5) nothing more than sanity can be asked
+            bound = 3 * e_orc[i]
+            chaotic = e_orc[i] > 0.5
+        if chaotic:          # the yardstick itself is decorrelated from fp64 here: sanity only
             m_got, m_ref = float(got.abs().max()), float(r64.abs().max())
             ok = bool(torch.isfinite(o).all()) and 0.25 * m_ref <= m_got <= 4 * m_ref
-            lines.append(f'{"ok " if ok else "BAD"} head {i:2d} (chaotic: ref32-vs-f64 {e_ref[i]:.2e}) hip-vs-f64 {e:.2e}, magnitude {m_got:.3g} vs {m_ref:.3g}')
+            lines.append(f'{"ok " if ok else "BAD"} head {i:2d} (chaotic: ref32-vs-f64 {e_ref[i]:.2e}' + ('' if fp32 else f', rounded oracle-vs-f64 {e_orc[i]:.2e}')
+                         + f') hip-vs-f64 {e:.2e}, magnitude {m_got:.3g} vs {m_ref:.3g}')
         else:
             ok = e <= bound and bool(torch.isfinite(o).all())
-            lines.append(f'{"ok " if ok else "BAD"} head {i:2d} hip-vs-f64 relL2={e:.3e}  ref32-vs-f64={e_ref[i]:.3e}  bound={bound:.3e}  vs ref32 {_rel2(got, g.t(f"out_sub/{i}")):.3e}')
+            direct = '' if fp32 else f'  hip-vs-rounded-oracle {_rel2(got, orc[i]):.3e}'
+            lines.append(f'{"ok " if ok else "BAD"} head {i:2d} hip-vs-f64 relL2={e:.3e}  ref32-vs-f64={e_ref[i]:.3e}  bound={bound:.3e}  vs ref32 {_rel2(got, g.t(f"out_sub/{i}")):.3e}' + direct)
+            if not fp32 and i < 2:
+                # same rounding points, different fp32 summation order: hip and the rounded oracle differ by far less than either
+                # differs from fp64 (measured: see gpurun_out/parity_configs_*) -- at most HALF the storage error on the first two heads
+                okd = _rel2(got, orc[i]) <= 0.5 * e_orc[i]
+                if not okd:
+                    bad.append(f'head {i} vs rounded oracle')
         if not ok:
             bad.append(f'head {i}')
     names = g.z['grad_norm_names'].tolist()
@@ -122,6 +150,29 @@ def _check_step(tag, mode, quan_bits=0):
             nb += 1
             if nb <= 10:
                 lines.append(f'BAD gradnorm {k} hip={got:.4e} ref32={n32:.4e} ref64={n64:.4e}')
+    if not fp32:
+        # against the rounded oracle's own gradients, grouped by the U-Net index the parameter belongs to: the backward chain
+        # from the loss to U-Net i is (L - i) U-Nets long, so agreement is expected to decay from the last U-Net to the first
+        import re
+        by_unet = {}
+        for k in names:
+            if orc_grads.get(k) is None:
+                continue
+            m = re.search(r'\.(?:layers|adapters_ahead|adapters_skip|adapters)\.(\d+)\.|^linears\.(\d+)\.', k)
+            if m is None:
+                u = -1
+            else:
+                u = int(m.group(1) if m.group(1) is not None else m.group(2)) + (1 if k.startswith('intermedia.') else 0)
+            o, nmel = off[k]
+            gh = net._grad_arena[o:o + nmel].double().cpu().view(-1)
+            go = orc_grads[k].double().view(-1)
+            num, den = by_unet.get(u, (0.0, 0.0))
+            by_unet[u] = (num + float((gh - go).pow(2).sum()), den + float(go.pow(2).sum()))
+        rels = {u: (num / max(den, 1e-300)) ** 0.5 for u, (num, den) in by_unet.items()}
+        lines.append('parameter gradients vs the rounded oracle, relative L2 per U-Net (-1 = stem): ' + ' '.join(f'{u}:{rels[u]:.2e}' for u in sorted(rels)))
+        last = spec.layer_num - 1
+        if not rels[last] <= GRAD_VS_ROUNDED_ORACLE_LAST_UNET:
+            bad.append(f'gradients of the last U-Net vs the rounded oracle: {rels[last]:.2e}')
     lines.append(f'gradient norms: {len(names)} parameters, {nb} beyond 3x the reference fp32-vs-fp64 deviation + {floor}; worst ratio to the bound {worst:.2f}')
     # a few percent may exceed it: e.g. features.norm0.weight -- with beta = 0 the stem output is scaled per channel by
     # gamma and every consumer starts with a train-mode BatchNorm, so d(loss)/d(gamma) is ~0 analytically and what any

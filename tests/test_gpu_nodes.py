@@ -148,7 +148,7 @@ def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0
     from cu_net_amd._lib import set_planner_option
     set_planner_option('wgrad3_min_rows', 0 if wgrad3_all else 1 << 30)
     try:
-        _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops)
+        return _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops)
     finally:
         set_planner_option('wgrad3_min_rows', 0)
 
@@ -256,6 +256,7 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
             torch.cuda.synchronize()
             _close(f'{nd["name"]} dW', pgrad(nd['conv'] + '.weight'), wt.grad, bad)
     assert not bad, f'{len(bad)} mismatches:\n' + '\n'.join(bad[:40])
+    return desc
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -265,7 +266,7 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
 # rounding through the (chaotic) network, so it keeps the per-kernel tolerance while covering what the node tests do
 # not: the per-tensor consumer lists (order-K FIFO, skip connections, intermedia carries), the 4-child sums behind
 # the up-sample maps, pool routing, and that no contribution is dropped or counted twice.
-def _check_composition(cfg, st, x, target):
+def _check_composition(cfg, st, x, target, check_params=False):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
@@ -281,6 +282,13 @@ def _check_composition(cfg, st, x, target):
     produced = {T[nd['out']]['name'] for nd in desc['nodes']}
     grads = {nm: plan.debug_tensor(nm, grad=True).cpu() for nm in produced}
     expect = {}
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    pbad = []
+
+    def pcheck(label, name, ref):
+        if check_params:
+            o, nmel, shape = off[name]
+            _close(label, net._grad_arena[o:o + nmel].view(shape), ref, pbad)
 
     def add(nm, g):
         expect[nm] = g if nm not in expect else expect[nm] + g
@@ -298,11 +306,17 @@ def _check_composition(cfg, st, x, target):
             leaves = [acts[T[s['t']]['name']].clone().requires_grad_(True) for s in nd['segs']]
             parts = [F.interpolate(l, scale_factor=2, mode='nearest') if s['ups'] else l for l, s in zip(leaves, nd['segs'])]
             cat = torch.cat(parts, 1) if len(parts) > 1 else parts[0]
-            y = F.conv2d(F.relu(F.batch_norm(cat, None, None, st[nd['bn'] + '.weight'], st[nd['bn'] + '.bias'], True, 0.1, 1e-5)),
-                         st[nd['conv'] + '.weight'], None, 1, 1 if nd['taps'] == 9 else 0)
+            gamma = st[nd['bn'] + '.weight'].clone().requires_grad_(check_params)
+            beta = st[nd['bn'] + '.bias'].clone().requires_grad_(check_params)
+            wt = st[nd['conv'] + '.weight'].clone().requires_grad_(check_params)
+            y = F.conv2d(F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5)), wt, None, 1, 1 if nd['taps'] == 9 else 0)
             y.backward(dy)
             for l, s in zip(leaves, nd['segs']):
                 add(T[s['t']]['name'], l.grad)
+            if check_params:
+                pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad)
+                pcheck(f'{nd["name"]} dgamma', nd['bn'] + '.weight', gamma.grad)
+                pcheck(f'{nd["name"]} dbeta', nd['bn'] + '.bias', beta.grad)
         elif op == 'pool':
             nm = T[nd['segs'][0]['t']]['name']
             leaf = acts[nm].clone().requires_grad_(True)
@@ -311,14 +325,24 @@ def _check_composition(cfg, st, x, target):
         elif op == 'stem_bnpool':
             nm = T[nd['segs'][0]['t']]['name']
             leaf = acts[nm].clone().requires_grad_(True)
-            F.max_pool2d(F.relu(F.batch_norm(leaf, None, None, st[nd['bn'] + '.weight'], st[nd['bn'] + '.bias'], True, 0.1, 1e-5)), 2, 2).backward(dy)
+            gamma = st[nd['bn'] + '.weight'].clone().requires_grad_(check_params)
+            beta = st[nd['bn'] + '.bias'].clone().requires_grad_(check_params)
+            F.max_pool2d(F.relu(F.batch_norm(leaf, None, None, gamma, beta, True, 0.1, 1e-5)), 2, 2).backward(dy)
             add(nm, leaf.grad)
+            if check_params:
+                pcheck(f'{nd["name"]} dgamma', nd['bn'] + '.weight', gamma.grad)
+                pcheck(f'{nd["name"]} dbeta', nd['bn'] + '.bias', beta.grad)
+        elif op == 'stem_conv' and check_params:
+            wt = st[nd['conv'] + '.weight'].clone().requires_grad_(True)
+            F.conv2d(x, wt, None, 2, 3).backward(dy)
+            pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad)
     assert heads == cfg['loss_num']
     bad = []
     for nm, g in expect.items():
         _close('d ' + nm, grads[nm], g, bad)
     assert len(expect) >= len(produced) - cfg['loss_num']
     assert not bad, f'{len(bad)} tensors whose gradient is not the sum of their consumers\' contributions:\n' + '\n'.join(bad[:30])
+    assert not pbad, f'{len(pbad)} parameter gradients off:\n' + '\n'.join(pbad[:30])
 
 
 @pytest.mark.parametrize('tag', ['G2_L3_o2', 'G3_L4_o1_ln2', 'G4_L2_o0', 'G9_L2_o1_c32'])
@@ -335,3 +359,42 @@ def test_whole_backward_composition_full_width_cu_net4():
     st = O.init_state(spec, seed=71)
     x, target = O.synthetic_batch(1, 16, 256, seed=72)
     _check_composition(cfg, st, x, target)
+
+
+def test_whole_backward_composition_bench_batch():
+    """BASELINE config 2 exactly as bench.py runs it -- CU-Net-2, K = 68, N = 24, 256 x 256, default planner options: every
+    weight-gradient workgroup walks 12 or more chunks (the double-buffer reuse of wgrad3_kernel needs >= 3), the 3x3 forward
+    is on the LDS row ring, the data gradients run their multi-tile loops, 1536 image rows per level.  Composition check of
+    the tensor gradients after ONE real backward pass, and the parameter gradients of every conv / BatchNorm against
+    autograd on the GPU's own activations and output gradients."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=81)
+    x, target = O.synthetic_batch(24, 68, 256, seed=82)
+    _check_composition(cfg, st, x, target, check_params=True)
+
+
+@pytest.mark.parametrize('mode', [False, 2])
+def test_weight_gradient_steady_state_loops(mode):
+    """The LDS-staged weight gradients with FEW, LONG splits (planner options wgrad3_max_splits = 8 and the bf16 pair): at N = 2
+    a workgroup of the 64 x 64 nodes owns 1024 pixels = 32 chunks (1x1: wgrad3_kernel / wgrad3_bf16_kernel) or 16 image rows
+    (3x3: wgrad3_3x3_kernel / wgrad3_3x3_bf16_kernel), i.e. the steady state of their double-buffered loops, which the default
+    split policy only reaches at bench batch sizes.  Conv nodes only, against autograd on identical inputs."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=83)
+    x, _ = O.synthetic_batch(2, 68, 256, seed=84)
+    saved = {'wgrad3_max_splits': 256, 'wgrad3_max_splits_bf16': 96}
+    for k in saved:
+        set_planner_option(k, 8)
+    try:
+        desc = _check_all_nodes(cfg, st, x, bf16=mode, wgrad3_all=True, only_ops=('conv',))
+    finally:
+        for k, v in saved.items():
+            set_planner_option(k, v)
+    key = 'wg3_bf16' if mode == 2 else 'wg3'
+    big = [nd for nd in desc['nodes'] if nd['op'] == 'conv' and nd.get(key, 0) > 0 and desc['tensors'][nd['out']]['W'] == 64]
+    assert big and all(nd[key] <= 8 for nd in big), [nd[key] for nd in big]
