@@ -73,13 +73,17 @@ def _rel2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
 
 
-def _check_step(tag, mode, quan_bits=0):
+def _check_step(tag, mode, quan_bits=0, quan_input_bits=0, popcount=False):
     g, spec, net, x, target = _setup(tag)
     quan = None
     if quan_bits:
         from cu_net_amd.quant import QuanOp
         quan = QuanOp(net, bits_w=quan_bits, bits_i=8, bits_g=8)
-    tr = FusedTrainer(net, quan_op=quan, bf16=mode != 'fp32', bf16_grads=mode == 'bf16_grads')
+    tr = FusedTrainer(net, quan_op=quan, bf16=mode != 'fp32', bf16_grads=mode == 'bf16_grads', quan_input_bits=quan_input_bits, popcount=popcount)
+    if popcount:
+        plan = net._get_plan(x.shape[0], x.shape[2], x.shape[3], True)
+        assert plan.popcount_nodes == 9 * spec.layer_num + spec.loss_num, plan.popcount_nodes      # every 3x3 conv and every head
+
     loss = tr.step(x.cuda(), target.cuda())
     outs = tr.last_outputs(x.shape)
     torch.cuda.synchronize()
@@ -179,7 +183,7 @@ def _check_step(tag, mode, quan_bits=0):
     # implementation computes is the residue of a cancellation (4.6 in fp32, 18 with bf16 activations)
     if nb > (len(names) // 50 if fp32 else len(names) // 25):
         bad.append(f'{nb} gradient norms')
-    if fp32:       # running statistics after the double (checkpoint) update: sums per buffer
+    if fp32 and 'running_names' in g.z.files:       # running statistics after the double (checkpoint) update: sums per buffer
         sd = net.state_dict()
         rw, nbr = 0.0, 0
         for k, s32, s64 in zip(g.z['running_names'].tolist(), g.z['running_sums'], g.z['running_sums64']):
@@ -190,7 +194,7 @@ def _check_step(tag, mode, quan_bits=0):
         lines.append(f'running statistics: {nbr} buffer sums beyond the bound, worst ratio {rw:.2f}')
         if nbr > len(g.z['running_sums']) // 100:
             bad.append('running stats')
-    _report(f'{tag}_{mode}' + (f'_bw{quan_bits}' if quan_bits else ''), lines)
+    _report(f'{tag}_{mode}' + (f'_bw{quan_bits}' if quan_bits else '') + ('_popcount' if popcount else ''), lines)
     assert not bad, (bad, lines[:20])
 
 
@@ -210,6 +214,17 @@ def test_config5_cu_net16_k16_fp32():
 
 def test_config5_cu_net16_k16_bits_w1():
     _check_step('G13_full_L16K16_bw1', 'fp32', quan_bits=1)
+
+
+@pytest.mark.parametrize('popcount', [False, True])
+def test_config5_cu_net16_k16_bits_w1_quantised_inputs(popcount):
+    """The `--popcount` line of bench.py at its own size: CU-Net-16, QuanOp(bits_w = 1), QuanInput2d(8 bits) in front of every 3x3 /
+    head conv, those convs' forward on AND-popcount (or on MFMA with the quantiser in the loads).  Fixture: the ORACLE's step of the
+    quantised-input model in fp32 and float64 (the reference's model file for it does not import; its pieces are pinned one by
+    one, see tools/gen_golden.py full_width_quan_input).  A discontinuous net: its own fp32-vs-fp64 distance is 1e-2 at the first
+    head and it is decorrelated from the fourth on, so the 3x rule bites on the first heads and the loss only; exactness of this
+    mode is asserted node by node (tests/test_gpu_quant.py::test_quantised_loop_is_exact_node_by_node)."""
+    _check_step('G13_full_L16K16_bw1_qin8', 'fp32', quan_bits=1, quan_input_bits=8, popcount=popcount)
 
 
 def test_every_node_backward_cu_net8():

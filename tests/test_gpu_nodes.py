@@ -266,12 +266,26 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
 # rounding through the (chaotic) network, so it keeps the per-kernel tolerance while covering what the node tests do
 # not: the per-tensor consumer lists (order-K FIFO, skip connections, intermedia carries), the 4-child sums behind
 # the up-sample maps, pool routing, and that no contribution is dropped or counted twice.
-def _check_composition(cfg, st, x, target, check_params=False):
+def _check_composition(cfg, st, x, target, check_params=False, quan_bits_w=0, quan_input_bits=0, popcount=False):
+    """quan_bits_w / quan_input_bits / popcount: the quantised loop of cu-net-prev-version-wig.py:163-190 -- QuanOp.quantization()
+    before the forward, QuanInput2d in front of the 3x3 / head convs, optionally their forward on AND-popcount.  The torch side
+    then differentiates the SAME quantised network: the weights it uses are read back from the GPU arena after quantization().
+    Returns (net, qop) with the raw (not yet rewritten) gradients in the arena and the weights still quantised."""
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
     n, _, h, w = x.shape
+    qop = None
+    if quan_bits_w:
+        from cu_net_amd.quant import QuanOp
+        qop = QuanOp(net, bits_w=quan_bits_w, bits_i=quan_input_bits or 8, bits_g=8)
+    if quan_input_bits:
+        net.set_quant_input(quan_input_bits, qop.target_names if popcount else ())
+    if qop is not None:
+        qop.quantization()
+        st = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     plan = net._get_plan(n, h, w, True)
+    assert (plan.popcount_nodes > 0) == bool(popcount)
     plan.forward(x.cuda(), True, want_outputs=False)
     plan.loss_mse(target.cuda())
     plan.backward(None)
@@ -283,7 +297,7 @@ def _check_composition(cfg, st, x, target, check_params=False):
     grads = {nm: plan.debug_tensor(nm, grad=True).cpu() for nm in produced}
     expect = {}
     off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
-    pbad = []
+    pbad, bad_fwd = [], []
 
     def pcheck(label, name, ref):
         if check_params:
@@ -309,7 +323,18 @@ def _check_composition(cfg, st, x, target, check_params=False):
             gamma = st[nd['bn'] + '.weight'].clone().requires_grad_(check_params)
             beta = st[nd['bn'] + '.bias'].clone().requires_grad_(check_params)
             wt = st[nd['conv'] + '.weight'].clone().requires_grad_(check_params)
-            y = F.conv2d(F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5)), wt, None, 1, 1 if nd['taps'] == 9 else 0)
+            act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
+            if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
+                from oracle.cunet_ref import _QuanInputFn
+                act = _QuanInputFn.apply(act, quan_input_bits)
+            y = F.conv2d(act, wt, None, 1, 1 if nd['taps'] == 9 else 0)
+            if quan_input_bits:
+                # the forward itself, node by node on the GPU's own inputs: with ternary weights and 2^-7-grid activations the 3x3 / head
+                # convs are exact on both sides, elsewhere the fp32 tolerance applies
+                # (an activation within rounding of a quantiser step lands on the neighbouring 2^-7 level on one side only: with
+                # fan-in 1152 about 1 % of the outputs contain such a flip, 1/128 each -- hence the wider element tolerance there)
+                site = nd['taps'] == 9 or nd.get('head', -1) >= 0
+                _close(f'{nd["name"]} forward', acts[oname], y, bad_fwd, **(dict(rtol=3e-3, frac=2e-3) if site else {}))
             y.backward(dy)
             for l, s in zip(leaves, nd['segs']):
                 add(T[s['t']]['name'], l.grad)
@@ -343,6 +368,8 @@ def _check_composition(cfg, st, x, target, check_params=False):
     assert len(expect) >= len(produced) - cfg['loss_num']
     assert not bad, f'{len(bad)} tensors whose gradient is not the sum of their consumers\' contributions:\n' + '\n'.join(bad[:30])
     assert not pbad, f'{len(pbad)} parameter gradients off:\n' + '\n'.join(pbad[:30])
+    assert not bad_fwd, f'{len(bad_fwd)} node forwards off:\n' + '\n'.join(bad_fwd[:30])
+    return net, qop
 
 
 @pytest.mark.parametrize('tag', ['G2_L3_o2', 'G3_L4_o1_ln2', 'G4_L2_o0', 'G9_L2_o1_c32'])

@@ -261,3 +261,90 @@ def test_quantised_input_train_step_matches_oracle(popcount):
         assert torch.equal(got * 128, torch.round(got * 128))
         num += float((got - ref_grads[n]).double().pow(2).sum()); den += float(ref_grads[n].double().pow(2).sum())
     assert (num / den) ** 0.5 <= 0.9, (num / den) ** 0.5      # 8-bit-rounded gradients of a discontinuous net: correlated, no more
+
+
+@pytest.mark.parametrize('net_kind,popcount', [('G9', False), ('G9', True), ('full', True)])
+def test_quantised_loop_is_exact_node_by_node(net_kind, popcount):
+    """The quantised training loop (cu-net-prev-version-wig.py:163-190) with QuanInput2d sites, checked EXACTLY instead of
+    end to end: after quantization() -> forward -> MSE -> backward on the GPU, (1) every node's forward equals torch's on the
+    GPU's own inputs and the quantised weights read back from the arena, (2) every tensor gradient is the sum of its consumers'
+    contributions differentiated by torch through the oracle's QuanInput function, (3) every raw parameter gradient matches,
+    (4) after restore() the weights are the saved latents and updateQuanGradWeight() turns the GPU's own raw gradients into what
+    the oracle's rewrite (pinned to the executed utils/quantize.py, G7) makes of them."""
+    from oracle import cunet_ref as O
+    from tests._golden import Golden
+    from tests.test_gpu_nodes import _check_composition
+    if net_kind == 'G9':
+        g = Golden('G9_L2_o1_c32')
+        cfg, st, x, target = g.cfg, g.group('state0'), g.t('x'), g.t('target')
+        spec = O.Spec(**cfg)
+        for n in O.conv_weight_names(spec):
+            st[n] = st[n] * 8.0
+    else:
+        cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+        spec = O.Spec(**cfg)
+        st = O.init_state(spec, seed=91)
+        x, target = O.synthetic_batch(1, 16, 256, seed=92)
+    latent0 = {k: v.clone() for k, v in st.items()}
+    net, qop = _check_composition(cfg, st, x, target, check_params=True, quan_bits_w=1, quan_input_bits=8, popcount=popcount)
+    off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    raw = net._grad_arena.clone().cpu()
+    qop.restore()
+    qop.updateQuanGradWeight()
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    nbad = ntot = 0
+    for n in qop.target_names:
+        k = n + '.weight'
+        o, nmel, shape = off[k]
+        wq, latent = QR.quantization(latent0[k], 1, 8)
+        b, t = _mismatch(sd[k], latent, 1 / 128)                       # restore(): the 8-bit-rounded latent
+        nbad += b; ntot += t
+        want = QR.grad_rewrite(sd[k].cpu(), raw[o:o + nmel].view(shape), 1, 8)
+        got = net._grad_arena[o:o + nmel].view(shape)
+        b, t = _mismatch(got, want, 1 / 128)
+        nbad += b; ntot += t
+    assert nbad <= 1e-3 * ntot, (nbad, ntot)
+
+
+def test_popcount_forward_only_while_weights_are_quantised():
+    """The AND-popcount forward packs the SIGN planes of a weight, so on weights that are not ternary it would compute a sign(w)
+    convolution.  It must therefore run only between QuanOp.quantization() and restore(): after a fused step (which restores),
+    an eval-mode forward of the popcount-configured net equals the forward of an MFMA-configured twin on the same state -- and
+    validation on QUANTISED weights (cu-net-prev-version-wig.py:230,285) still takes the popcount path."""
+    from cu_net_amd.trainer import FusedTrainer
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=93)
+    x, target = O.synthetic_batch(2, 16, 256, seed=94)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    qop = QuanOp(net, bits_w=1, bits_i=8, bits_g=8)
+    tr = FusedTrainer(net, quan_op=qop, quan_input_bits=8, popcount=True)
+    tr.step(x.cuda(), target.cuda())
+    assert not net._weights_ternary
+    twin = cu_net_amd.create_cu_net(**cfg)
+    twin.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    twin = twin.cuda().eval()
+    twin.set_quant_input(8, ())
+    net.eval()
+    with torch.no_grad():
+        a = net(x.cuda())
+        b = twin(x.cuda())
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)                      # the same kernels on the same state (eval mode: no atomics)
+    qop.quantization()                                # validation on quantised weights: popcount is live again
+    assert net._weights_ternary
+    with torch.no_grad():
+        c = net(x.cuda())
+    tq = QuanOp(twin, bits_w=1, bits_i=8, bits_g=8)
+    tq.quantization()
+    with torch.no_grad():
+        d = twin(x.cuda())
+    qop.restore(); tq.restore()
+    first_site = net._get_plan(2, 256, 256, False)
+    assert first_site.popcount_nodes > 0
+    for u, v in zip(c, d):       # popcount and MFMA forwards of the same ternary convs are bit-identical node by node; downstream
+        assert ((u - v).double().norm() / v.double().norm()).item() <= 1e-5      # fp32 nodes only reorder sums (eval mode)

@@ -15,6 +15,7 @@ refuses to write fixtures if the oracle disagrees.
 Usage:  python -B tools/gen_golden.py      (needs /root/reference; not runnable on the GPU box)
 """
 import contextlib
+from collections import OrderedDict
 import io
 import os
 import sys
@@ -265,6 +266,36 @@ def full_width_cfg(ref, tag, cfg, n, init_seed, batch_seed, rq=None, bits_w=None
     e = [float((a.double() - b).norm() / b.norm()) for a, b in zip(out, out64)]
     np.savez_compressed(os.path.join(OUT, tag + '.npz'), **fx)
     print(f'{tag}: full width {cfg} N={n} bits_w={bits_w} loss={float(loss):.6f}  oracle == reference; '
+          f'fp32-vs-fp64 relL2 per head {["%.1e" % v for v in e]}')
+
+
+def full_width_quan_input(tag, cfg, n, init_seed, batch_seed, bits_w, bits_i):
+    """G13 ... _qin8: BASELINE config 5's network in the reference's QUANTISED-INPUT form -- QuanOp(bits_w) weights AND a
+    QuanInput2d of bits_i bits in front of every 3x3 / head conv (models/cu_net_prev_version_wig.py:96-98,277-279).  That model
+    file does not import on a modern torch (raw cuDNN bindings of 0.1.12), so unlike G12 / G13 this fixture is NOT a run of a
+    reference module: it is the ORACLE's step, whose pieces are each pinned to executed reference code -- the network and the
+    train step (G1..G13), QuanOp's three phases (G7, G13_bw1) and QuanInput.forward/backward (G14).  Stored like G12 / G13:
+    sub-sampled heat maps, loss, gradient norms, in fp32 and in float64."""
+    spec = O.Spec(**cfg)
+    x, target = O.synthetic_batch(n, cfg['class_num'], 256, seed=batch_seed)
+    st = O.init_state(spec, seed=init_seed)
+    loss, outs, grads = O.train_step(spec, st, x, target, apply_update=False, quant=(bits_w, 8), quan_input_bits=bits_i)
+    fx = {'cfg': np.array(list(cfg.values()), dtype=np.int64), 'init_seed': np.array(init_seed), 'batch_seed': np.array(batch_seed),
+          'n': np.array(n), 'loss': to_np(loss), 'bits_w': np.array(bits_w), 'bits_i': np.array(bits_i)}
+    for i, a in enumerate(outs):
+        fx[f'out_sub/{i}'] = to_np(a)[:, ::4, ::4, ::4].copy()
+    names = [k for k in grads if grads[k] is not None]
+    fx['grad_norm_names'] = np.array(names, dtype='U')
+    fx['grad_norms'] = np.array([float(grads[k].double().norm()) for k in names])
+    st64 = OrderedDict((k, (v.double() if v.is_floating_point() else v.clone())) for k, v in O.init_state(spec, seed=init_seed).items())
+    loss64, outs64, grads64 = O.train_step(spec, st64, x.double(), target.double(), apply_update=False, quant=(bits_w, 8), quan_input_bits=bits_i)
+    fx['loss64'] = to_np(loss64)
+    for i, a in enumerate(outs64):
+        fx[f'out64_sub/{i}'] = to_np(a)[:, ::4, ::4, ::4].copy()
+    fx['grad_norms64'] = np.array([float(grads64[k].norm()) for k in names])
+    e = [float((a.double() - b).norm() / b.norm()) for a, b in zip(outs, outs64)]
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **fx)
+    print(f'{tag}: oracle-generated (quantised-input model), N={n} bits_w={bits_w} bits_i={bits_i} loss={float(loss):.6f}; '
           f'fp32-vs-fp64 relL2 per head {["%.1e" % v for v in e]}')
 
 
@@ -598,6 +629,8 @@ def big_configs(ref, rq=None):
     full_width_cfg(ref, 'G13_full_L16K16', dict(full, class_num=16, layer_num=16, order=1, loss_num=16), n=1, init_seed=4, batch_seed=24)
     full_width_cfg(ref, 'G13_full_L16K16_bw1', dict(full, class_num=16, layer_num=16, order=1, loss_num=16), n=1, init_seed=4,
                    batch_seed=24, rq=rq, bits_w=1)
+    full_width_quan_input('G13_full_L16K16_bw1_qin8', dict(full, class_num=16, layer_num=16, order=1, loss_num=16), n=1, init_seed=4,
+                          batch_seed=24, bits_w=1, bits_i=8)
 
 
 def augment_parity():
@@ -674,6 +707,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 2 and sys.argv[1] == '--only':       # regenerate one fixture
+        if sys.argv[2] == 'qin':
+            full = dict(neck_size=4, growth_rate=32, init_chan_num=128)
+            full_width_quan_input('G13_full_L16K16_bw1_qin8', dict(full, class_num=16, layer_num=16, order=1, loss_num=16), n=1, init_seed=4,
+                                  batch_seed=24, bits_w=1, bits_i=8)
+            return
         if sys.argv[2] in ('big', 'binop'):
             ref = load_reference_models()
             {'big': big_configs, 'binop': lambda r: binop_quaninput_parity(r, load_reference_quantize())}[sys.argv[2]](ref)
