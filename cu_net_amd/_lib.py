@@ -75,7 +75,7 @@ def lib():
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
         'cunet_final_preds': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'cunet_flip_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-        'cunet_augment_batch': (i32, [vp, i32, vp, i32, vp]),
+        'cunet_augment_batch': (i32, [vp, vp, i32, vp, i32, vp]),
         'cunet_render_targets': (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
         'cunet_debug_tensor_offset': (i64, [vp, C.c_char_p, i32]),
         'cunet_quant_prepare': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

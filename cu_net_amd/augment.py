@@ -1,13 +1,13 @@
 """Training-sample preparation on the GPU: the image half of the reference's data loader
 (data/mpii_for_mpii_22.py:120-145 -- scale / rotation jitter, horizontal flip, per-channel colour gain, `HumanAug.crop`
-to the 256 x 256 network input, `TransformPts` / `shufflelr` for the target points) for a whole batch in one launch.
+to the 256 x 256 network input, `TransformPts` / `shufflelr` for the target points) for a whole batch.
 
-The per-sample geometry (crop window, rotation padding, pre-shrink factor) is computed on the host exactly as
-pylib/HumanAug.py:10-42,118-142 computes it (float64, the same integer truncation); the kernel then takes ONE bilinear
-sample per output pixel (and per k x k sub-sample when the reference would shrink the image first) at the composition of
-the resize, the rotation and the window offset.  The reference's resamplers (scipy.misc.imresize / imrotate: 8-bit PIL
-images with a data-dependent contrast stretch) no longer exist; pixel values are therefore defined by
-oracle/augment_ref.py (same geometry, plain bilinear), not by the reference -- see DESIGN.md.
+The per-sample geometry (crop window, rotation padding, pre-shrink size) is computed on the host exactly as
+pylib/HumanAug.py:10-42,118-142 computes it (float64, the same integer truncation).  The pixels follow the reference's own
+route: its resamplers scipy.misc.imresize / imrotate were PIL's 8-bit `Image.resize` / `Image.rotate(BILINEAR)` behind scipy's
+byte-scale, so the library keeps crop()'s stages (byte-scale -> [shrink] -> canvas -> [rotate] -> resize -> / 255) with uint8
+intermediates and PIL's arithmetic restated exactly; the result equals the reference function executed over PIL bit for bit
+(tests/golden/G16_crop.npz; oracle/augment_ref.py is the numpy restatement the GPU tests compare with).
 """
 from __future__ import annotations
 
@@ -21,34 +21,36 @@ from .module import _ptr, _stream_ptr
 
 MPII_PAIRS = ([0, 5], [1, 4], [2, 3], [10, 15], [11, 14], [12, 13])      # pylib/HumanAug.py:238-242
 
-_REC = np.dtype([('src', np.uint64), ('sh', np.int32), ('sw', np.int32), ('ulx', np.int32), ('uly', np.int32),
-                 ('win_w', np.int32), ('win_h', np.int32), ('pad', np.int32), ('k', np.int32),
-                 ('cw', np.int32), ('ch', np.int32), ('flip', np.int32), ('rotated', np.int32),
-                 ('sf', np.float64), ('cs', np.float64), ('sn', np.float64), ('g0', np.float32), ('g1', np.float32), ('g2', np.float32),
-                 ('pad_', np.float32)])        # == struct AugSample of csrc/common.h (96 bytes)
+_REC = np.dtype([('src', np.uint64), ('mm', np.uint64), ('i8', np.uint64), ('t1', np.uint64), ('i1', np.uint64), ('c8', np.uint64),
+                 ('r8', np.uint64), ('t2', np.uint64), ('o8', np.uint64), ('rm', np.float64, (6,)),
+                 ('sh', np.int32), ('sw', np.int32), ('sh1', np.int32), ('sw1', np.int32), ('ulx', np.int32), ('uly', np.int32),
+                 ('cw', np.int32), ('ch', np.int32), ('win_w', np.int32), ('win_h', np.int32), ('pad', np.int32),
+                 ('flip', np.int32), ('rotated', np.int32), ('pre', np.int32), ('gain', np.float32, (3,)), ('pad_', np.int32)])
+assert _REC.itemsize == 192        # == struct AugSample of csrc/common.h
+
+
+def _translation(dx, dy):
+    m = np.eye(3)
+    m[0, 2], m[1, 2] = dx, dy
+    return m
 
 
 def get_transform(center, scale, rot, res, size):
-    """pylib/HumanAug.py:10-34."""
-    h = size * scale
-    t = np.zeros((3, 3))
-    t[0, 0] = float(res) / h
-    t[1, 1] = float(res) / h
-    t[0, 2] = res * (-float(center[0]) / h + .5)
-    t[1, 2] = res * (-float(center[1]) / h + .5)
-    t[2, 2] = 1
-    if not rot == 0:
-        rot = -rot
-        rot_rad = rot * np.pi / 180
-        sn, cs = np.sin(rot_rad), np.cos(rot_rad)
-        rot_mat = np.array([[cs, -sn, 0.], [sn, cs, 0.], [0., 0., 1.]])
-        t_mat = np.eye(3)
-        t_mat[0, 2] = -res / 2
-        t_mat[1, 2] = -res / 2
-        t_inv = t_mat.copy()
-        t_inv[:2, 2] *= -1
-        t = np.dot(t_inv, np.dot(rot_mat, np.dot(t_mat, t)))
-    return t
+    """Image -> crop coordinates as a 3 x 3 homogeneous matrix (pylib/HumanAug.py:10-34): the box of `size * scale` pixels
+    around `center` is mapped onto [0, res)^2; a rotation by -rot degrees is taken about the centre of the crop.  The
+    factors are multiplied in the reference's order (right to left: map, shift the crop centre to the origin, rotate,
+    shift back), which keeps the entries -- and so the truncated point coordinates -- identical to its."""
+    box = size * scale
+    k = float(res) / box
+    m = np.array([[k, 0., res * (0.5 - float(center[0]) / box)],
+                  [0., k, res * (0.5 - float(center[1]) / box)],
+                  [0., 0., 1.]])
+    if rot == 0:
+        return m
+    phi = -rot * np.pi / 180
+    s_, c_ = np.sin(phi), np.cos(phi)
+    turn = np.array([[c_, -s_, 0.], [s_, c_, 0.], [0., 0., 1.]])
+    return _translation(res / 2, res / 2) @ (turn @ (_translation(-res / 2, -res / 2) @ m))
 
 
 def transform_pts(pts, center, scale, rot, res, size=200, invert=0):
@@ -70,10 +72,19 @@ def shufflelr(pts, width, pairs=MPII_PAIRS):
     return x
 
 
-def _geometry(center, scale, rot, res, size):
-    """pylib/HumanAug.py:118-142 (window of the source image, rotation padding, pre-shrink factor)."""
-    sf_full = float(scale * size) / float(res)
-    sf = sf_full if sf_full >= 2 else 1.0
+def _geometry(center, scale, rot, res, size, sh, sw):
+    """pylib/HumanAug.py:118-142 for an sh x sw image: pre-shrunk size (or None), canvas corners ul / br incl. the rotation
+    padding, pad."""
+    sf = float(scale * size) / float(res)
+    pre = None
+    if sf < 2:
+        sf = 1
+    else:
+        if np.floor(max(sh, sw) / sf) < 2:
+            raise CUNetError('augment_batch: the person box is larger than the whole image can be shrunk to (HumanAug.crop returns the '
+                             'image unchanged there, :124-125)')
+        frac = 1 / sf                                           # imresize(img, size=1/scale_factor): int(W * frac) x int(H * frac)
+        pre = (int(sh * frac), int(sw * frac))
     c = np.asarray(center, dtype=np.float64) / sf
     s = scale / sf
 
@@ -87,14 +98,28 @@ def _geometry(center, scale, rot, res, size):
     if not rot == 0:
         ul = ul - pad
         br = br + pad
-    k = int(np.floor(sf_full)) if sf_full >= 2 else 1
-    return ul, br, pad, sf, k
+    return ul, br, pad, pre
+
+
+def _pil_rotate_matrix(w, h, angle_deg):
+    """Image.rotate(angle) of a w x h image (expand off, centre = image centre): the destination -> source affine map,
+    computed the way PIL computes it (entries rounded to 15 decimals)."""
+    import math
+    angle = angle_deg % 360.0
+    cx, cy = w / 2.0, h / 2.0
+    ang = -math.radians(angle)
+    m = [round(math.cos(ang), 15), round(math.sin(ang), 15), 0.0, round(-math.sin(ang), 15), round(math.cos(ang), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
 
 
 def augment_batch(images, centers, scales, rots=None, flips=None, gains=None, res: int = 256, size: float = 200.0):
     """images: list of C x H x W fp32 GPU tensors in [0, 1] (any sizes); centers N x 2 (x, y) -- already mirrored for flipped
     samples, as the reference does (`c[0] = W - c[0]`); scales N; rots N degrees (0 = none); flips N bool; gains N x 3.
-    Returns N x 3 x res x res fp32.  One launch for the batch."""
+    Returns N x 3 x res x res fp32 (values k / 255: the reference's crop ends in uint8)."""
     n = len(images)
     if n == 0:
         raise CUNetError('augment_batch: empty batch')
@@ -108,22 +133,56 @@ def augment_batch(images, centers, scales, rots=None, flips=None, gains=None, re
     scales = np.asarray(scales, dtype=np.float64).reshape(-1)
     rec = np.zeros(n, dtype=_REC)
     keep = []
+    need = 0
+
+    def take(nbytes):                     # scratch offsets (16-byte aligned) inside one caller-owned buffer
+        nonlocal need
+        off = need
+        need += (int(nbytes) + 15) // 16 * 16
+        return off
+    offs = []
     for i, img in enumerate(images):
         if img.dim() != 3 or img.shape[0] != 3 or img.dtype != torch.float32 or img.device != dev:
             raise CUNetError('augment_batch: every image must be a 3 x H x W fp32 tensor on the same GPU')
         img = img.contiguous()
         keep.append(img)
         rot = float(rots[i])
-        ul, br, pad, sf, k = _geometry(centers[i], float(scales[i]), rot, res, size)
+        if rot != 0 and rot % 90.0 == 0:
+            raise CUNetError('augment_batch: rotations by multiples of 90 degrees take PIL\'s transpose path, which is not restated')
+        sh, sw = int(img.shape[1]), int(img.shape[2])
+        ul, br, pad, pre = _geometry(centers[i], float(scales[i]), rot, res, size, sh, sw)
         cw, ch = int(br[0] - ul[0]), int(br[1] - ul[1])
         rotated = 1 if rot != 0 else 0
-        phi = -np.deg2rad(rot)
-        rec[i] = (img.data_ptr(), img.shape[1], img.shape[2], int(ul[0]), int(ul[1]), cw - 2 * pad * rotated, ch - 2 * pad * rotated,
-                  pad, k, cw, ch, int(bool(flips[i])), rotated, sf, np.cos(phi), np.sin(phi), gains[i, 0], gains[i, 1], gains[i, 2], 0.0)
-    tab = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        win_w, win_h = cw - 2 * pad * rotated, ch - 2 * pad * rotated
+        if cw < 1 or ch < 1 or win_w < 1 or win_h < 1:
+            raise CUNetError('augment_batch: empty crop window')
+        r = rec[i]
+        r['src'] = img.data_ptr()
+        r['sh'], r['sw'] = sh, sw
+        r['pre'] = 1 if pre is not None else 0
+        if pre is not None:
+            r['sh1'], r['sw1'] = pre
+        r['ulx'], r['uly'], r['cw'], r['ch'], r['win_w'], r['win_h'], r['pad'] = int(ul[0]), int(ul[1]), cw, ch, win_w, win_h, pad
+        r['flip'], r['rotated'] = int(bool(flips[i])), rotated
+        r['gain'] = gains[i].astype(np.float32)
+        if rotated:
+            r['rm'] = _pil_rotate_matrix(cw, ch, rot)
+        o = {'mm': take(32), 'c8': take(ch * cw * 3), 't2': take(win_h * res * 3), 'o8': take(res * res * 3)}
+        if rotated:
+            o['r8'] = take(win_h * win_w * 3)
+        if pre is not None:
+            o['i8'], o['t1'], o['i1'] = take(sh * sw * 3), take(sh * pre[1] * 3), take(pre[0] * pre[1] * 3)
+        offs.append(o)
+    scratch = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    base = scratch.data_ptr()
+    for i, o in enumerate(offs):
+        for k, v in o.items():
+            rec[i][k] = base + v
+    host = np.ascontiguousarray(rec.view(np.uint8))
+    tab = torch.from_numpy(host.copy()).to(dev)
     out = torch.empty((n, 3, res, res), dtype=torch.float32, device=dev)
-    check(lib().cunet_augment_batch(_ptr(tab), n, _ptr(out), int(res), _stream_ptr(dev)), 'cunet_augment_batch')
-    out._cunet_keepalive = (keep, tab)          # the launch is asynchronous: inputs must outlive it
+    check(lib().cunet_augment_batch(_ptr(tab), C.c_void_p(host.ctypes.data), n, _ptr(out), int(res), _stream_ptr(dev)), 'cunet_augment_batch')
+    out._cunet_keepalive = (keep, tab, scratch)          # the launches are asynchronous: inputs and scratch must outlive them
     return out
 
 

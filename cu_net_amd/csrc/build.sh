@@ -4,7 +4,7 @@
 #                                work-skipping timing switches compiled in; tools/ only, never the shipped library)
 set -e
 cd "$(dirname "$0")"
-SRCS="conv_kernels.hip wgrad_kernels.hip wgrad3_kernels.hip elementwise_kernels.hip quant_kernels.hip bf16_kernels.hip runtime.hip"
+SRCS="augment_kernels.hip conv_kernels.hip wgrad_kernels.hip wgrad3_kernels.hip elementwise_kernels.hip quant_kernels.hip bf16_kernels.hip runtime.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function"
 if [ -n "$CUNET_TUNING" ]; then
   OUT=../libcunet_hip_tuning.so; BUILD=build_tuning; FLAGS="$FLAGS -DCUNET_TUNING"

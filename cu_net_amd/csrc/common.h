@@ -211,19 +211,28 @@ struct TernArgs {
     double* ystats;          // [2][O] sum / sum of squares of the output (or null)
 };
 
-struct AugSample {           // one training sample of cunet_augment_batch (host-computed crop geometry, pylib/HumanAug.py:118-142)
+struct AugSample {           // one training sample of cunet_augment_batch (host-computed crop geometry, pylib/HumanAug.py:118-142); 192 bytes
     const float* src;        // 3 x sh x sw fp32 CHW image in [0, 1]
+    unsigned* mm;            // 5 words of scratch: min / max bit patterns of the image (pre-shrink) and of the canvas, maximum output byte
+    unsigned char* i8;       // pre-shrink only: byte-scaled image sh x sw x 3, its horizontal pass sh x sw1 x 3, the shrunk image sh1 x sw1 x 3
+    unsigned char* t1;
+    unsigned char* i1;
+    unsigned char* c8;       // byte-scaled canvas ch x cw x 3
+    unsigned char* r8;       // rotated only: the rotated canvas without its padding, win_h x win_w x 3
+    unsigned char* t2;       // horizontal pass of the final resize, win_h x res x 3
+    unsigned char* o8;       // res x res x 3
+    double rm[6];            // rotated only: PIL's destination -> source affine map of Image.rotate on the cw x ch canvas
     int sh, sw;
-    int ulx, uly;            // upper-left corner of the (padded) window in the (pre-shrunk) image
-    int win_w, win_h;        // window size without the rotation padding: what is resized to res x res
-    int pad, k;              // rotation padding; k x k sub-samples per output pixel (pre-shrink factor >= 2)
-    int cw, ch;              // padded canvas size (rotation centre = its middle)
-    int flip, rotated;
-    double sf;               // pre-shrink factor of the reference (1 if scale * size / res < 2)
-    double cs, sn;           // cos / sin of PIL's destination -> source rotation angle (-rot degrees)
+    int sh1, sw1;            // pre-shrink only: int(sh / sf), int(sw / sf)
+    int ulx, uly;            // upper-left corner of the (padded) canvas in the (shrunk) image
+    int cw, ch;              // canvas size incl. the rotation padding
+    int win_w, win_h;        // canvas size without it: what is resized to res x res
+    int pad;
+    int flip, rotated, pre;
     float gain[3];           // per-channel colour gain (clamped to [0, 1] afterwards)
-    float pad_;
+    int pad_;
 };
+static_assert(sizeof(AugSample) == 192, "AugSample is bound from Python (cu_net_amd/augment.py _REC)");
 
 struct TernPackEntry {       // one conv whose (ternary) weights are packed into AND-popcount bit masks
     int64_t src;             // float offset of the weight [O][C][taps] in the parameter arena

@@ -852,59 +852,4 @@ hipError_t launch_render_targets(const double* pts, const float* patch, int half
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// Training-sample preparation (data/mpii_for_mpii_22.py:127-141): horizontal flip, per-channel colour gain + clamp and
-// HumanAug.crop (window on a zero canvas -> rotation about the canvas centre -> resize to res x res) as ONE bilinear sample
-// per output pixel at the composed coordinate.  One thread per output pixel (all three channels), blockIdx.y = sample.
-// Coordinates in fp64 (the host computed the window exactly as the reference; see cu_net_amd/augment.py).
-__global__ __launch_bounds__(256) void augment_kernel(const AugSample* __restrict__ tab, float* __restrict__ out, int res) {
-    const AugSample a = tab[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= res * res) return;
-    const int oy = idx / res, ox = idx - oy * res;
-    const double padd = a.rotated ? (double)a.pad : 0.0;
-    const double ccx = 0.5 * a.cw, ccy = 0.5 * a.ch;
-    float acc[3] = {0.f, 0.f, 0.f};
-    const size_t plane = (size_t)a.sh * a.sw;
-    for (int sy = 0; sy < a.k; ++sy)
-        for (int sx = 0; sx < a.k; ++sx) {
-            const double offx = ((double)sx + 0.5) / a.k - 0.5, offy = ((double)sy + 0.5) / a.k - 0.5;
-            double u = ((double)ox + offx + 0.5) * a.win_w / res - 0.5 + padd;      // resize: pixel centres at half-integers
-            double v = ((double)oy + offy + 0.5) * a.win_h / res - 0.5 + padd;
-            if (a.rotated) {
-                const double px = u + 0.5 - ccx, py = v + 0.5 - ccy;
-                u = a.cs * px + a.sn * py + ccx - 0.5;
-                v = -a.sn * px + a.cs * py + ccy - 0.5;
-            }
-            const double xs = (u + a.ulx + 0.5) * a.sf - 0.5;
-            const double ys = (v + a.uly + 0.5) * a.sf - 0.5;
-            const double fx0 = floor(xs), fy0 = floor(ys);
-            const int x0 = (int)fx0, y0 = (int)fy0;
-            const double fx = xs - fx0, fy = ys - fy0;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int yy = y0 + dy, xx = x0 + dx;
-                    if (yy < 0 || yy >= a.sh || xx < 0 || xx >= a.sw) continue;       // zero canvas outside the image
-                    const double w = (dy ? fy : 1.0 - fy) * (dx ? fx : 1.0 - fx);
-                    const int xsrc = a.flip ? a.sw - 1 - xx : xx;                       // the crop reads the mirrored image
-                    const float* px = a.src + (size_t)yy * a.sw + xsrc;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float g = fminf(fmaxf(px[c * plane] * a.gain[c], 0.f), 1.f);   // gain + clamp BEFORE the resampling
-                        acc[c] += (float)(w * (double)g);
-                    }
-                }
-        }
-    const float inv = 1.f / (float)(a.k * a.k);
-    float* o = out + ((size_t)blockIdx.y * 3) * res * res + idx;
-    o[0] = acc[0] * inv; o[(size_t)res * res] = acc[1] * inv; o[(size_t)2 * res * res] = acc[2] * inv;
-}
-
-hipError_t launch_augment(const AugSample* tab, int n, float* out, int res, hipStream_t s) {
-    hipLaunchKernelGGL(augment_kernel, dim3((res * res + 255) / 256, n), dim3(256), 0, s, tab, out, res);
-    return hipGetLastError();
-}
-
 }  // namespace cunet

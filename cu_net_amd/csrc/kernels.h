@@ -40,7 +40,7 @@ hipError_t launch_render_targets(const double* pts, const float* patch, int half
 hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, float* out, int N, int K, int H, int W, hipStream_t s);
 hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,
                               int H, int W, int res0, int res1, hipStream_t s);
-hipError_t launch_augment(const AugSample* tab, int n, float* out, int res, hipStream_t s);
+hipError_t launch_augment(const AugSample* tab_dev, const AugSample* tab_host, int n, float* out, int res, hipStream_t s);
 hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, int W, hipStream_t s);
 
 hipError_t launch_quant_prepare(const QuantEntry* tab, int nconv, int maxO, int maxN, float* params, float* saved,

@@ -945,9 +945,12 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
     return CUNET_OK;
 }
 
-int cunet_augment_batch(const void* table, int n, float* out, int res, void* stream) {
-    if (!table || !out || n < 1 || res < 1) return fail(CUNET_ERR_INVALID, "bad argument");
-    HIPCHK(launch_augment(reinterpret_cast<const AugSample*>(table), n, out, res, (hipStream_t)stream));
+int cunet_augment_batch(const void* table_dev, const void* table_host, int n, float* out, int res, void* stream) {
+    if (!table_dev || !table_host || !out || n < 1 || res < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    const hipError_t e = launch_augment(reinterpret_cast<const AugSample*>(table_dev), reinterpret_cast<const AugSample*>(table_host), n, out, res,
+                                        (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(CUNET_ERR_INVALID, "cunet_augment_batch: inconsistent sample record (sizes / scratch pointers)");
+    HIPCHK(e);
     return CUNET_OK;
 }
 

@@ -239,16 +239,19 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
 int cunet_set_planner_option(const char* name, int value);
 
 /* training-sample preparation on the device: replaces the per-sample CPU work of data/mpii_for_mpii_22.py:127-141 between the
- * decoded image and the network input -- horizontal flip (pylib/HumanAug.py:267-271), per-channel colour gain with clamp
- * to [0, 1], and HumanAug.crop (:115-172: window on a zero canvas, rotation about the canvas centre, resize to res x res).
- *   table: DEVICE array of n records {const float* src (3 x sh x sw fp32 CHW in [0,1]); int32 sh, sw, ulx, uly, win_w,
- *          win_h, pad, k, cw, ch, flip, rotated; double sf, cs, sn; float gain[3], pad} (96 bytes): the crop geometry
+ * decoded image and the network input -- horizontal flip (pylib/HumanAug.py:267-271), per-channel colour gain with clamp to
+ * [0, 1], and HumanAug.crop (:115-172) INCLUDING its resamplers: scipy.misc.imresize / imrotate were 8-bit PIL operations behind
+ * scipy's byte-scale (a contrast stretch by the minimum / maximum of the array), so crop()'s stages are kept as stages with uint8
+ * intermediates and PIL's arithmetic restated exactly (triangle-filter resize in 22-bit fixed point, bilinear rotate truncated to
+ * uint8): outputs are bit-identical to the reference function executed over PIL (tests/golden/G16_crop.npz).
+ *   table_dev / table_host: the same array of n 192-byte records, on the device (read by the kernels) and on the host (read
+ *          for launch geometry): {const float* src (3 x sh x sw fp32 CHW in [0,1]); uint32* mm (5 words scratch); uint8* i8, t1,
+ *          i1 (pre-shrink intermediates or NULL), c8 (canvas ch x cw x 3), r8 (rotated: win_h x win_w x 3, else NULL),
+ *          t2 (win_h x res x 3), o8 (res x res x 3); double rm[6] (PIL's rotate matrix); int32 sh, sw, sh1, sw1, ulx, uly, cw,
+ *          ch, win_w, win_h, pad, flip, rotated, pre; float gain[3]; int32 pad}.  All scratch is caller-owned; the crop geometry
  *          is computed by the caller exactly as the reference computes it (cu_net_amd/augment.py::_geometry)
- *   out:   n x 3 x res x res fp32
- * One bilinear sample (k x k when the reference would shrink the image first) per output pixel at the composed
- * coordinate; the reference's own resamplers (scipy.misc.imresize / imrotate) are gone from scipy, so pixel values are
- * defined by oracle/augment_ref.py, not by the reference (geometry, flip and colour ARE pinned to it). */
-int cunet_augment_batch(const void* table, int n, float* out, int res, void* stream);
+ *   out:   n x 3 x res x res fp32 (uint8 / 255, utils/imutils.py:31-36) */
+int cunet_augment_batch(const void* table_dev, const void* table_host, int n, float* out, int res, void* stream);
 
 /* ---- introspection for tests ------------------------------------------------------------------
  * byte offset inside the workspace of a named tensor's activation (which=0) or gradient (which=1);

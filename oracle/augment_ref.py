@@ -6,13 +6,13 @@ Restates, in numpy, the per-sample work of the reference's data loader between "
     pylib/HumanAug.py:115-172          crop (window of the source image on a zero canvas, rotation, resize to res x res)
     pylib/HumanAug.py:234-271          shufflelr / fliplr
 
-Pinning (tools/gen_golden.py --only augment, tests/golden/G15_augment.npz): the transform functions, shufflelr / fliplr and
-the WINDOW EXTRACTION of crop (ul, br, pad and the zero-padded canvas handed to the resampler) are checked bit-for-bit
-against the reference's own functions, compiled from pylib/HumanAug.py's AST and executed.  The two resamplers the
-reference calls -- scipy.misc.imrotate and scipy.misc.imresize -- no longer exist (scipy >= 1.3) and went through an
-8-bit PIL image with a data-dependent contrast stretch (scipy.misc.bytescale): that part is PARITY-UNPINNED.  Here, and
-in the HIP kernel, the canvas -> network-input map is ONE bilinear sample (pixel centres at half-integers, the PIL
-convention) at the composition of the resize and the rotation about the canvas centre; no 8-bit round trip.
+Pinning (tools/gen_golden.py --only augment): G15_augment.npz holds the transform functions, shufflelr / fliplr and the WINDOW
+EXTRACTION of crop (ul, br, pad, the zero-padded canvas) checked bit-for-bit against the reference's own functions compiled from
+pylib/HumanAug.py's AST; G16_crop.npz holds whole crop() outputs of the EXECUTED reference function with its two removed
+resamplers (scipy.misc.imresize / imrotate) rebuilt over the installed PIL exactly as scipy <= 1.2 wrapped it (byte-scale ->
+Image.resize / Image.rotate(BILINEAR) -> uint8 array), and `crop` below -- a restatement of the PIL algorithms, no PIL import --
+equals it bit for bit.  What "the reference" is for these pixels is therefore: reference code + scipy 1.x wrapper semantics + the
+PIL of this image (12.2); Pillow's 8-bit resize / rotate arithmetic has been stable since 4.x but is not versioned against here.
 """
 from __future__ import annotations
 
@@ -113,52 +113,194 @@ def crop_canvas(img_hwc, center, scale, rot, res, size):
     return new_img
 
 
-def augment_sample(img_chw, center, scale, rot=0.0, flip=False, gain=(1.0, 1.0, 1.0), res=256, size=200):
-    """C x H x W float image in [0, 1] -> C x res x res float32 network input.
+# ---- the reference's resamplers, restated ---------------------------------------------------------------------------------
+# crop() ends in scipy.misc.imresize and, for rot != 0, scipy.misc.imrotate (pylib/HumanAug.py:128,167,173).  Both were thin
+# wrappers (scipy <= 1.2, scipy/misc/pilutil.py): toimage(arr) -- which BYTE-SCALES a float array with a data-dependent contrast
+# stretch, (x - min) * 255 / (max - min) + 0.5 truncated to uint8 over the WHOLE array -- then PIL's Image.resize / Image.rotate
+# with resample = BILINEAR, then back to a uint8 array.  scipy.misc is gone, PIL is not: tools/gen_golden.py rebuilds the two
+# wrappers over the installed PIL, EXECUTES the reference's crop() with them and pins the functions below bit-for-bit (G16).
+# The PIL algorithms restated here (Pillow src/libImaging/Resample.c, Geometry.c):
+#   resize BILINEAR on 8-bit images: separable triangle filter, support = max(1, in/out) input pixels around the output pixel's
+#     centre (an antialiasing filter when shrinking), weights normalised, converted to 22-bit fixed point, horizontal pass then
+#     vertical pass with a uint8 intermediate image, each output = clip8((2^21 + sum coeff * pixel) >> 22);
+#   rotate BILINEAR: inverse affine map about the image centre (matrix entries rounded to 15 decimals), 2 x 2 bilinear
+#     interpolation in double with edge clamping, TRUNCATED to uint8, zero where the source position is outside the image.
+PIL_PRECISION_BITS = 32 - 8 - 2
 
-    Order of the reference (data/mpii_for_mpii_22.py:127-141): flip (the CALLER also flips center[0] and the points, as the
-    reference does), per-channel gain + clamp, crop.  The crop is one bilinear sample per output pixel: output pixel centre
-    -> window coordinates by the resize (u = (ox + 0.5) * w / res - 0.5), rotation by `rot` degrees about the centre of the
-    padded canvas (PIL's rotate: destination -> source with angle -rot), + ul -> source image; zero outside the image.
-    With scale * size / res >= 2 the reference shrinks the image first: here the footprint is then averaged over k x k
-    sub-samples, k = floor(scale * size / res)."""
-    img = np.asarray(img_chw, dtype=np.float64)
-    c, ht, wd = img.shape
+
+def bytescale(data):
+    """scipy.misc.bytescale(data) with its defaults (cmin = data.min(), cmax = data.max(), low = 0, high = 255)."""
+    data = np.asarray(data)
+    if data.dtype == np.uint8:
+        return data
+    cmin, cmax = data.min(), data.max()
+    cscale = cmax - cmin
+    if cscale == 0:
+        cscale = 1
+    scale = float(255) / cscale
+    bytedata = (data - cmin) * scale + 0
+    return (bytedata.clip(0, 255) + 0.5).astype(np.uint8)
+
+
+def _pil_coeffs(in_size, out_size):
+    """Pillow precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle) filter over the whole input range."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    bounds, coeffs = [], []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = []
+        for x in range(xmax):
+            t = abs((x + xmin - center + 0.5) * ss)
+            w.append(1.0 - t if t < 1.0 else 0.0)
+        ww = sum(w)
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        bounds.append((xmin, xmax))
+        coeffs.append(np.array([int(0.5 + v * (1 << PIL_PRECISION_BITS)) for v in w], dtype=np.int64))
+    return bounds, coeffs
+
+
+def _pil_resample_axis1(img, out_size):
+    """One pass along axis 1 of an H x W x C uint8 image."""
+    h, w, c = img.shape
+    bounds, coeffs = _pil_coeffs(w, out_size)
+    out = np.zeros((h, out_size, c), dtype=np.uint8)
+    src = img.astype(np.int64)
+    for xx in range(out_size):
+        xmin, n = bounds[xx]
+        ss = (1 << (PIL_PRECISION_BITS - 1)) + (src[:, xmin:xmin + n, :] * coeffs[xx][None, :, None]).sum(1)
+        out[:, xx, :] = np.clip(ss >> PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_resize_bilinear(img_u8, out_w, out_h):
+    """Image.resize((out_w, out_h), BILINEAR) of an H x W x C uint8 image (identity size: a copy)."""
+    img = np.asarray(img_u8)
+    if out_w != img.shape[1]:
+        img = _pil_resample_axis1(img, out_w)
+    if out_h != img.shape[0]:
+        img = _pil_resample_axis1(img.transpose(1, 0, 2), out_h).transpose(1, 0, 2)
+    return np.ascontiguousarray(img)
+
+
+def pil_rotate_matrix(w, h, angle_deg):
+    """The inverse affine map of Image.rotate(angle) (expand = False, centre = image centre): destination pixel centre
+    -> source position, [a, b, c, d, e, f] with x_src = a x + b y + c, y_src = d x + e y + f."""
+    import math
+    angle = angle_deg % 360.0
+    cx, cy = w / 2.0, h / 2.0
+    ang = -math.radians(angle)
+    m = [round(math.cos(ang), 15), round(math.sin(ang), 15), 0.0, round(-math.sin(ang), 15), round(math.cos(ang), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def pil_rotate_bilinear(img_u8, angle_deg):
+    """Image.rotate(angle, resample=BILINEAR) of an H x W x C uint8 image, angle not a multiple of 90 degrees."""
+    img = np.asarray(img_u8)
+    h, w = img.shape[:2]
+    if angle_deg % 360.0 == 0:
+        return img.copy()
+    assert (angle_deg % 90.0) != 0, 'PIL special-cases multiples of 90 degrees (transpose); the loader draws from N(0, 30)'
+    m = pil_rotate_matrix(w, h, angle_deg)
+    ys, xs = np.mgrid[0:h, 0:w]
+    xin = m[0] * (xs + 0.5) + m[1] * (ys + 0.5) + m[2]
+    yin = m[3] * (xs + 0.5) + m[4] * (ys + 0.5) + m[5]
+    inside = (xin >= 0) & (xin < w) & (yin >= 0) & (yin < h)
+    xi, yi = xin - 0.5, yin - 0.5
+    x, y = np.floor(xi).astype(np.int64), np.floor(yi).astype(np.int64)
+    dx, dy = xi - x, yi - y
+    x0, x1 = np.clip(x, 0, w - 1), np.clip(x + 1, 0, w - 1)
+    r0 = np.clip(y, 0, h - 1)
+    has2 = (y + 1 >= 0) & (y + 1 < h)
+    r1 = np.clip(y + 1, 0, h - 1)
+    f = img.astype(np.float64)
+    out = np.zeros_like(img)
+    for c in range(img.shape[2]):
+        ch = f[:, :, c]
+        a, b = ch[r0, x0], ch[r0, x1]
+        v1 = a + (b - a) * dx
+        a2, b2 = ch[r1, x0], ch[r1, x1]
+        v2 = np.where(has2, a2 + (b2 - a2) * dx, v1)
+        v = v1 + (v2 - v1) * dy
+        out[:, :, c] = np.where(inside, v, 0.0).astype(np.uint8)          # (UINT8) v: truncation
+    return out
+
+
+def imresize(arr, size):
+    """scipy.misc.imresize(arr, size, interp='bilinear') for H x W x 3 arrays; size: float fraction or (rows, cols)."""
+    u8 = bytescale(arr)
+    h, w = u8.shape[:2]
+    if isinstance(size, float):
+        out_w, out_h = int(w * size), int(h * size)
+    else:
+        out_h, out_w = size
+    return pil_resize_bilinear(u8, out_w, out_h)
+
+
+def imrotate(arr, angle):
+    """scipy.misc.imrotate(arr, angle, interp='bilinear') for H x W x 3 arrays."""
+    return pil_rotate_bilinear(bytescale(arr), angle)
+
+
+def crop(img_hwc, center, scale, rot, res, size):
+    """pylib/HumanAug.py:115-172 with the two resamplers above: H x W x 3 float image -> res x res x 3 uint8."""
+    img = np.asarray(img_hwc)
+    scale_factor = float(scale * size) / float(res)
+    if scale_factor < 2:
+        scale_factor = 1
+    else:
+        new_img_size = np.floor(max(img.shape[0], img.shape[1]) / scale_factor)
+        if new_img_size < 2:
+            return img
+        img = imresize(img, 1 / scale_factor)
+    center = np.asarray(center, dtype=float) / scale_factor
+    scale = scale / scale_factor
+    ul = np.array(transform_single_pts([0, 0], center, scale, 0, res, size, invert=1))
+    br = np.array(transform_single_pts([res, res], center, scale, 0, res, size, invert=1))
+    if scale_factor >= 2:
+        br = br - (br - ul - res)
+    pad = np.ceil(np.linalg.norm(br - ul) / 2 - float(br[1] - ul[1]) / 2).astype(int)
+    if not rot == 0:
+        ul = ul - pad
+        br = br + pad
+    new_img = np.zeros([br[1] - ul[1], br[0] - ul[0], img.shape[2]])
+    ht, wd = img.shape[0], img.shape[1]
+    new_x = max(0, -ul[0]), min(br[0], wd) - ul[0]
+    new_y = max(0, -ul[1]), min(br[1], ht) - ul[1]
+    old_x = max(0, ul[0]), min(wd, br[0])
+    old_y = max(0, ul[1]), min(ht, br[1])
+    new_img[new_y[0]:new_y[1], new_x[0]:new_x[1]] = img[old_y[0]:old_y[1], old_x[0]:old_x[1]]
+    if not rot == 0:
+        new_img = imrotate(new_img, rot)
+        new_img = new_img[pad:-pad, pad:-pad]
+    return imresize(new_img, (res, res))
+
+
+def augment_sample(img_chw, center, scale, rot=0.0, flip=False, gain=(1.0, 1.0, 1.0), res=256, size=200):
+    """C x H x W float32 image in [0, 1] -> C x res x res float32 network input, the reference's way
+    (data/mpii_for_mpii_22.py:127-141): flip (the CALLER also flips center[0] and the points), per-channel gain + clamp in
+    float32 (`img[c].mul_(gain).clamp_(0, 1)` on the torch tensor), crop() through the 8-bit resamplers, and
+    utils/imutils.py:31-36 `im_to_torch`: uint8 -> float32 / 255 (when the crop's maximum exceeds 1, i.e. always but for an
+    all-black / all-{0,1} crop, which the reference leaves unscaled and so does this)."""
+    img = np.array(img_chw, dtype=np.float32, copy=True)
     if flip:
         img = img[:, :, ::-1]
-    img = np.clip(img * np.asarray(gain, dtype=np.float64)[:, None, None], 0.0, 1.0)
-    sf_full = float(scale * size) / float(res)
-    ul, br, pad, sf = crop_geometry(center, scale, rot, res, size)
-    k = int(np.floor(sf_full)) if sf_full >= 2 else 1
-    cw, chh = br[0] - ul[0], br[1] - ul[1]                # padded canvas size (in pre-shrunk pixels)
-    win_w, win_h = cw - 2 * pad * (rot != 0), chh - 2 * pad * (rot != 0)
-    phi = -np.deg2rad(rot)                                # PIL rotate(): destination -> source with angle = -radians(rot)
-    cs, sn = np.cos(phi), np.sin(phi)
-    ccx, ccy = cw / 2.0, chh / 2.0
-    out = np.zeros((c, res, res), dtype=np.float64)
-    sub = (np.arange(k) + 0.5) / k - 0.5                  # sub-sample offsets in output-pixel units
-    for oy in range(res):
-        for ox in range(res):
-            acc = np.zeros(c)
-            for sy in sub:
-                for sx in sub:
-                    u = (ox + sx + 0.5) * win_w / res - 0.5 + (pad if rot != 0 else 0)
-                    v = (oy + sy + 0.5) * win_h / res - 0.5 + (pad if rot != 0 else 0)
-                    if rot != 0:                          # pixel-centre coordinates -> rotate about the canvas centre
-                        px, py = u + 0.5 - ccx, v + 0.5 - ccy
-                        u = cs * px + sn * py + ccx - 0.5
-                        v = -sn * px + cs * py + ccy - 0.5
-                    # canvas pixel centres -> pixel centres of the (un-shrunk) source image
-                    xs = (u + ul[0] + 0.5) * sf - 0.5
-                    ys = (v + ul[1] + 0.5) * sf - 0.5
-                    x0, y0 = int(np.floor(xs)), int(np.floor(ys))
-                    fx, fy = xs - x0, ys - y0
-                    for (yy, wy) in ((y0, 1 - fy), (y0 + 1, fy)):
-                        for (xx, wx) in ((x0, 1 - fx), (x0 + 1, fx)):
-                            if 0 <= yy < ht and 0 <= xx < wd:
-                                acc += wy * wx * img[:, yy, xx]
-            out[:, oy, ox] = acc / (k * k)
-    return out.astype(np.float32)
+    g = np.asarray(gain, dtype=np.float64).astype(np.float32)
+    img = np.clip(img * g[:, None, None], np.float32(0), np.float32(1)).astype(np.float32)
+    out = crop(np.transpose(img, (1, 2, 0)), center, scale, rot, res, size)
+    out = np.transpose(out, (2, 0, 1)).astype(np.float32)
+    if out.max() > 1:
+        out = out / np.float32(255)
+    return out
 
 
 # ---- the loader's per-sample recipe (data/mpii_for_mpii_22.py:86-145), one sample at a time on the CPU -------------------

@@ -118,15 +118,43 @@ def test_augment_geometry_matches_executed_reference():
         assert (ul[0], ul[1], br[0], br[1]) == (ulx, uly, brx, bry)
         canvas = A.crop_canvas(img, np.array([cx, cy]), s, 0, 256, 200)
         assert canvas.shape[:2] == (h, w) and abs(canvas.sum() - total) <= 1e-6 * total
-        ul2, br2, pad2, sf2, k2 = P._geometry(np.array([cx, cy]), s, 0, 256, 200)          # the product's host geometry
-        assert (ul2[0], ul2[1], br2[0], br2[1], k2) == (ulx, uly, brx, bry, 1)
-    # identity resample: a window of exactly res x res pixels, no rotation -> the canvas itself
-    small = np.random.RandomState(0).uniform(0, 1, size=(3, 40, 50))
+        ul2, br2, pad2, pre2 = P._geometry(np.array([cx, cy]), s, 0, 256, 200, img.shape[0], img.shape[1])      # the product's host geometry
+        assert (ul2[0], ul2[1], br2[0], br2[1], pre2) == (ulx, uly, brx, bry, None)
+    # identity resample: a window of exactly res x res pixels, no rotation -> the BYTE-SCALED canvas (scipy.misc.toimage), / 255
+    small = np.random.RandomState(0).uniform(0, 1, size=(3, 40, 50)).astype(np.float32)
     out = A.augment_sample(small, center=(25.0, 20.0), scale=32 / 200.0, rot=0, res=32, size=200)
     ul, br, _, _ = A.crop_geometry(np.array([25.0, 20.0]), 32 / 200.0, 0, 32, 200)
     assert tuple(br - ul) == (32, 32)
     canvas = A.crop_canvas(np.transpose(small, (1, 2, 0)), np.array([25.0, 20.0]), 32 / 200.0, 0, 32, 200)
-    assert np.allclose(out, np.transpose(canvas, (2, 0, 1)).astype(np.float32), atol=1e-7)
+    assert np.array_equal(out, np.transpose(A.bytescale(canvas), (2, 0, 1)).astype(np.float32) / np.float32(255))
+
+
+def test_crop_resamplers_match_executed_reference():
+    """G16: whole outputs of the reference's crop() executed with scipy.misc.imresize / imrotate rebuilt over PIL
+    (tools/gen_golden.py crop_parity) -- the oracle's numpy restatement of PIL's 8-bit resize / rotate reproduces every byte,
+    and the product's host-side geometry (window, pre-shrunk size, PIL rotate matrix) is the oracle's."""
+    from oracle import augment_ref as A
+    from cu_net_amd import augment as P
+    z = np.load(os.path.join(GOLDEN_DIR, 'G16_crop.npz'))
+    imgs = [(z[f'img/{i}'].astype(np.float32) / np.float32(255)) for i in range(2)]
+    seen_pre = seen_rot = 0
+    for k, (ii, cx, cy, s, r, flip, g0, g1, g2) in enumerate(z['cases']):
+        img = imgs[int(ii)]
+        out = A.augment_sample(img, np.array([cx, cy]), float(s), float(r), bool(flip), (g0, g1, g2))
+        assert np.array_equal(out, np.transpose(z[f'out/{k}'], (2, 0, 1)).astype(np.float32) / np.float32(255)), k
+        ul, br, pad, sf = A.crop_geometry(np.array([cx, cy]), float(s), float(r), 256, 200)
+        ul2, br2, pad2, pre2 = P._geometry(np.array([cx, cy]), float(s), float(r), 256, 200, img.shape[1], img.shape[2])
+        assert np.array_equal(ul, ul2) and np.array_equal(br, br2) and pad == pad2
+        if sf != 1:
+            assert pre2 == (int(img.shape[1] * (1 / sf)), int(img.shape[2] * (1 / sf)))
+            seen_pre += 1
+        else:
+            assert pre2 is None
+        if r != 0:
+            cw, ch = int(br[0] - ul[0]), int(br[1] - ul[1])
+            assert P._pil_rotate_matrix(cw, ch, float(r)) == A.pil_rotate_matrix(cw, ch, float(r))
+            seen_rot += 1
+    assert seen_pre >= 2 and seen_rot >= 3
 
 
 def test_train_sample_draws_follow_the_reference_order():

@@ -703,6 +703,134 @@ def augment_parity():
     print(f'G15: GetTransform / TransformPts ({len(cases)} cases), shufflelr, fliplr, crop windows ({len(crops)}): oracle == reference')
 
 
+class _ScipyMiscOverPIL:
+    """scipy.misc.{bytescale, toimage, fromimage, imresize, imrotate} as scipy <= 1.2 defined them (scipy/misc/pilutil.py), over
+    the installed PIL -- the module object the reference's `scipy.misc.imresize / imrotate` calls resolve to while its crop()
+    is executed for G16.  Restated for the array kinds crop() passes (H x W x 3 float64 / float32 / uint8)."""
+
+    @staticmethod
+    def bytescale(data, cmin=None, cmax=None, high=255, low=0):
+        if data.dtype == np.uint8:
+            return data
+        if cmin is None:
+            cmin = data.min()
+        if cmax is None:
+            cmax = data.max()
+        cscale = cmax - cmin
+        if cscale < 0:
+            raise ValueError('`cmax` should be larger than `cmin`.')
+        elif cscale == 0:
+            cscale = 1
+        scale = float(high - low) / cscale
+        bytedata = (data - cmin) * scale + low
+        return (bytedata.clip(low, high) + 0.5).astype(np.uint8)
+
+    @classmethod
+    def toimage(cls, arr):
+        from PIL import Image
+        data = np.asarray(arr)
+        shape = list(data.shape)
+        assert len(shape) == 3 and 3 in shape
+        ca = np.flatnonzero(np.asarray(shape) == 3)[0]
+        assert ca == 2, 'crop() hands H x W x 3 arrays over (first axis of length 3 is the channel axis)'
+        bytedata = cls.bytescale(data)
+        return Image.frombytes('RGB', (shape[1], shape[0]), bytedata.tobytes())
+
+    @staticmethod
+    def fromimage(im):
+        return np.array(im)
+
+    @classmethod
+    def imrotate(cls, arr, angle, interp='bilinear'):
+        from PIL import Image
+        assert interp == 'bilinear'
+        im = cls.toimage(np.asarray(arr))
+        im = im.rotate(angle, resample=Image.BILINEAR)
+        return cls.fromimage(im)
+
+    @classmethod
+    def imresize(cls, arr, size, interp='bilinear', mode=None):
+        from PIL import Image
+        assert interp == 'bilinear' and mode is None
+        im = cls.toimage(arr)
+        ts = type(size)
+        if np.issubdtype(ts, np.signedinteger):
+            percent = size / 100.0
+            size = tuple((np.array(im.size) * percent).astype(int))
+        elif np.issubdtype(type(size), np.floating):
+            size = tuple((np.array(im.size) * size).astype(int))
+        else:
+            size = (size[1], size[0])
+        imnew = im.resize(size, resample=Image.BILINEAR)
+        return cls.fromimage(imnew)
+
+
+def crop_parity():
+    """G16: whole outputs of the reference's crop() (pylib/HumanAug.py:115-172, compiled from the file's AST and EXECUTED) with
+    scipy.misc rebuilt over PIL as above -- up- and down-scaling windows, windows leaving the image, rotations, the pre-shrink
+    branch (scale * 200 / 256 >= 2) with and without rotation, float images that do and do not reach 1.0 (the byte-scale
+    contrast stretch) -- and the check that oracle/augment_ref.py::crop (pure numpy, no PIL) reproduces every byte."""
+    import ast, re
+    import PIL
+    from oracle import augment_ref as A
+    src = open(os.path.join(REF, 'pylib', 'HumanAug.py')).read()
+    src = re.sub(r"(?m)^(\s*)print (.+)$", r"\1print(\2)", src)
+    tree = ast.parse(src)
+    want = ('GetTransform', 'TransformSinglePts', 'crop')
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(keep) == len(want)
+    fake_scipy = types.ModuleType('scipy_over_pil')
+    fake_scipy.misc = _ScipyMiscOverPIL
+    ha = types.ModuleType('ref_humanaug_crop')
+    ha.__dict__.update(np=np, torch=torch, scipy=fake_scipy)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), '<reference pylib/HumanAug.py crop>', 'exec'), ha.__dict__)
+    rng = np.random.RandomState(16)
+    # two source images, C x H x W float32 as load_image gives them (k / 255 values): smooth structure + texture
+    def make(h, w, top):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([0.5 + 0.5 * np.sin(xx / 17.0 + c) * np.cos(yy / 23.0 - c) for c in range(3)])
+        tex = rng.uniform(-0.2, 0.2, size=(3, h, w))
+        img = np.clip((base + tex) * top, 0, 1)
+        return (np.round(img * 255) / 255).astype(np.float32)
+    imgs = [make(240, 320, 1.0), make(200, 150, 0.8)]
+    cases = [   # image, centre, scale, rot, flip, gains
+        (0, (160.0, 120.0), 0.90, 0.0, False, (1.0, 1.0, 1.0)),      # up-scaling window inside the image
+        (0, (150.5, 99.25), 1.50, 0.0, True, (1.3, 0.7, 1.1)),       # down-scaling (antialiasing filter), gains clamp at 1
+        (0, (20.0, 30.0), 1.10, 0.0, False, (0.8, 0.9, 0.7)),        # window leaves the image (zero padding), maximum < 1
+        (1, (75.0, 100.0), 0.70, 0.0, False, (0.9, 0.9, 0.9)),       # interior window of a dim image: minimum > 0 (black level shifts)
+        (0, (160.0, 120.0), 1.00, 17.5, False, (1.0, 1.2, 0.9)),     # rotation
+        (1, (60.0, 90.0), 1.28, -33.0, True, (1.1, 1.0, 0.6)),
+        (0, (170.0, 110.0), 2.70, 0.0, False, (1.0, 1.0, 1.0)),      # pre-shrink branch
+        (0, (150.0, 100.0), 3.10, 21.0, True, (1.2, 0.8, 1.0)),      # pre-shrink + rotation
+    ]
+    fx = {'pil_version': np.array(PIL.__version__)}
+    for i, im in enumerate(imgs):
+        fx[f'img/{i}'] = np.round(im * 255).astype(np.uint8)         # stored as the bytes they were made from
+    recs = []
+    for k, (ii, c, s, r, flip, gains) in enumerate(cases):
+        img = torch.from_numpy(imgs[ii].copy())
+        cc = np.array(c, dtype=np.float64)
+        if flip:                                                      # data/mpii_for_mpii_22.py:128-131
+            img = torch.from_numpy(np.ascontiguousarray(img.numpy()[:, :, ::-1]))
+            cc[0] = img.size(2) - cc[0]
+        for ch in range(3):                                           # :134-136
+            img[ch, :, :].mul_(gains[ch]).clamp_(0, 1)
+        hwc = np.transpose(img.numpy(), (1, 2, 0))                    # utils/imutils.py im_to_numpy
+        ref_out = ha.crop(hwc, cc, s, r, 256, 200)
+        mine = A.crop(hwc, cc, s, r, 256, 200)
+        assert ref_out.dtype == np.uint8 and ref_out.shape == (256, 256, 3)
+        if not np.array_equal(ref_out, mine):
+            d = np.abs(ref_out.astype(int) - mine.astype(int))
+            raise SystemExit(f'ORACLE MISMATCH at G16 case {k}: {int((d > 0).sum())} bytes differ, max {d.max()}')
+        full = A.augment_sample(imgs[ii], cc, s, r, flip, gains)
+        assert np.array_equal(full, np.transpose(ref_out, (2, 0, 1)).astype(np.float32) / np.float32(255))
+        fx[f'out/{k}'] = ref_out
+        recs.append((ii, cc[0], cc[1], s, r, float(flip), gains[0], gains[1], gains[2]))
+    fx['cases'] = np.array(recs, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'G16_crop.npz'), **fx)
+    print(f'G16: crop() through the PIL-backed resamplers (PIL {PIL.__version__}), {len(cases)} cases: oracle == executed reference, byte for byte')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -716,7 +844,7 @@ def main():
             ref = load_reference_models()
             {'big': big_configs, 'binop': lambda r: binop_quaninput_parity(r, load_reference_quantize())}[sys.argv[2]](ref)
             return
-        {'decode': decode_parity, 'tta': tta_accuracy_parity, 'targets': target_synthesis_parity, 'augment': augment_parity}[sys.argv[2]]()
+        {'decode': decode_parity, 'tta': tta_accuracy_parity, 'targets': target_synthesis_parity, 'augment': augment_parity, 'crop': crop_parity}[sys.argv[2]]()
         return
     ref = load_reference_models()
     tiny = dict(neck_size=2, growth_rate=4, init_chan_num=8)
@@ -739,6 +867,7 @@ def main():
     tta_accuracy_parity()
     target_synthesis_parity()
     augment_parity()
+    crop_parity()
 
 
 if __name__ == '__main__':
