@@ -145,6 +145,8 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "wgrad3_max_splits_bf16") o.wgrad3_max_splits_bf16 = value;
     else if (n == "wgrad3_stem") o.wgrad3_stem = value;
     else if (n == "conv3x3_ring_min_rows") o.conv3x3_ring_min_rows = value;
+    else if (n == "wgrad_fork_group") o.wgrad_fork_group = value;
+    else if (n == "fwd_fork_min_w") o.fwd_fork_min_w = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -457,20 +459,14 @@ static int reduce_wgrad3(cunet_plan* h, int first, int count, int max_numel, hip
     return CUNET_OK;
 }
 
-// Backward of one node: data gradient (+ReLU mask + BN reductions), weight gradient, BN apply.
-static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s) {
+// Backward of one node.  BWD_MAIN: what the rest of backward waits for -- data gradient (+ReLU mask + BN reductions), pool /
+// stem BN-pool backward -- on `s`.  BWD_WGRAD: the weight gradient, which only reads d(loss)/d(out) and activations and only
+// writes dW (or partial tiles), on `ws`: the caller decides where that is and when it may start (fork_wgrads).
+enum { BWD_MAIN = 1, BWD_WGRAD = 2 };
+static bool node_has_wgrad(const Node& n) { return n.type == N_CONV || n.type == N_STEM_CONV; }
+
+static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s, hipStream_t ws, int parts) {
     Exec E(h);
-    // weight gradients only read d(loss)/d(out) and activations and only write dW: they fork to the side stream
-    hipStream_t ws = s;
-    static const int fork_after = tune_int("CUNET_FORK_AFTER", 0);
-    const bool forks = h->use_side && h->side && (n.type == N_CONV || n.type == N_STEM_CONV);
-    if (forks) {
-        if (!(fork_after && n.type == N_CONV)) {
-            HIPCHK(hipEventRecord(h->fork_ev[node_index], s));
-            HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[node_index], 0));
-        }
-        ws = h->side;
-    }
     Plan& P = h->plan;
     const int cus = h->num_cus;
     float* dz = n.dz >= 0 ? E.wsf + n.dz : nullptr;
@@ -479,7 +475,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         const ConvInfo& c = P.convs[n.conv];
         const BnInfo& b = P.bns[n.bn];
         double* red = E.zero + n.red;
-        {   // data gradient + ReLU mask + BN reductions
+        if (parts & BWD_MAIN) {   // data gradient + ReLU mask + BN reductions
             ConvArgs a{};
             a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
             a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
@@ -512,11 +508,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
                 PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
                      launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
         }
-        if (forks && fork_after) {
-            HIPCHK(hipEventRecord(h->fork_ev[node_index], s));
-            HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[node_index], 0));
-        }
-        {   // weight gradient
+        if (parts & BWD_WGRAD) {   // weight gradient
             WgradArgs w{};
             w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
             w.nseg = E.fill_segs(n, w.seg); w.Ccat = n.Ccat;
@@ -540,6 +532,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             }
         }
     } else if (n.type == N_POOL) {
+        if (!(parts & BWD_MAIN)) return CUNET_OK;
         const int tin = n.segs[0].tensor;
         const TensorInfo& ti = P.tensors[tin];
         PoolArgs a{};
@@ -548,6 +541,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
         PROF(PC_POOLB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_pool_bwd(a, cus, s));
     } else if (n.type == N_STEM_BNPOOL) {
+        if (!(parts & BWD_MAIN)) return CUNET_OK;
         const int tin = n.segs[0].tensor;
         const TensorInfo& ti = P.tensors[tin];
         const BnInfo& b = P.bns[n.bn];
@@ -561,6 +555,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
         PROF(PC_STEMBPB, 0.0, 4.0 * 1.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 0, nullptr, nullptr, cus, s));
         PROF(PC_STEMBPB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
     } else {  // N_STEM_CONV: weight gradient only (the image needs no gradient)
+        if (!(parts & BWD_WGRAD)) return CUNET_OK;
         const ConvInfo& c = P.convs[n.conv];
         WgradArgs w{};
         w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
@@ -575,6 +570,27 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s)
             PROF_ON(ws, PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout, launch_wgrad(w, WGL_STEM, cus, ws));
         }
     }
+    return CUNET_OK;
+}
+
+// Weight gradients of the nodes in `pending` (their d(loss)/d(out) has been enqueued on `s`): ONE event on `s`, the side stream
+// waits for it, then all of them go to the side stream.  An event record is a marker packet in the caller's queue and the kernel
+// behind it waits for the marker to retire: 6-7 us of bubble on the critical path per record (rocprofv3 traces of round 3: 0.7 ms
+// per CU-Net-2 step and 3.2 ms per CU-Net-8 bf16 step when every node recorded its own) -- hence groups.
+static int fork_wgrads(cunet_plan* h, std::vector<int>& pending, hipStream_t s) {
+    if (pending.empty()) return CUNET_OK;
+    Plan& P = h->plan;
+    hipStream_t ws = s;
+    if (h->use_side && h->side) {
+        HIPCHK(hipEventRecord(h->fork_ev[pending.back()], s));
+        HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[pending.back()], 0));
+        ws = h->side;
+    }
+    for (int k : pending) {
+        const int rc = bwd_node(h, P.nodes[k], k, s, ws, BWD_WGRAD);
+        if (rc != CUNET_OK) return rc;
+    }
+    pending.clear();
     return CUNET_OK;
 }
 
@@ -613,7 +629,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
         }
         // fork: the skip adapter of a down block is consumed only on the way up (models/cu_net.py:257,267),
         // so it runs on the side stream next to the ahead adapter / pool / next block
-        const bool forked = fork_fwd && n.type == N_CONV && n.name.find(".adapters_skip.") != std::string::npos;
+        const bool forked = fork_fwd && n.type == N_CONV && o.W >= P.opts.fwd_fork_min_w && n.name.find(".adapters_skip.") != std::string::npos;
         if (forked) {
             HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
             HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[ni], 0));
@@ -864,9 +880,13 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
     int bucket_hi = (int)P.nodes.size();                       // nodes [k+1, bucket_hi) belong to cur_bucket
+    std::vector<int> pending;                                  // nodes whose weight gradient has not been forked yet
+    const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, P.opts.wgrad_fork_group) : 1;
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
+            const int rcf = fork_wgrads(h, pending, s);
+            if (rcf != CUNET_OK) return rcf;
             const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket],
                                           (h->use_side && h->side) ? h->side : s);
             if (rcr != CUNET_OK) return rcr;
@@ -884,10 +904,19 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             const int rcg = gather_tensor_grad(h, n.out, -1, s);
             if (rcg != CUNET_OK) return rcg;
         }
-        const int rc = bwd_node(h, n, k, s);
+        if (node_has_wgrad(n)) {           // (its d(loss)/d(out) is enqueued: the weight gradient may start once that has run)
+            pending.push_back(k);
+            if (pending.size() >= group || k == 0) {
+                const int rcf = fork_wgrads(h, pending, s);
+                if (rcf != CUNET_OK) return rcf;
+            }
+        }
+        const int rc = bwd_node(h, n, k, s, s, BWD_MAIN);
         if (rc != CUNET_OK) return rc;
     }
     {
+        const int rcf = fork_wgrads(h, pending, s);
+        if (rcf != CUNET_OK) return rcf;
         if (cur_bucket >= 0) {
             const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket],
                                           (h->use_side && h->side) ? h->side : s);
@@ -1016,7 +1045,13 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (n.red >= 0)
         HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * n.red, 0, (size_t)16 * n.Ccat, s));
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
-    const int rc = bwd_node(h, n, node, s);
+    {
+        std::vector<int> one;
+        if (node_has_wgrad(n)) one.push_back(node);
+        const int rcf = fork_wgrads(h, one, s);
+        if (rcf != CUNET_OK) return rcf;
+    }
+    const int rc = bwd_node(h, n, node, s, s, BWD_MAIN);
     if (rc != CUNET_OK) return rc;
     if (n.wg3_S > 0) {
         const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, (int)P.wg3_numel(n), (h->use_side && h->side) ? h->side : s);

@@ -235,6 +235,10 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        allows (128 output channels, output width a multiple of 64); 0: per-wave atomic kernel
  *   "conv3x3_ring_min_rows"  the 3x3 forward of 64-pixel-wide levels runs on the LDS row ring when the batch has at least this many
  *                        image rows N*H (default 512 = two per CU; tests lower it to cover the kernel at small batches)
+ *   "wgrad_fork_group"   backward hands the weight gradients to the internal side stream in groups of this many nodes (default 4):
+ *                        every hand-over is an event record on the caller's stream, i.e. a marker packet the next kernel waits
+ *                        behind (6-7 us of bubble on the critical path each); 1 = one hand-over per node
+ *   "fwd_fork_min_w"     forward: the down blocks' skip adapters run on the side stream at levels at least this wide (default 0: all)
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 

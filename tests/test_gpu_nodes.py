@@ -299,10 +299,10 @@ def _check_composition(cfg, st, x, target, check_params=False, quan_bits_w=0, qu
     off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
     pbad, bad_fwd = [], []
 
-    def pcheck(label, name, ref):
+    def pcheck(label, name, ref, **tol):
         if check_params:
             o, nmel, shape = off[name]
-            _close(label, net._grad_arena[o:o + nmel].view(shape), ref, pbad)
+            _close(label, net._grad_arena[o:o + nmel].view(shape), ref, pbad, **tol)
 
     def add(nm, g):
         expect[nm] = g if nm not in expect else expect[nm] + g
@@ -339,7 +339,10 @@ def _check_composition(cfg, st, x, target, check_params=False, quan_bits_w=0, qu
             for l, s in zip(leaves, nd['segs']):
                 add(T[s['t']]['name'], l.grad)
             if check_params:
-                pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad)
+                # (at a QuanInput site the weight gradient contracts dY with the QUANTISED activation: an activation on a quantiser
+                # boundary that lands on the other 2^-7 level moves a dW element by dy / 128 -- 6e-4 of max|dW| measured)
+                site_tol = dict(rtol=2e-3, frac=5e-3) if (quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0)) else {}
+                pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad, **site_tol)
                 pcheck(f'{nd["name"]} dgamma', nd['bn'] + '.weight', gamma.grad)
                 pcheck(f'{nd["name"]} dbeta', nd['bn'] + '.bias', beta.grad)
         elif op == 'pool':
