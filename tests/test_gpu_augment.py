@@ -47,7 +47,7 @@ def test_augment_batch_matches_oracle():
         assert np.array_equal(out[i], ref), (i, int((out[i] != ref).sum()), float(np.abs(out[i] - ref).max()) * 255)
         assert out[i].max() <= 1.0 and out[i].min() >= 0.0
     assert out[0].max() > 0.3 and (out[1] == 0).any()          # sample 1 hangs over the border: zero canvas shows
-    assert out[4].min() == 0.0 and out[4].max() == 1.0         # interior window of the dim image: stretched to the full range
+    assert out[4].min() == 0.0 and out[4].max() > 0.95         # interior window of the dim image (values 0.1 .. 0.7): stretched to the full range
 
 
 def test_augment_identity_window_is_the_byte_scaled_window():
