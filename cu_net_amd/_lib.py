@@ -64,6 +64,7 @@ def lib():
         'cunet_set_popcount_live': (i32, [vp, i32]),
         'cunet_forward': (i32, [vp, vp, C.POINTER(vp), i32, vp]),
         'cunet_loss_mse': (i32, [vp, vp, vp, vp]),
+        'cunet_loss_mse_fused': (i32, [vp, vp, vp, vp]),
         'cunet_backward': (i32, [vp, C.POINTER(vp), vp]),
         'cunet_num_buckets': (i32, [vp]),
         'cunet_bucket_range': (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
@@ -103,7 +104,7 @@ def lib():
 EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set_planner_option', 'cunet_plan_destroy', 'cunet_state_count',
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind', 'cunet_set_quant_input', 'cunet_set_popcount_live',
-            'cunet_forward', 'cunet_loss_mse', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
+            'cunet_forward', 'cunet_loss_mse', 'cunet_loss_mse_fused', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_flip_merge', 'cunet_augment_batch', 'cunet_render_targets',
             'cunet_debug_tensor_offset', 'cunet_quant_prepare', 'cunet_quant_restore', 'cunet_quant_grad',
             'cunet_ternary_pack', 'cunet_ternary_conv', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',

@@ -58,14 +58,26 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
     if (active) {
-        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
-            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)row * C + 8 * g);
-            const float4 b = *reinterpret_cast<const float4*>(src + (size_t)row * C + 8 * g + 4);
-            const uint4 q = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
-            *reinterpret_cast<uint4*>(dst + (size_t)row * C + 8 * g) = q;
-            const float v[8] = {bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y), bf16_lo(q.z), bf16_hi(q.z), bf16_lo(q.w), bf16_hi(q.w)};
+        const long stride = (long)gridDim.x * rpi;
+        for (long row0 = (long)blockIdx.x * rpi + ry; row0 < rows; row0 += stride * 4) {      // four rows' loads in flight together
+            float4 va[4], vb[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += (double)v[e] * v[e]; }
+            for (int u = 0; u < 4; ++u) {
+                const long row = row0 + u * stride < rows ? row0 + u * stride : row0;
+                va[u] = ldg4(src + (size_t)row * C + 8 * g);
+                vb[u] = ldg4(src + (size_t)row * C + 8 * g + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long row = row0 + u * stride;
+                if (row >= rows) break;
+                const float4 a = va[u], b = vb[u];
+                const uint4 q = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+                *reinterpret_cast<uint4*>(dst + (size_t)row * C + 8 * g) = q;
+                const float v[8] = {bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y), bf16_lo(q.z), bf16_hi(q.z), bf16_lo(q.w), bf16_hi(q.w)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += (double)v[e] * v[e]; }
+            }
         }
     }
     if (ystats == nullptr) return;
@@ -90,7 +102,7 @@ hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long row
     if (g8 < 1 || g8 > 256 || C % 8) return hipErrorInvalidValue;
     const int rpi = 256 / g8;
     long gx = (rows + rpi - 1) / rpi;
-    if (gx > 8L * num_cus) gx = 8L * num_cus;
+    if (gx > 2L * num_cus) gx = 2L * num_cus;      // (every block ends in 2 * C fp64 atomics on the same addresses)
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)gx), dim3(256), (size_t)rpi * C * 16, s, src, (u16*)dst, ystats, rows, C);
     return hipGetLastError();
@@ -145,6 +157,8 @@ hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params
 // ---------------------------------------------------------------------------------------------
 // 2x2/2 max-pool over bf16 NHWC (the max of bf16 values is exact) + fp64 batch statistics of the pooled tensor when
 // ystats != null (training).  A thread owns 8 channels; 256 / (C/8) rows per block iteration.
+constexpr int B16_POOL_U = 4;
+
 __global__ __launch_bounds__(256) void pool_bf16_kernel(const u16* __restrict__ x, u16* __restrict__ y, double* ystats,
                                                          int N, int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,16 +175,31 @@ __global__ __launch_bounds__(256) void pool_bf16_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
     if (active) {
-        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
+        // B16_POOL_U output rows per thread and iteration with all their loads requested up front; a few hundred fat blocks (see
+        // pool_fwd_kernel): at 64 x 64 and batch 24 the thin version was 1536 blocks x 256 fp64 atomics on the same 256 addresses
+        const long stride = (long)gridDim.x * rpi;
+        for (long row0 = (long)blockIdx.x * rpi + ry; row0 < rows; row0 += stride * B16_POOL_U) {
+          uint4 vv[B16_POOL_U][4];
+#pragma unroll
+          for (int u = 0; u < B16_POOL_U; ++u) {
+            const long row = row0 + u * stride < rows ? row0 + u * stride : row0;
             const int ni = (int)(row / (Ho * Wo));
             const int rm = (int)(row - (long)ni * Ho * Wo);
             const int yo = rm / Wo, xo = rm - yo * Wo;
             const size_t m00 = ((size_t)ni * H + 2 * yo) * W + 2 * xo;
-            const size_t off[4] = {m00, m00 + 1, m00 + W, m00 + W + 1};
+            vv[u][0] = ldg16(x + m00 * C + 8 * g);
+            vv[u][1] = ldg16(x + (m00 + 1) * C + 8 * g);
+            vv[u][2] = ldg16(x + (m00 + W) * C + 8 * g);
+            vv[u][3] = ldg16(x + (m00 + W + 1) * C + 8 * g);
+          }
+#pragma unroll
+          for (int u = 0; u < B16_POOL_U; ++u) {
+            const long row = row0 + u * stride;
+            if (row >= rows) break;
             float best[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint4 v = ldg16(x + off[k] * C + 8 * g);
+                const uint4 v = vv[u][k];
                 const unsigned q[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -183,6 +212,7 @@ __global__ __launch_bounds__(256) void pool_bf16_kernel(const u16* __restrict__ 
                 make_uint4(pack_bf16(best[0], best[1]), pack_bf16(best[2], best[3]), pack_bf16(best[4], best[5]), pack_bf16(best[6], best[7]));
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] += best[e]; s2[e] += (double)best[e] * best[e]; }
+          }
         }
     }
     if (ystats == nullptr) return;
@@ -207,8 +237,8 @@ hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H
     if (g8 < 1 || g8 > 256 || C % 8) return hipErrorInvalidValue;
     const int rpi = 256 / g8;
     const long rows = (long)N * (H / 2) * (W / 2);
-    long gx = (rows + rpi - 1) / rpi;
-    if (gx > 8L * num_cus) gx = 8L * num_cus;
+    long gx = (rows + (long)rpi * B16_POOL_U - 1) / ((long)rpi * B16_POOL_U);
+    if (gx > 2L * num_cus) gx = 2L * num_cus;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(pool_bf16_kernel, dim3((unsigned)gx), dim3(256), (size_t)rpi * C * 16, s, (const u16*)x, (u16*)y, ystats, N, H, W, C);
     return hipGetLastError();
@@ -376,7 +406,32 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + nt * 32 + li;
             float s1 = 0.f, s2 = 0.f;
-            if (col < p.Nout) {
+            if (OUTF32 && p.mse_tgt != nullptr) {           // heat-map head with the pixelwise MSE fused in (see conv_kernel)
+                const float ginv = (float)(2.0 * p.mse_inv);
+                const bool colok = col < p.Nout;
+                const bool padcol = !colok && col < p.ldy;
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    tv[r] = ldg1(p.mse_tgt + (size_t)mm * p.ldy + (colok ? col : 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (colok) {
+                        const float v = acc[nt][r];
+                        p.y[(size_t)mm * p.ldy + col] = v;
+                        const float d = v - tv[r];
+                        if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, d * ginv);
+                        else p.mse_dout[(size_t)mm * p.ldy + col] = d * ginv;
+                        s1 = fmaf(d, d, s1);
+                    } else if (padcol) {
+                        if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, 0.f);
+                        else p.mse_dout[(size_t)mm * p.ldy + col] = 0.f;
+                    }
+                }
+            } else if (col < p.Nout) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -396,6 +451,16 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
         }
     }
 
+    if (OUTF32 && p.mse_tgt != nullptr) {               // fused MSE: the block's sum of squared errors -> one fp64 atomic
+        double t = 0.0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t += dsum[nt];
+        for (int o = 32; o > 0; o >>= 1) t += shfl_xor_d(t, o);
+        if (lane == 0) atomicAdd(&redbuf[0], t);
+        __syncthreads();
+        if (tid == 0) atomic_add_f64(p.mse_acc, redbuf[0] * p.mse_inv);
+        return;
+    }
     // ---- batch statistics of the output (training): lanes (l, l+32) -> waves through LDS -> one fp64 atomic per channel per block
     if (p.ystats != nullptr && !OUTF32) {
         double a1[NT], a2[NT];

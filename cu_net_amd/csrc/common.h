@@ -71,6 +71,13 @@ struct ConvArgs {
     int any_ups;           // some segment is read through the nearest-upsample map
     int xcd_gx, xcd_gy;    // > 0: the grid is 1-D (8 * ceil(gx / 8) * gy blocks) and decoded so that the gy column-slice blocks of a row
                            // block are consecutive workgroups of ONE XCD (round-robin dispatch: id % 8): they share A through its L2
+    // ---- fused pixelwise MSE of a heat-map head (EP_FWD, cu-net.py:175-178): with mse_tgt != null the epilogue also writes
+    //      d(loss)/d(out) = 2 (out - target) / numel and adds sum((out - target)^2) / numel to *mse_acc
+    const float* mse_tgt;  // target [M][ldy] (NHWC like y)
+    float* mse_dout;       // d(loss)/d(out) [M][ldy], fp32 or (mse_gbf16) bf16; pad columns Nout..ldy-1 are zeroed
+    double* mse_acc;
+    double mse_inv;        // 1 / (M * Nout)
+    int mse_gbf16;
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
                            // planner option conv3x3_ring_min_rows; 0 = the default 512)
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,

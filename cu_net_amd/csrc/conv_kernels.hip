@@ -387,7 +387,35 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             const int col = n0 + nt * 32 + li;
             const bool colok = col < p.Nout;
             float s1 = 0.f, s2 = 0.f;
-            if (EP == EP_FWD) {
+            if (EP == EP_FWD && p.mse_tgt != nullptr) {
+                // heat-map head with the pixelwise MSE fused in (uniform branch): the target values are requested first
+                const float ginv = (float)(2.0 * p.mse_inv);
+                const bool padcol = !colok && col < p.ldy;      // pad columns of d(loss)/d(out) must read as zero downstream
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int mq = (FAST || mm < p.M) ? mm : p.M - 1;
+                    tv[r] = ldg1(p.mse_tgt + (size_t)mq * p.ldy + (colok ? col : 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (FAST || mm < p.M) {
+                        if (colok) {
+                            const float v = acc[nt][r];
+                            p.y[(size_t)mm * p.ldy + col] = v;
+                            const float d = v - tv[r];
+                            if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, d * ginv);
+                            else p.mse_dout[(size_t)mm * p.ldy + col] = d * ginv;
+                            s1 = fmaf(d, d, s1);
+                        } else if (padcol) {
+                            if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, 0.f);
+                            else p.mse_dout[(size_t)mm * p.ldy + col] = 0.f;
+                        }
+                    }
+                }
+            } else if (EP == EP_FWD) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -426,6 +454,16 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     }
     }
 
+    if (EP == EP_FWD && p.mse_tgt != nullptr) {      // fused MSE: sum of squared errors of the block -> one fp64 atomic
+        double t = 0.0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t += dsum[nt];
+        for (int o = 32; o > 0; o >>= 1) t += shfl_xor_d(t, o);
+        if (lane == 0) atomicAdd(&redbuf[0], t);
+        __syncthreads();
+        if (tid == 0) atomic_add_f64(p.mse_acc, redbuf[0] * p.mse_inv);
+        return;
+    }
     // ---- per-channel reductions: lanes (l, l+32) -> waves (serialised through LDS) -> one fp64
     //      atomic per channel per block
     if (p.ystats != nullptr && !CUNET_DBG(p, 1)) {
@@ -919,7 +957,7 @@ __global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const ConvArgs p) {
 }
 
 static bool conv1x1_splitk_supported(const ConvArgs& a, int num_cus) {
-    if (a.taps != 1 || a.K % 32 || a.K != a.Kpad || a.K < 128 || a.K > 32 * 4 * SK_MAXCH || a.M % 32 || a.qin_bits || a.xbf16) return false;
+    if (a.taps != 1 || a.K % 32 || a.K != a.Kpad || a.K < 128 || a.K > 32 * 4 * SK_MAXCH || a.M % 32 || a.qin_bits || a.xbf16 || a.mse_tgt) return false;
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].C % 32 || a.seg[i].ld % 4) return false;
     const long blocks = (long)(a.M / 32) * ((a.Nout + 31) / 32);

@@ -191,6 +191,8 @@ hipError_t launch_bn_param_grad(const BnParamGradArgs& a, hipStream_t s) {
 // 2x2/2 max-pool over NHWC (+ fp64 batch statistics of the pooled tensor).  MODE 0: plain
 // (models/cu_net.py:249,260); MODE 1: the stem's BN -> ReLU -> pool (models/cu_net.py:301-303).
 
+constexpr int POOL_U = 4;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,16 +232,29 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolArgs p) {
             S = *reinterpret_cast<const float4*>(sc + 4 * g);
             Hh = *reinterpret_cast<const float4*>(sh + 4 * g);
         }
-        for (long row = (long)blockIdx.x * rpi + ry; row < rows; row += (long)gridDim.x * rpi) {
+        // POOL_U output rows per thread and iteration, all 4 * POOL_U loads requested before the first is used: the launch is a few
+        // hundred fat blocks (one round, <= 2 per CU) instead of a thousand thin ones -- a third of the fp64 statistics atomics, which
+        // all blocks aim at the same 2 * C addresses, and no load -> store -> load chain across grid-stride iterations
+        const long stride = (long)gridDim.x * rpi;
+        for (long row0 = (long)blockIdx.x * rpi + ry; row0 < rows; row0 += stride * POOL_U) {
+          float4 vv[POOL_U][4];
+#pragma unroll
+          for (int u = 0; u < POOL_U; ++u) {
+            const long row = row0 + u * stride < rows ? row0 + u * stride : row0;
             const int ni = (int)(row / (Ho * Wo));
             const int rm = (int)(row - (long)ni * Ho * Wo);
             const int yo = rm / Wo, xo = rm - yo * Wo;
             const size_t m00 = ((size_t)ni * p.H + 2 * yo) * p.W + 2 * xo;
-            float4 v[4];
-            v[0] = *reinterpret_cast<const float4*>(p.x + m00 * p.C + 4 * g);
-            v[1] = *reinterpret_cast<const float4*>(p.x + (m00 + 1) * p.C + 4 * g);
-            v[2] = *reinterpret_cast<const float4*>(p.x + (m00 + p.W) * p.C + 4 * g);
-            v[3] = *reinterpret_cast<const float4*>(p.x + (m00 + p.W + 1) * p.C + 4 * g);
+            vv[u][0] = ldg4(p.x + m00 * p.C + 4 * g);
+            vv[u][1] = ldg4(p.x + (m00 + 1) * p.C + 4 * g);
+            vv[u][2] = ldg4(p.x + (m00 + p.W) * p.C + 4 * g);
+            vv[u][3] = ldg4(p.x + (m00 + p.W + 1) * p.C + 4 * g);
+          }
+#pragma unroll
+          for (int u = 0; u < POOL_U; ++u) {
+            const long row = row0 + u * stride;
+            if (row >= rows) break;
+            float4 v[4] = {vv[u][0], vv[u][1], vv[u][2], vv[u][3]};
             if (MODE == 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolArgs p) {
             s1[1] += m.y; s2[1] += (double)m.y * m.y;
             s1[2] += m.z; s2[2] += (double)m.z * m.z;
             s1[3] += m.w; s2[3] += (double)m.w * m.w;
+          }
         }
     }
     if (p.ystats == nullptr) return;
@@ -290,8 +306,8 @@ static size_t pool_smem(int C, int mode) {
 hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t s) {
     const int rpi = 256 / (a.C / 4);
     const long rows = (long)a.N * (a.H / 2) * (a.W / 2);
-    long gx = (rows + rpi - 1) / rpi;
-    if (gx > 4L * num_cus) gx = 4L * num_cus;
+    long gx = (rows + (long)rpi * POOL_U - 1) / ((long)rpi * POOL_U);
+    if (gx > 2L * num_cus) gx = 2L * num_cus;
     if (gx < 1) gx = 1;
     if (mode == 0)
         hipLaunchKernelGGL(pool_fwd_kernel<0>, dim3((unsigned)gx), dim3(256), pool_smem(a.C, 0), s, a);

@@ -36,6 +36,7 @@ struct cunet_plan {
     std::vector<int> node_qin, node_tern;
     std::vector<TernPackEntry> ternpack;
     int ternpack_dirty = 0;
+    float* fused_loss_out = nullptr;  // cunet_loss_mse_fused: the next training forward computes the loss in its head epilogues
     int tern_live = 0;               // cunet_set_popcount_live: the caller vouches that those convs' weights ARE ternary right now
     // call-order state
     int fwd_training_done = 0;
@@ -391,6 +392,18 @@ struct Exec {
 
 }  // namespace
 
+// Heat-map head with the pixelwise MSE fused into its epilogue (cunet_loss_mse_fused): target staged in the workspace (NHWC),
+// d(loss)/d(out) into the head's gradient tensor, the squared error into the loss accumulator.
+static void set_fused_mse(cunet_plan* h, const Exec& E, const Node& n, ConvArgs& a) {
+    Plan& P = h->plan;
+    const TensorInfo& o = P.tensors[n.out];
+    a.mse_tgt = E.wsf + P.target_off;
+    a.mse_dout = E.grad(n.out);
+    a.mse_acc = E.zero + P.loss_acc;
+    a.mse_inv = 1.0 / ((double)o.rows() * o.C);
+    a.mse_gbf16 = 0;
+}
+
 // Gradient of tensor `t`: one gather over the dz slices of the conv nodes that read it (all of them have
 // run their data-gradient kernel: they come later in the forward order).  `only_node` >= 0 restricts the
 // gather to one consumer (node-local debugging / tests).
@@ -672,7 +685,10 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             a.qin_bits = h->qin_bits ? h->node_qin[ni] : 0;
             a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
-            if (a.qin_bits && h->node_tern[ni] && h->tern_live) {
+            const bool on_popcount = a.qin_bits && h->node_tern[ni] && h->tern_live;
+            const bool fuse_mse = n.head >= 0 && training && h->fused_loss_out != nullptr;
+            if (fuse_mse && !on_popcount) set_fused_mse(h, E, n, a);
+            if (on_popcount) {
                 // ternary weights x quantised activations: multiplier-free AND-popcount forward (one input tensor: the
                 // bottleneck output for a 3x3 conv, the U-Net output for a head)
                 const TensorInfo& ti = P.tensors[n.segs[0].tensor];
@@ -686,6 +702,8 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
                 t.gamma = a.gamma; t.beta = a.beta; t.rmean = a.rmean; t.rvar = a.rvar; t.training = training ? 1 : 0;
                 t.ystats = a.ystats;
                 PROF(PC_TERN, 0.0, 4.0 * (double)a.M * (a.K + a.Nout), launch_ternary_conv(t, cus, s));
+                if (fuse_mse)       // (the AND-popcount kernel has no loss epilogue: this head's MSE is its own launch)
+                    HIPCHK(launch_mse(E.act(n.out), E.wsf + P.target_off, E.grad(n.out), E.zero + P.loss_acc, (long)o.rows(), o.C, o.ld, 0, cus, s));
             } else {
                 PROF(c.taps == 9 ? PC_C3F : PC_C1F, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + a.Nout),
                      launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
@@ -711,6 +729,11 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     }
     h->fwd_training_done = training ? 1 : 0;
     h->loss_done = 0;
+    if (training && h->fused_loss_out != nullptr) {      // the heads' epilogues have staged d(loss)/d(out) and summed the loss
+        HIPCHK(launch_loss_finalize(E.zero + P.loss_acc, h->fused_loss_out, s));
+        h->loss_done = 1;
+    }
+    h->fused_loss_out = nullptr;
     h->last_x = x;
     return CUNET_OK;
 }
@@ -778,6 +801,10 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
             a.ldy = o.ld; a.Nout = c.Cout; a.ystats = (training && !is_head) ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            if (is_head && training && h->fused_loss_out != nullptr) {
+                set_fused_mse(h, E, n, a);
+                a.mse_gbf16 = training == 2;             // bf16 gradient tensors
+            }
             int slot_;
             HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3F16 : PC_C1F16, s, slot_));
             hipError_t e = launch_conv_bf16(a, is_head, cus, s);
@@ -799,6 +826,11 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
     }
     h->fwd_training_done = training ? (training == 2 ? 3 : 2) : 0;        // 2: activations are in the bf16 arena; 3: gradient tensors bf16 too
     h->loss_done = 0;
+    if (training && h->fused_loss_out != nullptr) {
+        HIPCHK(launch_loss_finalize(E.zero + P.loss_acc, h->fused_loss_out, s));
+        h->loss_done = 1;
+    }
+    h->fused_loss_out = nullptr;
     h->last_x = x;
     return CUNET_OK;
 }
@@ -811,6 +843,7 @@ int cunet_loss_mse(cunet_plan_t* h, const float* target, float* loss, void* stre
     Plan& P = h->plan;
     const TensorInfo& t0 = P.tensors[P.head_tensors[0]];
     float* tgt = E.wsf + P.target_off;
+    h->fused_loss_out = nullptr;
     HIPCHK(launch_transpose(target, tgt, t0.N, t0.C, t0.H * t0.W, t0.ld, 1, s));
     double* acc = E.zero + P.loss_acc;
     HIPCHK(hipMemsetAsync(acc, 0, 8, s));
@@ -820,6 +853,18 @@ int cunet_loss_mse(cunet_plan_t* h, const float* target, float* loss, void* stre
     }
     HIPCHK(launch_loss_finalize(acc, loss, s));
     h->loss_done = 1;
+    return CUNET_OK;
+}
+
+int cunet_loss_mse_fused(cunet_plan_t* h, const float* target, float* loss, void* stream) {
+    if (!h || !target || !loss) return fail(CUNET_ERR_INVALID, "null argument");
+    if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
+    hipStream_t s = (hipStream_t)stream;
+    Exec E(h);
+    Plan& P = h->plan;
+    const TensorInfo& t0 = P.tensors[P.head_tensors[0]];
+    HIPCHK(launch_transpose(target, E.wsf + P.target_off, t0.N, t0.C, t0.H * t0.W, t0.ld, 1, s));
+    h->fused_loss_out = loss;
     return CUNET_OK;
 }
 

@@ -103,6 +103,14 @@ class _BoundPlan:
               'cunet_loss_mse')
         return self.loss
 
+    def stage_target(self, target: torch.Tensor) -> torch.Tensor:
+        """cunet_loss_mse_fused: the NEXT training forward computes the MSE and its gradient in the heads' epilogues; returns the
+        0-dim device tensor that forward will write the loss to."""
+        check(lib().cunet_loss_mse_fused(self.handle.h, _ptr(target), _ptr(self.loss), _stream_ptr(target.device)),
+              'cunet_loss_mse_fused')
+        self._staged_target = target          # read asynchronously by the transpose
+        return self.loss
+
     def backward(self, grad_heat=None, on_bucket=None):
         dev = self.workspace.device
         arr = None

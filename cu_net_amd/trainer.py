@@ -77,11 +77,11 @@ class FusedTrainer:
             self.quan_op.quantization()
         reducing = False
         try:
+            loss = plan.stage_target(heatmap)     # MSE + d(loss)/d(out) in the head epilogues of the forward (cu-net.py:175-178)
             if self.bf16:
                 plan.forward_bf16(img, 2 if self.bf16_grads else 1, want_outputs=False)
             else:
                 plan.forward(img, True, want_outputs=False)
-            loss = plan.loss_mse(heatmap)
             if self.pg is None:
                 plan.backward(None)
             else:

@@ -97,6 +97,13 @@ int cunet_forward(cunet_plan_t* plan, const float* x, float* const* heat, int tr
  * and stages d(loss)/d(out_k) for cunet_backward. target is N x class_num x H/4 x W/4 NCHW. */
 int cunet_loss_mse(cunet_plan_t* plan, const float* target, float* loss, void* stream);
 
+/* The same loss FUSED into the next training forward: call before cunet_forward / cunet_forward_bf16 (training != 0) on the same
+ * stream.  The target is staged now; the heads' convolution epilogues then write d(loss)/d(out_k) and sum the squared error while
+ * the heat maps are still in registers (no separate pass over them), *loss is written at the end of that forward, and
+ * cunet_backward(plan, NULL, ...) may follow directly.  One-shot: it arms exactly one forward.  Same numbers as cunet_loss_mse
+ * up to the order of the fp64 partial sums. */
+int cunet_loss_mse_fused(cunet_plan_t* plan, const float* target, float* loss, void* stream);
+
 /* backward: replaces loss.backward() (cu-net.py:182) for this network.
  *   grad_heat: NULL -> use the gradients staged by cunet_loss_mse;
  *              else loss_num NCHW tensors d(loss)/d(heat[i]) (autograd path).

@@ -182,3 +182,43 @@ def test_backward_error_vs_fp64_tracks_torch_fp32(tag):
     except OSError:
         pass
     assert not bad, (len(bad), bad[:5], lines[-1])
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16_grads'])
+@pytest.mark.parametrize('class_num', [68, 3])
+def test_fused_head_loss_equals_the_separate_loss_pass(mode, class_num):
+    """cunet_loss_mse_fused (MSE and d(loss)/d(out) in the head convolutions' epilogues) against cunet_loss_mse after the same
+    forward: same loss (fp64 partial sums in another order), identical d(loss)/d(out) -- so identical parameter gradients up to
+    the atomics of the kernels behind it.  class_num = 3: a head tensor with a pad column (ld 4), which must read as zero."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=class_num, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=61)
+    x, target = O.synthetic_batch(2, class_num, 256, seed=62)
+    res = {}
+    for fused in (False, True):
+        net = cu_net_amd.create_cu_net(**cfg)
+        net.load_state_dict(st)
+        net = net.cuda().train()
+        plan = net._get_plan(2, 256, 256, True, bf16=mode != 'fp32')
+        xd, td = x.cuda(), target.cuda()
+        if fused:
+            loss = plan.stage_target(td)
+        if mode == 'fp32':
+            plan.forward(xd, True, want_outputs=False)
+        else:
+            plan.forward_bf16(xd, 2 if mode == 'bf16_grads' else 1, want_outputs=False)
+        if not fused:
+            loss = plan.loss_mse(td)
+        torch.cuda.synchronize()
+        heads = sorted((nd['head'], plan.handle.describe()['tensors'][nd['out']]['name'])
+                       for nd in plan.handle.describe()['nodes'] if nd.get('head', -1) >= 0)
+        dout = [plan.debug_tensor(name, grad=True).cpu() for _, name in heads]
+        plan.backward(None)
+        torch.cuda.synchronize()
+        res[fused] = (float(loss), dout, net._grad_arena.clone().cpu())
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    ga, gb = res[True][2], res[False][2]
+    assert float((ga - gb).norm() / gb.norm()) <= 1e-5
