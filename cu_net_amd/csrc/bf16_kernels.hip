@@ -741,6 +741,140 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 forward, tap-split, bf16 (norm2 -> relu2 -> conv2, 128 -> 32 channels; the bf16 twin of conv3x3_tapsplit_kernel).
+// conv_bf16_kernel<9> walks 9 taps x 4 chunks in one wave: 36 dependent load -> MFMA steps, 19-25 us at every level from 4x4 to
+// 32x32 (rocprofv3, round 3: 1.2 ms of a CU-Net-8 step).  Here a block is 9 waves and wave t owns tap t: its K x 32 slice of the
+// weights lives in 32 registers, its lane requests the eight 16-byte pieces of its shifted row together, BatchNorm + ReLU in
+// fp32, re-rounded, 8 MFMAs 32x32x16; the nine partial tiles meet in LDS where 512 threads add them, round to bf16, store and
+// keep the statistics of the ROUNDED values.  The next tile's loads are in flight across the reduction.
+__global__ __launch_bounds__(576) void conv3x3_tapsplit_bf16_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 128;
+    float* part = reinterpret_cast<float*>(smem);                 // [9][1024] partial tiles
+    float* sc = part + 9 * 1024;                                  // [K]
+    float* sh = sc + K;                                           // [K]
+    double* redbuf = reinterpret_cast<double*>(sh + K);           // [32][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int tap = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const Seg sg = p.seg[0];
+    const u16* xin = reinterpret_cast<const u16*>(sg.x);
+    const u16* wB = reinterpret_cast<const u16*>(p.wB);
+
+    // this wave's tap of the packed weights [tap][K/8][Npad][8]: piece (kq = 2j + hi, n = li) feeds MFMA j
+    uint4 bw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bw[j] = ldg16(wB + ((size_t)(tap * (K / 8) + 2 * j + hi) * p.Npad + li) * 8);
+
+    const int HW = p.H * p.W;
+    const int ntiles = p.M >> 5;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    uint4 a[8];
+    bool valid = false;
+    auto fetch = [&](int tile) {                      // raw loads of this wave's shifted rows (always a valid address)
+        const int m = tile * 32 + li;
+        const int nimg = m / HW;
+        const int rem = m - nimg * HW;
+        const int py = rem / p.W;
+        const int px = rem - py * p.W;
+        const int yy = py + dy, xx = px + dx;
+        valid = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+        const u16* src = xin + (size_t)(valid ? m + dy * p.W + dx : m) * sg.ld + 8 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = ldg16(src + 16 * j);
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);                   // requested before the BatchNorm tables are built
+
+    for (int c = tid; c < K; c += 576) {
+        double mean, istd;
+        if (p.training) {
+            mean = sg.stats[c] / sg.count;
+            double var = sg.stats[sg.C + c] / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            istd = 1.0 / sqrt(var + (double)BN_EPS);
+        } else {
+            mean = (double)p.rmean[c];
+            istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+        }
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+    }
+    if (tid < 64) redbuf[tid] = 0.0;
+    __syncthreads();
+
+    double dsum = 0.0, dsq = 0.0;
+    for (; tile < ntiles; tile += gridDim.x) {        // block-uniform trip count
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bool v = valid;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* scp = sc + 16 * j + 8 * hi;
+            const float* shp = sh + 16 * j + 8 * hi;
+            const float4 s0 = *reinterpret_cast<const float4*>(scp), s1 = *reinterpret_cast<const float4*>(scp + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(shp), h1 = *reinterpret_cast<const float4*>(shp + 4);
+            const uint4 x = a[j];
+            uint4 t;
+            t.x = pack_bf16(fmaxf(fmaf(bf16_lo(x.x), s0.x, h0.x), 0.f), fmaxf(fmaf(bf16_hi(x.x), s0.y, h0.y), 0.f));
+            t.y = pack_bf16(fmaxf(fmaf(bf16_lo(x.y), s0.z, h0.z), 0.f), fmaxf(fmaf(bf16_hi(x.y), s0.w, h0.w), 0.f));
+            t.z = pack_bf16(fmaxf(fmaf(bf16_lo(x.z), s1.x, h1.x), 0.f), fmaxf(fmaf(bf16_hi(x.z), s1.y, h1.y), 0.f));
+            t.w = pack_bf16(fmaxf(fmaf(bf16_lo(x.w), s1.z, h1.z), 0.f), fmaxf(fmaf(bf16_hi(x.w), s1.w, h1.w), 0.f));
+            if (!v) t = make_uint4(0, 0, 0, 0);                         // zero padding is post-activation
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t), __builtin_bit_cast(bf16x8, bw[j]), acc, 0, 0, 0);
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);               // in flight across the reduction below
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[tap * 1024 + r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (tid < 512) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + 512 * u;
+                float vsum = part[e];
+#pragma unroll
+                for (int w = 1; w < 9; ++w) vsum += part[w * 1024 + e];
+                const int r = e >> 6;                 // C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const unsigned q = pack_bf16(vsum, 0.f);
+                reinterpret_cast<u16*>(p.y)[(size_t)(tile * 32 + row) * p.ldy + li] = (u16)(q & 0xffffu);
+                const float vr = bf16_lo(q);          // statistics of what the consumers will read
+                dsum += (double)vr;
+                dsq += (double)vr * (double)vr;
+            }
+        }
+        __syncthreads();
+    }
+    if (p.ystats != nullptr) {                        // (threads 512..575 carry zeros)
+        const double a1 = dsum + shfl_xor_d16(dsum);
+        const double b1 = dsq + shfl_xor_d16(dsq);
+        if (hi == 0) {
+            atomicAdd(&redbuf[li * 2 + 0], a1);
+            atomicAdd(&redbuf[li * 2 + 1], b1);
+        }
+        __syncthreads();
+        if (tid < 32 && tid < p.Nout) {
+            __hip_atomic_fetch_add(p.ystats + tid, redbuf[tid * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static hipError_t launch_conv3x3_tapsplit_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
+    const int ntiles = a.M / 32;
+    static const int bpc = tune_int("CUNET_B16_TS_BPC", 2);         // blocks per CU (38 KB of LDS, 9 waves each)
+    const int grid = ntiles < bpc * num_cus ? ntiles : bpc * num_cus;
+    const size_t smem = (size_t)9 * 1024 * 4 + (size_t)128 * 8 + 64 * 8;
+    hipLaunchKernelGGL(conv3x3_tapsplit_bf16_kernel, dim3(grid), dim3(576), smem, s, a);
+    return hipGetLastError();
+}
+
 static size_t dgrad_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
     return (size_t)taps * (Kpad / 8) * NT * 32 * 16 + (size_t)Ccat * 16 + (size_t)(Ccat / 4) * sizeof(Grp16) + (size_t)NT * 32 * 16 + 16;
 }
@@ -820,6 +954,11 @@ hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStre
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
     const int ntiles = a.M / 32;
+    // 3x3 (128 -> 32) up to 12 tiles per CU (64 x 64 at batch 24): one tap per wave (tuning builds: CUNET_B16_TS = tiles per CU, 0 = off)
+    static const int use_ts = tune_int("CUNET_B16_TS", 12);
+    if (use_ts && a.taps == 9 && !out_f32 && a.nseg == 1 && a.K == 128 && a.Nout == 32 && a.Npad == 32 && !a.seg[0].ups && a.ldy % 2 == 0 &&
+        ntiles <= (long)use_ts * num_cus)
+        return launch_conv3x3_tapsplit_bf16(a, num_cus, s);
     const int ncol32 = (a.Nout + 31) / 32;
     const long target = 2L * 4 * num_cus;
     int NT = 1;

@@ -5,7 +5,7 @@ export CUNET_LIB_PATH=$(pwd)/cu_net_amd/libcunet_hip_tuning.so
 EXTRA=${1:-}
 run() {
   local tag=$1; shift
-  env "$@" python bench.py --no-also --no-cpu-baseline --steps 30 --warmup 4 $EXTRA 2> gpurun_out/sweep_$tag.err | python -c "
+  env "$@" python tools/bench_tuning.py --no-also --no-cpu-baseline --steps 30 --warmup 4 $EXTRA 2> gpurun_out/sweep_$tag.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline'] or {}
 print('$tag', d['value'], d['ms_per_step'], r.get('kernel'), r.get('avg_launch_us'), r.get('frac'))"

@@ -3,7 +3,7 @@
 export CUNET_LIB_PATH=$(pwd)/cu_net_amd/libcunet_hip_tuning.so
 run() {
   local tag=$1; shift
-  env "$@" python bench.py --no-also --no-cpu-baseline --steps 30 --warmup 4 2> gpurun_out/sweep2_$tag.err | python -c "
+  env "$@" python tools/bench_tuning.py --no-also --no-cpu-baseline --steps 30 --warmup 4 2> gpurun_out/sweep2_$tag.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$tag', d['value'], d['ms_per_step'])"
