@@ -509,6 +509,8 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
     float* is = mu + p.Ccat;
     Grp16* grp = reinterpret_cast<Grp16*>(is + p.Ccat);               // [Ccat / 4]
     double* redbuf = reinterpret_cast<double*>(grp + (p.Ccat >> 2));  // [NB][2]
+    constexpr int TP = NB + 8;                                        // element pitch of the epilogue tiles (16-byte aligned rows)
+    u16* tileT = reinterpret_cast<u16*>(redbuf + NB * 2);             // [waves][32][TP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -657,63 +659,83 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
             }
         }
 
-        if (tile + tstride < ntiles) begin_tile(tile + tstride);
-
-        // ---- epilogue.  Rows of this lane's 16 accumulator registers, plain and through the up-sample map (W % 4 == 0:
-        //      registers 4k..4k+3 lie in one image row, one division per group)
+        // ---- epilogue.  x (for the ReLU mask and x-hat) and dz move through a wave-private LDS tile T[32][NB + 8] so that global
+        //      memory sees 16-byte pieces: a lane requests four pieces (8 channels of one row each: 8 lanes cover 128 contiguous
+        //      bytes of a row) instead of 16 x NT two-byte loads, the tile is read back in the accumulator layout (col = lane & 31,
+        //      rows (r&3) + 8*(r>>2) + 4*hi), dz is written over the x it came from, and leaves as 16-byte pieces again.  The
+        //      two-byte version issued 64 memory instructions per lane and tile next to 16 MFMAs; LDS takes the narrow ones.
         const int mrow0 = tile * 32;
-        int rowP[16], rowUp[16];
+        u16* T = tileT + (size_t)wave * 32 * TP;
+        constexpr int PPR = NB / 8;                       // pieces per tile row
+        constexpr int NPJ = (32 * PPR) / 64;              // pieces per lane (4 for NB = 64, 2 for NB = 32)
+        const int pc8 = lane % PPR;                       // this lane's piece column ...
+        const int pr0 = lane / PPR;                       // ... and first row; further rows every 64 / PPR
+        const int pcol = n0 + 8 * pc8;
+        const bool pok = pcol < p.Nout;
+        Grp16 pg;
+        pg.ptr = dY; pg.ld = 0; pg.ups = 0;
+        if (pok) pg = grp[pcol >> 2];
+        uint4 xp[NPJ];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int m4 = mrow0 + 8 * k + 4 * hi;
-            int base = 0;
-            if (p.any_ups) {
+        for (int j = 0; j < NPJ; ++j) {
+            const int mm = mrow0 + pr0 + j * (64 / PPR);
+            int row = mm;
+            if (p.any_ups && pg.ups) {
                 int ni, yy, xx;
                 if (p.wshift >= 0) {
-                    ni = m4 >> p.hwshift;
-                    const int rm = m4 & (HW - 1);
+                    ni = mm >> p.hwshift;
+                    const int rm = mm & (HW - 1);
                     yy = rm >> p.wshift;
                     xx = rm & (p.W - 1);
                 } else {
-                    ni = m4 / HW;
-                    const int rm = m4 - ni * HW;
+                    ni = mm / HW;
+                    const int rm = mm - ni * HW;
                     yy = rm / p.W;
                     xx = rm - yy * p.W;
                 }
-                base = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { rowP[4 * k + j] = m4 + j; rowUp[4 * k + j] = base + (j >> 1); }
+            xp[j] = ldg16(pg.ptr + (size_t)row * pg.ld);
         }
+        if (tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j)
+            *reinterpret_cast<uint4*>(T + (size_t)(pr0 + j * (64 / PPR)) * TP + 8 * pc8) = xp[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + nt * 32 + li;
             const bool colok = col < p.Nout;
-            Grp16 g;
-            g.ptr = dY; g.ld = 0; g.ups = 0;                     // always a valid address: the loads stay branch-free
-            if (colok) g = grp[col >> 2];
-            const u16* xcol = g.ptr + (colok ? (col & 3) : 0);
-            const bool up = g.ups != 0;
-            float xv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                xv[r] = bf16_lo((unsigned)*(gptr_u16)(uintptr_t)(xcol + (size_t)(up ? rowUp[r] : rowP[r]) * g.ld));
             float csc = 0.f, csh = 0.f, cmu = 0.f, cis = 0.f;
             if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
             float s1 = 0.f, s2 = 0.f;
-            if (colok) {
+            u16* tcol = T + nt * 32 + li;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float z = fmaf(xv[r], csc, csh);
-                    const float dz = z > 0.f ? acc[nt][r] : 0.f;
-                    reinterpret_cast<u16*>(p.y)[(size_t)rowP[r] * p.ldy + col] = (u16)(pack_bf16(dz, 0.f) & 0xffffu);
-                    s1 += dz;
-                    s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float xv = bf16_lo((unsigned)tcol[(size_t)rr * TP]);
+                const float z = fmaf(xv, csc, csh);
+                const float dz = (colok && z > 0.f) ? acc[nt][r] : 0.f;
+                tcol[(size_t)rr * TP] = (u16)(pack_bf16(dz, 0.f) & 0xffffu);
+                s1 += dz;
+                s2 = fmaf(dz, (xv - cmu) * cis, s2);
             }
             dsum[nt] += (double)s1;
             dsq[nt] += (double)s2;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (pok) {
+#pragma unroll
+            for (int j = 0; j < NPJ; ++j) {
+                const int rr = pr0 + j * (64 / PPR);
+                const uint4 q = *reinterpret_cast<const uint4*>(T + (size_t)rr * TP + 8 * pc8);
+                *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.y) + (size_t)(mrow0 + rr) * p.ldy + pcol) = q;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+        __builtin_amdgcn_wave_barrier();
     }
 
     if (p.ystats != nullptr) {
@@ -894,25 +916,38 @@ static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, si
 
 // a.a (dY), a.seg[*].x, a.wB (backward operand), a.y (dz): bf16 behind float-typed pointers.  hipErrorInvalidValue when
 // the shape is outside the kernel's requirements (the caller then uses conv_kernel's XB = 2 variant).
+// LDS of a block: operand + tables (dgrad_bf16_smem) + one epilogue tile of 32 x (32 NT + 8) bf16 per wave, for the largest wave
+// count the block may get at `bpc` blocks per CU.  Returns false when even one block per CU does not fit.
+static bool dgrad_bf16_plan(int NT, int taps, int Kpad, int Ccat, int& bpc, size_t& smem) {
+    const size_t base = dgrad_bf16_smem(NT, taps, Kpad, Ccat);
+    for (bpc = 3; bpc >= 1; --bpc) {
+        const int wmax = B16_MAX_WAVES / bpc < 4 ? 4 : B16_MAX_WAVES / bpc;
+        smem = base + (size_t)wmax * 32 * (NT * 32 + 8) * 2;
+        const size_t limit = bpc == 3 ? 50 * 1024 : (bpc == 2 ? 76 * 1024 : 150 * 1024);
+        if (smem <= limit) return true;
+    }
+    return false;
+}
+
 hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
-    if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9) || (a.W & 3) || a.lda % 8 || a.Nout % 4) return hipErrorInvalidValue;
+    if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9) || (a.W & 3) || a.lda % 8 || a.Nout % 8 || a.ldy % 8) return hipErrorInvalidValue;
     for (int i = 0; i < a.nseg; ++i)
-        if (a.seg[i].C % 32) return hipErrorInvalidValue;
+        if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
     const int ntiles = a.M / 32;
     const int ncol32 = (a.Nout + 31) / 32;
     static const int ntmax = tune_int("CUNET_DG16_NT", 2);
-    int NT = 1;
+    int NT = 0, blocks_per_cu = 1;
+    size_t smem = 0;
     float best = 1e30f;
     for (int c = ntmax >= 2 ? 2 : 1; c >= 1; --c) {
-        if (dgrad_bf16_smem(c, a.taps, a.Kpad, a.Ccat) > 150 * 1024) continue;
+        int bpc; size_t sm;
+        if (!dgrad_bf16_plan(c, a.taps, a.Kpad, a.Ccat, bpc, sm)) continue;
         const int slices = (ncol32 + c - 1) / c;
         const float cost = slices * ((float)c + 0.3f);
-        if (cost < best) { best = cost; NT = c; }
+        if (cost < best) { best = cost; NT = c; blocks_per_cu = bpc; smem = sm; }
     }
-    const size_t smem = dgrad_bf16_smem(NT, a.taps, a.Kpad, a.Ccat);
-    if (smem > 150 * 1024) return hipErrorInvalidValue;
+    if (NT == 0) return hipErrorInvalidValue;
     const int gy = (ncol32 + NT - 1) / NT;
-    const int blocks_per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : 3);
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
     if (waves > B16_MAX_WAVES / blocks_per_cu) waves = B16_MAX_WAVES / blocks_per_cu;

@@ -219,6 +219,8 @@ def test_fused_head_loss_equals_the_separate_loss_pass(mode, class_num):
         res[fused] = (float(loss), dout, net._grad_arena.clone().cpu())
     assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
-        assert torch.equal(a, b)
+        # (two separate forwards: the fp64 statistics atomics of the fp32 nodes commit in another order, so the heat maps of the
+        # two runs agree to a few ulp, not bit for bit)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     ga, gb = res[True][2], res[False][2]
     assert float((ga - gb).norm() / gb.norm()) <= 1e-5
