@@ -44,6 +44,11 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     float* mu = sh + p.Ccat;
     float* is = mu + p.Ccat;
     double* redbuf = reinterpret_cast<double*>(is + p.Ccat);   // [NB][2]
+    // fp32 data gradient, one channel tile per wave, nothing ragged: the epilogue's x loads and dz stores go through a wave-private
+    // LDS tile (see below).  The other instantiations keep the element-wise epilogue.
+    constexpr bool TEPI = (EP == EP_BWD && FAST && NT == 1 && XBG == 0);
+    constexpr int TEPI_PITCH = 36;                             // floats per tile row (16-byte aligned rows)
+    float* tileT = reinterpret_cast<float*>(redbuf + NB * 2);  // TEPI: [waves][32][36]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                 }
                 mfma_chunk(ch, acur);
             }
-            if (EARLY_NEXT && tile + tstride < ntiles) begin_tile(tile + tstride);      // before this tile's epilogue (see above)
+            if (!TEPI && EARLY_NEXT && tile + tstride < ntiles) begin_tile(tile + tstride);      // before this tile's epilogue (see above)
         } else {
             // ---- generic path: per-group table look-ups and predicates (odd channel counts, ragged M)
             load_a(0, anext);
@@ -321,6 +326,81 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
         // ---- epilogue ---------------------------------------------------------------------
         // C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const int mrow0 = tile * 32;
+        if constexpr (TEPI) {
+            // BatchNorm / ReLU backward, first half, with global memory seen in 16-byte pieces.  The element-wise version below
+            // issues 16 four-byte x loads and 16 four-byte dz stores per lane and tile next to 64 MFMAs -- its cost was the
+            // per-CU rate of those 32 instructions, not their bytes (without them the kernel ran 24 % faster, round 2).  Here a
+            // lane requests FOUR 16-byte pieces of x (4 channels of one row; 8 lanes cover 128 contiguous bytes), the pieces go
+            // into the wave's LDS tile T[32][36], the tile is read back in the accumulator layout, dz overwrites the x it came
+            // from, and leaves as four 16-byte stores per lane.
+            float* T = tileT + (size_t)wave * 32 * TEPI_PITCH;
+            const int pc4 = lane & 7, pr0 = lane >> 3;          // piece column / first row (further rows + 8)
+            const int pcol = n0 + 4 * pc4;
+            const bool pok = pcol < p.Nout;
+            GrpEnt pg;
+            pg.ptr = p.a; pg.ld = 0; pg.ups = 0;                 // always a valid address
+            if (pok) pg = grp[pcol >> 2];
+            float4 xp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mm = mrow0 + pr0 + 8 * j;
+                int row = mm;
+                if (p.any_ups && pg.ups) {
+                    int ni, yy, xx;
+                    if (p.wshift >= 0) {
+                        ni = mm >> p.hwshift;
+                        const int rm = mm & (HW - 1);
+                        yy = rm >> p.wshift;
+                        xx = rm & (p.W - 1);
+                    } else {
+                        ni = mm / HW;
+                        const int rm = mm - ni * HW;
+                        yy = rm / p.W;
+                        xx = rm - yy * p.W;
+                    }
+                    row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                }
+                xp[j] = ldg4(pg.ptr + (size_t)row * pg.ld);
+            }
+            if (tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * TEPI_PITCH + 4 * pc4) = xp[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int col = n0 + li;
+                const bool colok = col < p.Nout;
+                float csc = 0.f, csh = 0.f, cmu = 0.f, cis = 0.f;
+                if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
+                float s1 = 0.f, s2 = 0.f;
+                float* tcol = T + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float xv = tcol[rr * TEPI_PITCH];
+                    const float z = fmaf(xv, csc, csh);
+                    // ReLU mask; with a QuanInput behind the ReLU also its straight-through mask (no gradient where z >= 1)
+                    const float dz = (colok && z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[0][r] : 0.f;
+                    tcol[rr * TEPI_PITCH] = dz;
+                    s1 += dz;
+                    s2 = fmaf(dz, colok ? (xv - cmu) * cis : 0.f, s2);
+                }
+                dsum[0] += (double)s1;
+                dsq[0] += (double)s2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (pok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = pr0 + 8 * j;
+                    *reinterpret_cast<float4*>(p.y + (size_t)(mrow0 + rr) * p.ldy + pcol) = *reinterpret_cast<const float4*>(T + rr * TEPI_PITCH + 4 * pc4);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         // EP_BWD: rows of this lane's 16 accumulator registers, plain and through the nearest-upsample map.
         // Everything below is branch-free per element: a branch around a load makes hipcc wait for that load
         // before issuing the next one (the first version of this epilogue spent 59 us of 177 in 64 serialised loads).
@@ -983,6 +1063,7 @@ static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
     b += (size_t)NT * 32 * 2 * 8;                          // reduction scratch
     return b;
 }
+constexpr size_t CONV_TEPI_TILE = 32 * 36 * 4;             // per wave: the data gradient's epilogue tile (TEPI instantiations)
 
 constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 
@@ -1071,10 +1152,24 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
             if (cost < best) { best = cost; NT = c; }
         }
     }
-    const size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat);
+    // fast path: nothing ragged (see the kernel)
+    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !tune_int("CUNET_CONV_GENERIC", 0);
+    if (load == LD_SEG) {
+        for (int i = 0; i < a.nseg; ++i) fast = fast && (a.seg[i].C % 32 == 0) && (a.seg[i].ld % 4 == 0);
+    }
+    size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat);
     if (smem > CONV_LDS_BUDGET) return hipErrorInvalidValue;   // weights of one 32-channel slice exceed the LDS
     const int gy = (ncol32 + NT - 1) / NT;
-    const int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
+    int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
+    if (epi == EP_BWD && fast && NT == 1 && a.xbf16 == 0) {      // + one epilogue tile per wave (TEPI instantiations of the kernel)
+        const size_t base = smem;
+        for (blocks_per_cu = 3; blocks_per_cu >= 1; --blocks_per_cu) {
+            const int wmax = CONV_MAX_WAVES / blocks_per_cu < 4 ? 4 : CONV_MAX_WAVES / blocks_per_cu;
+            smem = base + (size_t)wmax * CONV_TEPI_TILE;
+            if (smem <= (blocks_per_cu == 3 ? 52 * 1024 : (blocks_per_cu == 2 ? 80 * 1024 : CONV_LDS_BUDGET))) break;
+        }
+        if (blocks_per_cu < 1) return hipErrorInvalidValue;
+    }
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
     const int maxw = CONV_MAX_WAVES;      // 16 waves for one-tile blocks (VGPR budget 128) measured 2-3 % slower
@@ -1090,11 +1185,6 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     if (xcd_remap && gy > 1 && (epi == EP_BWD || xcd_fwd)) {        // column slices of a row block re-read the same A rows: keep them on one XCD
         a.xcd_gx = gx; a.xcd_gy = gy;
         grid = dim3(8 * ((gx + 7) / 8) * gy, 1);
-    }
-    // fast path: nothing ragged (see the kernel)
-    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !tune_int("CUNET_CONV_GENERIC", 0);
-    if (load == LD_SEG) {
-        for (int i = 0; i < a.nseg; ++i) fast = fast && (a.seg[i].C % 32 == 0) && (a.seg[i].ld % 4 == 0);
     }
     // never fewer than 4 waves: idle waves still help copying B into LDS and building the BN tables
     const int threads = (waves < 4 ? 4 : waves) * 64;
