@@ -216,7 +216,12 @@ struct TernArgs {
     const float* gamma; const float* beta; const float* rmean; const float* rvar;
     int training;
     double* ystats;          // [2][O] sum / sum of squares of the output (or null)
+    uint64_t* planes;        // plan path: [M + 1][16] bit-plane records of the quantised input (ternary_planes_kernel), or null
 };
+// One record of 16 words per input pixel: words [7 g + b] = bit b of the quantised activation of channels 64 g .. 64 g + 63 (g < 2,
+// b < 7: C <= 128, bits_i <= 8), word 14 = the sum of the pixel's quantised activations, word 15 = 0; record M is all zero (what a
+// tap outside the image reads).
+constexpr int TERN_REC_WORDS = 16;
 
 struct AugSample {           // one training sample of cunet_augment_batch (host-computed crop geometry, pylib/HumanAug.py:118-142); 192 bytes
     const float* src;        // 3 x sh x sw fp32 CHW image in [0, 1]

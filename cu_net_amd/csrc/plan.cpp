@@ -506,6 +506,11 @@ void Plan::layout_workspace() {
         off += round_up64((int64_t)(n_tern_sites > 0 ? n_tern_sites : 1) * (int64_t)sizeof(TernPackEntry), 256);
         off_tern = off;
         off += round_up64(words * 8, 256);
+        int64_t max_rows = 0;
+        for (auto& n : nodes)
+            if (n.type == N_CONV && convs[n.conv].tern >= 0) max_rows = std::max(max_rows, tensors[n.segs[0].tensor].rows());
+        off_planes = off;
+        off += round_up64((max_rows + 1) * TERN_REC_WORDS * 8, 256);
     }
     loss_acc = n_zero_doubles;
     n_zero_doubles += 2;

@@ -113,6 +113,7 @@ struct Plan {
     int64_t off_bf16 = 0, ws_bytes_bf16 = 0;     // bf16 inference: a bf16 arena of n_floats_infer elements behind the fp32 inference layout
     int64_t off_bf16_train = 0, ws_bytes_bf16_train = 0;   // the same arena behind the training layout (bf16 activations, fp32 gradients)
     int n_runstat = 0;
+    int64_t off_planes = 0;                      // bit-plane records of the AND-popcount forward: (largest site rows + 1) x 128 bytes, reused site after site
     int64_t off_ternpack_tab = 0, off_tern = 0;   // pack table / bit-mask region of the quantised-input mode (bytes)
     int n_tern_sites = 0;
     int64_t off_wgred_tab = 0;                // reduce table of the wgrad3 nodes (bytes), entries grouped by bucket

@@ -254,6 +254,179 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second-generation AND-popcount forward (plan path, C <= 128, bits_i <= 8): the activation is quantised and cut into bit-planes
+// ONCE per tensor instead of once per tap, and a wave works on 64 / LP pixels at a time.
+//   ternary_planes_kernel        x -> BatchNorm -> ReLU -> QuanInput -> one 128-byte record per pixel (TERN_REC_WORDS)
+//   ternary_conv_planes_kernel   lane = (pixel slot, output channel): its +1 / -1 masks of all taps in registers, per tap eight 16-byte
+//                                loads of the neighbour's record (a record outside the image is the all-zero record M), per plane
+//                                word v_and + v_bcnt accumulating per-plane counts; sum_b 2^b (popc(P & plane_b) - popc(N & plane_b)).
+//                                Where no weight of the wave is zero (QuanOp bits_w = 1: N = ~P) the N half is not computed:
+//                                sum w q = 2 sum_b 2^b popc(P & plane_b) - sum q, the last term read from word 14 of the records.
+// Every quantity is an integer below 2^24: the result is exact, bit-identical to the MFMA forward of the same node.
+__global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
+    __shared__ float s_sc[128], s_sh[128];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int G = (p.C + 63) >> 6;
+    for (int c = tid; c < 128; c += 256) {
+        float sc = 0.f, sh = 0.f;
+        if (c < p.C) {
+            double mean, istd;
+            if (p.training) {
+                mean = p.xstats[c] / p.count;
+                double var = p.xstats[p.C + c] / p.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                istd = 1.0 / sqrt(var + (double)BN_EPS);
+            } else {
+                mean = (double)p.rmean[c];
+                istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+            }
+            const double scale = (double)p.gamma[c] * istd;
+            sc = (float)scale;
+            sh = (float)((double)p.beta[c] - mean * scale);
+        }
+        s_sc[c] = sc; s_sh[c] = sh;
+    }
+    __syncthreads();
+    const int nb = p.bits_i - 1;
+    const float qs = exp2f((float)nb);
+    if (blockIdx.x == 0 && wave == 0 && lane < TERN_REC_WORDS) p.planes[(size_t)p.M * TERN_REC_WORDS + lane] = 0;      // the zero record
+    const int nwaves = gridDim.x * 4;
+    for (int m0 = (blockIdx.x * 4 + wave) * 2; m0 < p.M; m0 += nwaves * 2) {      // two pixels per iteration: four loads in flight
+        float xv[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int m = m0 + u < p.M ? m0 + u : m0;
+                const int c = 64 * g + lane;
+                xv[u][g] = (g < G && c < p.C) ? ldg1(p.x + (size_t)m * p.ldx + c) : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (m0 + u >= p.M) break;
+            uint64_t mine = 0;                  // lanes 0..13 end up holding plane word (7 g + b), lane 14 the sum
+            long long ssum = 0;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int c = 64 * g + lane;
+                int q = 0;
+                if (g < G && c < p.C) {
+                    float a = fmaxf(fmaf(xv[u][g], s_sc[c], s_sh[c]), 0.f);
+                    a = fminf(a, 1.f - 1.f / qs);                          // C(x, bits_i); relu already >= 0
+                    q = (int)rintf(a * qs);                                // Q(x, bits_i) * 2^(bits_i-1)
+                }
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const uint64_t plane = b < nb ? __ballot((q >> b) & 1) : 0;
+                    if (lane == 7 * g + b) mine = plane;
+                    ssum += (long long)__popcll(plane) << b;
+                }
+            }
+            if (lane == 14) mine = (uint64_t)ssum;
+            if (lane < TERN_REC_WORDS) p.planes[(size_t)(m0 + u) * TERN_REC_WORDS + lane] = mine;
+        }
+    }
+}
+
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+typedef const u64x2_t __attribute__((address_space(1)))* gptr_u64x2;
+
+template <int TAPS, int LP>      // LP lanes (= output channels of this block) per pixel: 32 or 64
+__global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs p) {
+    __shared__ double s_red[2][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    constexpr int PPW = 64 / LP;                          // pixels per wave and iteration
+    const int slot = lane / LP;
+    const int o = blockIdx.y * LP + (lane % LP);          // this lane's output channel
+    const int G = (p.C + 63) >> 6;
+    if (tid < 128) s_red[tid >> 6][tid & 63] = 0.0;
+    __syncthreads();
+
+    unsigned Pl[TAPS][2], Ph[TAPS][2], Nl[TAPS][2], Nh[TAPS][2];
+    bool binary = true;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint64_t pp = 0, nn = 0;
+            if (g < G && o < p.Opad) {
+                pp = p.wpos[((size_t)t * G + g) * p.Opad + o];
+                nn = p.wneg[((size_t)t * G + g) * p.Opad + o];
+            }
+            Pl[t][g] = (unsigned)pp; Ph[t][g] = (unsigned)(pp >> 32);
+            Nl[t][g] = (unsigned)nn; Nh[t][g] = (unsigned)(nn >> 32);
+            const int nch = p.C - 64 * g;                 // channels of this group
+            const uint64_t full = (g >= G || nch <= 0) ? 0 : (nch >= 64 ? ~0ull : ((1ull << nch) - 1));
+            if (o < p.O && (pp | nn) != full) binary = false;
+        }
+    const bool wave_binary = __ballot(!binary) == 0;      // uniform: no zero weight among this wave's output channels
+    const float qs = exp2f((float)(p.bits_i - 1));
+    const int HW = p.H * p.W;
+    const int stride = gridDim.x * 4 * PPW;
+    double d1 = 0.0, d2 = 0.0;
+    for (int m0 = (blockIdx.x * 4 + wave) * PPW; m0 < p.M; m0 += stride) {
+        const int m = m0 + slot;
+        const bool mok = m < p.M;
+        const int mc = mok ? m : 0;
+        const int ni = mc / HW;
+        const int rem = mc - ni * HW;
+        const int py = rem / p.W, px = rem - py * p.W;
+        int cp[7] = {0, 0, 0, 0, 0, 0, 0}, cn[7] = {0, 0, 0, 0, 0, 0, 0};
+        long long ssum = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            int row = mc;
+            bool valid = mok;
+            if (TAPS == 9) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const int yy = py + dy, xx = px + dx;
+                valid = mok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
+                row = mc + dy * p.W + dx;
+            }
+            if (!valid) row = p.M;                        // the all-zero record
+            const gptr_u64x2 rec = (gptr_u64x2)(uintptr_t)(p.planes + (size_t)row * TERN_REC_WORDS);
+            u64x2_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = rec[i];
+            ssum += (long long)w[7].x;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const int wi = 7 * g + b;
+                    const uint64_t v = (wi & 1) ? w[wi >> 1].y : w[wi >> 1].x;
+                    const unsigned vl = (unsigned)v, vh = (unsigned)(v >> 32);
+                    cp[b] += __popc(Pl[t][g] & vl) + __popc(Ph[t][g] & vh);
+                    if (!wave_binary) cn[b] += __popc(Nl[t][g] & vl) + __popc(Nh[t][g] & vh);
+                }
+        }
+        int accp = 0, accn = 0;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) { accp += cp[b] << b; accn += cn[b] << b; }
+        const int val = wave_binary ? 2 * accp - (int)ssum : accp - accn;
+        const float yv = (float)val / qs;
+        if (mok && o < p.O) {
+            p.y[(size_t)m * p.ldy + o] = yv;
+            d1 += (double)yv;
+            d2 += (double)yv * (double)yv;
+        }
+    }
+    if (p.ystats != nullptr) {        // batch statistics of the output for the consumer BatchNorms
+        atomicAdd(&s_red[0][lane % LP], d1);
+        atomicAdd(&s_red[1][lane % LP], d2);
+        __syncthreads();
+        if (tid < LP && blockIdx.y * LP + tid < p.O) {
+            __hip_atomic_fetch_add(p.ystats + blockIdx.y * LP + tid, s_red[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ystats + p.O + blockIdx.y * LP + tid, s_red[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // every conv of a table in one launch: blockIdx.y = table entry (same packing as ternary_pack_kernel)
 __global__ __launch_bounds__(256) void ternary_pack_all_kernel(const TernPackEntry* __restrict__ tab, const float* __restrict__ params,
                                                                uint64_t* __restrict__ masks) {
@@ -318,6 +491,21 @@ hipError_t launch_ternary_pack_all(const TernPackEntry* tab, int n, const float*
 
 hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
     if ((a.taps != 1 && a.taps != 9) || a.bits_i < 2 || a.bits_i > 15) return hipErrorInvalidValue;
+    if (a.planes != nullptr && a.scale == nullptr && a.C <= 128 && a.bits_i <= 8) {      // plan path: bit-planes once per tensor
+        int gp = (a.M + 7) / 8;
+        if (gp > 8 * num_cus) gp = 8 * num_cus;
+        hipLaunchKernelGGL(ternary_planes_kernel, dim3(gp), dim3(256), 0, s, a);
+        const int LP = a.O <= 32 ? 32 : 64;
+        const int ppb = 4 * (64 / LP);                       // pixels per block and iteration
+        int gx = (a.M + ppb - 1) / ppb;
+        if (gx > 8 * num_cus) gx = 8 * num_cus;
+        const dim3 grid(gx, (a.O + LP - 1) / LP);
+        if (a.taps == 9 && LP == 32) hipLaunchKernelGGL((ternary_conv_planes_kernel<9, 32>), grid, dim3(256), 0, s, a);
+        else if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_planes_kernel<9, 64>), grid, dim3(256), 0, s, a);
+        else if (LP == 32) hipLaunchKernelGGL((ternary_conv_planes_kernel<1, 32>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ternary_conv_planes_kernel<1, 64>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if ((a.C + 63) / 64 > (a.taps == 1 ? TC_MAXG1 : TC_MAXG9)) return hipErrorInvalidValue;
     int gx = (a.M + 3) / 4;
     if (gx > 8 * num_cus) gx = 8 * num_cus;

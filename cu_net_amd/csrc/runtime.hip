@@ -701,6 +701,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
                 t.xstats = E.stats(n.segs[0].tensor); t.count = (double)ti.rows();
                 t.gamma = a.gamma; t.beta = a.beta; t.rmean = a.rmean; t.rvar = a.rvar; t.training = training ? 1 : 0;
                 t.ystats = a.ystats;
+                t.planes = reinterpret_cast<uint64_t*>(h->ws + P.off_planes);
                 PROF(PC_TERN, 0.0, 4.0 * (double)a.M * (a.K + a.Nout), launch_ternary_conv(t, cus, s));
                 if (fuse_mse)       // (the AND-popcount kernel has no loss epilogue: this head's MSE is its own launch)
                     HIPCHK(launch_mse(E.act(n.out), E.wsf + P.target_off, E.grad(n.out), E.zero + P.loss_acc, (long)o.rows(), o.C, o.ld, 0, cus, s));

@@ -24,11 +24,18 @@ namespace cunet {
 
 constexpr int WG3_P = 32;            // pixels per chunk
 constexpr int WG3_THREADS = 512;
+// Minimum waves per SIMD the fp32 kernels are compiled for: 2 = up to 256 VGPRs (the 320-channel instantiation uses 220, i.e. two of
+// its waves fill a SIMD's register file and no data-gradient wave can sit next to them); a probe build with 3 (<= 168 VGPRs) measures
+// whether leaving room for a co-resident wave of the caller's stream is worth the spills (-DCUNET_WG3_MIN_WAVES=3).
+#ifndef CUNET_WG3_MIN_WAVES
+#define CUNET_WG3_MIN_WAVES 2
+#endif
+constexpr int WG3_MIN_WAVES = CUNET_WG3_MIN_WAVES;
 constexpr int WG3_NOUT = 128;        // output channels (4 tiles): the bottleneck / adapter convs of the network
 constexpr int WG3_MAXCW = 320;
 
 template <int CTW, bool SPLITK, int XB>
-__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_kernel(const Wg3Args q) {
+__global__ __launch_bounds__(WG3_THREADS, WG3_MIN_WAVES) void wgrad3_kernel(const Wg3Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgradArgs& p = q.w;
     const int CW = q.CW;                                   // channels of this launch's slice (multiple of 32)
@@ -611,7 +618,7 @@ hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, c
 constexpr int WG3C_C = 128, WG3C_N = 32;
 
 template <int XBG>      // 0: fp32 x and dY; 1: bf16 x; 2: bf16 x and bf16 dY (both widened to fp32 on the way into LDS; fp32 MFMA)
-__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_kernel(const Wg3Args q) {
+__global__ __launch_bounds__(WG3_THREADS, WG3_MIN_WAVES) void wgrad3_3x3_kernel(const Wg3Args q) {
     constexpr int XB = XBG != 0, GB = XBG == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgradArgs& p = q.w;
