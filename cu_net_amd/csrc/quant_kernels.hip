@@ -258,11 +258,7 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
 // Second-generation AND-popcount forward (plan path, C <= 128, bits_i <= 8): the activation is quantised and cut into bit-planes
 // ONCE per tensor instead of once per tap, and a wave works on 64 / LP pixels at a time.
 //   ternary_planes_kernel        x -> BatchNorm -> ReLU -> QuanInput -> one 128-byte record per pixel (TERN_REC_WORDS)
-//   ternary_conv_planes_kernel   lane = (pixel slot, output channel): its +1 / -1 masks of all taps in registers, per tap eight 16-byte
-//                                loads of the neighbour's record (a record outside the image is the all-zero record M), per plane
-//                                word v_and + v_bcnt accumulating per-plane counts; sum_b 2^b (popc(P & plane_b) - popc(N & plane_b)).
-//                                Where no weight of the wave is zero (QuanOp bits_w = 1: N = ~P) the N half is not computed:
-//                                sum w q = 2 sum_b 2^b popc(P & plane_b) - sum q, the last term read from word 14 of the records.
+//   ternary_conv_planes_kernel   a wave per pixel, plane words as scalar operands, + / - masks on the two halves of the wave (see there)
 // Every quantity is an integer below 2^24: the result is exact, bit-identical to the MFMA forward of the same node.
 __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
     __shared__ float s_sc[128], s_sh[128];
@@ -331,98 +327,84 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
     }
 }
 
-typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-typedef const u64x2_t __attribute__((address_space(1)))* gptr_u64x2;
+// A wave owns ONE pixel: its nine neighbour records are wave-uniform, so they come through the SCALAR cache (s_load_dwordx16) and the
+// plane words are scalar operands of the v_and's -- the first version of this kernel fetched them with per-lane 16-byte loads and sat
+// on the vector-memory issue rate (72 load instructions per pixel, 84 us per launch).  Lane = (output channel o = lane & 31, sign =
+// lane >> 5): lanes 0..31 hold the +1 masks of their output channel and count popc(P & plane), lanes 32..63 the -1 masks and count
+// popc(N & plane); one cross-lane add at the end gives sum_b 2^b (popc(P & plane_b) - popc(N & plane_b)).  32 output channels per block
+// column (blockIdx.y).
+typedef const unsigned __attribute__((address_space(4)))* cptr_u32;      // constant address space: uniform loads become s_load
 
-template <int TAPS, int LP>      // LP lanes (= output channels of this block) per pixel: 32 or 64
+template <int TAPS>
 __global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs p) {
-    __shared__ double s_red[2][64];
+    __shared__ double s_red[2][32];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    constexpr int PPW = 64 / LP;                          // pixels per wave and iteration
-    const int slot = lane / LP;
-    const int o = blockIdx.y * LP + (lane % LP);          // this lane's output channel
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ol = lane & 31;
+    const int sgn = lane >> 5;
+    const int o = blockIdx.y * 32 + ol;                   // this lane's output channel
     const int G = (p.C + 63) >> 6;
-    if (tid < 128) s_red[tid >> 6][tid & 63] = 0.0;
+    if (tid < 64) s_red[tid >> 5][tid & 31] = 0.0;
     __syncthreads();
 
-    unsigned Pl[TAPS][2], Ph[TAPS][2], Nl[TAPS][2], Nh[TAPS][2];
-    bool binary = true;
+    unsigned Ml[TAPS][2], Mh[TAPS][2];                    // this lane's masks (+1 masks for sgn = 0, -1 masks for sgn = 1)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            uint64_t pp = 0, nn = 0;
-            if (g < G && o < p.Opad) {
-                pp = p.wpos[((size_t)t * G + g) * p.Opad + o];
-                nn = p.wneg[((size_t)t * G + g) * p.Opad + o];
-            }
-            Pl[t][g] = (unsigned)pp; Ph[t][g] = (unsigned)(pp >> 32);
-            Nl[t][g] = (unsigned)nn; Nh[t][g] = (unsigned)(nn >> 32);
-            const int nch = p.C - 64 * g;                 // channels of this group
-            const uint64_t full = (g >= G || nch <= 0) ? 0 : (nch >= 64 ? ~0ull : ((1ull << nch) - 1));
-            if (o < p.O && (pp | nn) != full) binary = false;
+            uint64_t mm = 0;
+            if (g < G && o < p.Opad) mm = (sgn ? p.wneg : p.wpos)[((size_t)t * G + g) * p.Opad + o];
+            Ml[t][g] = (unsigned)mm; Mh[t][g] = (unsigned)(mm >> 32);
         }
-    const bool wave_binary = __ballot(!binary) == 0;      // uniform: no zero weight among this wave's output channels
     const float qs = exp2f((float)(p.bits_i - 1));
     const int HW = p.H * p.W;
-    const int stride = gridDim.x * 4 * PPW;
+    const int stride = gridDim.x * 4;
+    const cptr_u32 planes = (cptr_u32)(uintptr_t)p.planes;
     double d1 = 0.0, d2 = 0.0;
-    for (int m0 = (blockIdx.x * 4 + wave) * PPW; m0 < p.M; m0 += stride) {
-        const int m = m0 + slot;
-        const bool mok = m < p.M;
-        const int mc = mok ? m : 0;
-        const int ni = mc / HW;
-        const int rem = mc - ni * HW;
+    for (int m = blockIdx.x * 4 + wave; m < p.M; m += stride) {      // m is wave-uniform
+        const int ni = m / HW;
+        const int rem = m - ni * HW;
         const int py = rem / p.W, px = rem - py * p.W;
-        int cp[7] = {0, 0, 0, 0, 0, 0, 0}, cn[7] = {0, 0, 0, 0, 0, 0, 0};
-        long long ssum = 0;
+        int cnt[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            int row = mc;
-            bool valid = mok;
+            int row = m;
             if (TAPS == 9) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
                 const int yy = py + dy, xx = px + dx;
-                valid = mok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
-                row = mc + dy * p.W + dx;
+                const bool valid = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
+                row = valid ? m + dy * p.W + dx : p.M;                              // record M is all zero
             }
-            if (!valid) row = p.M;                        // the all-zero record
-            const gptr_u64x2 rec = (gptr_u64x2)(uintptr_t)(p.planes + (size_t)row * TERN_REC_WORDS);
-            u64x2_t w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = rec[i];
-            ssum += (long long)w[7].x;
+            const cptr_u32 rec = planes + (size_t)row * (TERN_REC_WORDS * 2);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int b = 0; b < 7; ++b) {
-                    const int wi = 7 * g + b;
-                    const uint64_t v = (wi & 1) ? w[wi >> 1].y : w[wi >> 1].x;
-                    const unsigned vl = (unsigned)v, vh = (unsigned)(v >> 32);
-                    cp[b] += __popc(Pl[t][g] & vl) + __popc(Ph[t][g] & vh);
-                    if (!wave_binary) cn[b] += __popc(Nl[t][g] & vl) + __popc(Nh[t][g] & vh);
+                    const unsigned vl = rec[2 * (7 * g + b)], vh = rec[2 * (7 * g + b) + 1];      // scalar operands
+                    cnt[b] += __popc(Ml[t][g] & vl) + __popc(Mh[t][g] & vh);
                 }
         }
-        int accp = 0, accn = 0;
+        int acc = 0;
 #pragma unroll
-        for (int b = 0; b < 7; ++b) { accp += cp[b] << b; accn += cn[b] << b; }
-        const int val = wave_binary ? 2 * accp - (int)ssum : accp - accn;
-        const float yv = (float)val / qs;
-        if (mok && o < p.O) {
+        for (int b = 0; b < 7; ++b) acc += cnt[b] << b;
+        const int other = __shfl_xor(acc, 32, 64);
+        const float yv = (float)(acc - other) / qs;          // (lanes 0..31: P - N)
+        if (sgn == 0 && o < p.O) {
             p.y[(size_t)m * p.ldy + o] = yv;
             d1 += (double)yv;
             d2 += (double)yv * (double)yv;
         }
     }
     if (p.ystats != nullptr) {        // batch statistics of the output for the consumer BatchNorms
-        atomicAdd(&s_red[0][lane % LP], d1);
-        atomicAdd(&s_red[1][lane % LP], d2);
+        if (sgn == 0) {
+            atomicAdd(&s_red[0][ol], d1);
+            atomicAdd(&s_red[1][ol], d2);
+        }
         __syncthreads();
-        if (tid < LP && blockIdx.y * LP + tid < p.O) {
-            __hip_atomic_fetch_add(p.ystats + blockIdx.y * LP + tid, s_red[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(p.ystats + p.O + blockIdx.y * LP + tid, s_red[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 32 && blockIdx.y * 32 + tid < p.O) {
+            __hip_atomic_fetch_add(p.ystats + blockIdx.y * 32 + tid, s_red[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ystats + p.O + blockIdx.y * 32 + tid, s_red[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -495,15 +477,11 @@ hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
         int gp = (a.M + 7) / 8;
         if (gp > 8 * num_cus) gp = 8 * num_cus;
         hipLaunchKernelGGL(ternary_planes_kernel, dim3(gp), dim3(256), 0, s, a);
-        const int LP = a.O <= 32 ? 32 : 64;
-        const int ppb = 4 * (64 / LP);                       // pixels per block and iteration
-        int gx = (a.M + ppb - 1) / ppb;
+        int gx = (a.M + 3) / 4;
         if (gx > 8 * num_cus) gx = 8 * num_cus;
-        const dim3 grid(gx, (a.O + LP - 1) / LP);
-        if (a.taps == 9 && LP == 32) hipLaunchKernelGGL((ternary_conv_planes_kernel<9, 32>), grid, dim3(256), 0, s, a);
-        else if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_planes_kernel<9, 64>), grid, dim3(256), 0, s, a);
-        else if (LP == 32) hipLaunchKernelGGL((ternary_conv_planes_kernel<1, 32>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((ternary_conv_planes_kernel<1, 64>), grid, dim3(256), 0, s, a);
+        const dim3 grid(gx, (a.O + 31) / 32);
+        if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_planes_kernel<9>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ternary_conv_planes_kernel<1>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
     if ((a.C + 63) / 64 > (a.taps == 1 ? TC_MAXG1 : TC_MAXG9)) return hipErrorInvalidValue;
