@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
 // Second-generation AND-popcount forward (plan path, C <= 128, bits_i <= 8): the activation is quantised and cut into bit-planes
 // ONCE per tensor instead of once per tap, and a wave works on 64 / LP pixels at a time.
 //   ternary_planes_kernel        x -> BatchNorm -> ReLU -> QuanInput -> one 128-byte record per pixel (TERN_REC_WORDS)
-//   ternary_conv_planes_kernel   a wave per pixel, plane words as scalar operands, + / - masks on the two halves of the wave (see there)
+//   ternary_conv_planes_kernel   a wave per pixel, plane words broadcast by v_readlane, + / - masks on the two halves of the wave (see there)
 // Every quantity is an integer below 2^24: the result is exact, bit-identical to the MFMA forward of the same node.
 __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
     __shared__ float s_sc[128], s_sh[128];
@@ -327,14 +327,13 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
     }
 }
 
-// A wave owns ONE pixel: its nine neighbour records are wave-uniform, so they come through the SCALAR cache (s_load_dwordx16) and the
-// plane words are scalar operands of the v_and's -- the first version of this kernel fetched them with per-lane 16-byte loads and sat
-// on the vector-memory issue rate (72 load instructions per pixel, 84 us per launch).  Lane = (output channel o = lane & 31, sign =
-// lane >> 5): lanes 0..31 hold the +1 masks of their output channel and count popc(P & plane), lanes 32..63 the -1 masks and count
-// popc(N & plane); one cross-lane add at the end gives sum_b 2^b (popc(P & plane_b) - popc(N & plane_b)).  32 output channels per block
-// column (blockIdx.y).
-typedef const unsigned __attribute__((address_space(4)))* cptr_u32;      // constant address space: uniform loads become s_load
-
+// A wave owns ONE pixel at a time.  Its nine neighbour records (32 dwords each) arrive as FIVE coalesced vector loads -- lane l reads
+// dword l & 31 of the record of tap 2k + (l >> 5) -- requested one pixel ahead; a plane word then reaches all lanes as a scalar operand
+// through v_readlane.  (History: per-lane 16-byte loads of the records sat on the vector-memory issue rate, 72 load instructions per
+// pixel; s_load through the scalar cache had nothing in flight behind its latency: 120 us per 64 x 64 launch either way.)
+// Lane = (output channel o = lane & 31, sign = lane >> 5): lanes 0..31 hold the +1 masks of their output channel and count
+// popc(P & plane), lanes 32..63 the -1 masks and count popc(N & plane); one cross-lane subtraction at the end gives
+// sum_b 2^b (popc(P & plane_b) - popc(N & plane_b)).  32 output channels per block column (blockIdx.y).
 template <int TAPS>
 __global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs p) {
     __shared__ double s_red[2][32];
@@ -360,28 +359,44 @@ __global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs
     const float qs = exp2f((float)(p.bits_i - 1));
     const int HW = p.H * p.W;
     const int stride = gridDim.x * 4;
-    const cptr_u32 planes = (cptr_u32)(uintptr_t)p.planes;
-    double d1 = 0.0, d2 = 0.0;
-    for (int m = blockIdx.x * 4 + wave; m < p.M; m += stride) {      // m is wave-uniform
+    const unsigned* planes = reinterpret_cast<const unsigned*>(p.planes);
+    constexpr int NL = (TAPS + 1) / 2;                    // record loads per pixel
+    auto fetch = [&](int m, unsigned (&v)[NL]) {          // m is wave-uniform
         const int ni = m / HW;
         const int rem = m - ni * HW;
         const int py = rem / p.W, px = rem - py * p.W;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            int row = m;
+            if (TAPS == 9) {
+                const int t = 2 * k + sgn;                // (t = 9 for the upper half of the last load: the zero record)
+                const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+                const int yy = py + dy, xx = px + dx;
+                const bool valid = t < 9 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
+                row = valid ? m + dy * p.W + dx : p.M;                                      // record M is all zero
+            }
+            v[k] = (unsigned)__builtin_nontemporal_load(planes + (size_t)row * (TERN_REC_WORDS * 2) + ol);
+        }
+    };
+    double d1 = 0.0, d2 = 0.0;
+    unsigned vnext[NL];
+    int m = blockIdx.x * 4 + wave;
+    if (m < p.M) fetch(m, vnext);
+    for (; m < p.M; m += stride) {
+        unsigned v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) v[k] = vnext[k];
+        if (m + stride < p.M) fetch(m + stride, vnext);   // the next pixel's records are in flight during this pixel's counting
         int cnt[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            int row = m;
-            if (TAPS == 9) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
-                const int yy = py + dy, xx = px + dx;
-                const bool valid = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
-                row = valid ? m + dy * p.W + dx : p.M;                              // record M is all zero
-            }
-            const cptr_u32 rec = planes + (size_t)row * (TERN_REC_WORDS * 2);
+            const int k = t >> 1, base = (t & 1) * 32;
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int b = 0; b < 7; ++b) {
-                    const unsigned vl = rec[2 * (7 * g + b)], vh = rec[2 * (7 * g + b) + 1];      // scalar operands
+                    const unsigned vl = (unsigned)__builtin_amdgcn_readlane((int)v[k], base + 2 * (7 * g + b));
+                    const unsigned vh = (unsigned)__builtin_amdgcn_readlane((int)v[k], base + 2 * (7 * g + b) + 1);
                     cnt[b] += __popc(Ml[t][g] & vl) + __popc(Mh[t][g] & vh);
                 }
         }
