@@ -334,8 +334,12 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
 // Lane = (output channel o = lane & 31, sign = lane >> 5): lanes 0..31 hold the +1 masks of their output channel and count
 // popc(P & plane), lanes 32..63 the -1 masks and count popc(N & plane); one cross-lane subtraction at the end gives
 // sum_b 2^b (popc(P & plane_b) - popc(N & plane_b)).  32 output channels per block column (blockIdx.y).
+// 16 waves per block, about one block per CU: every block ends in 64 fp64 atomics on the SAME addresses, which the L2 serialises at
+// ~12 ns each -- with 2048 four-wave blocks that tail alone was 40 - 50 us, more than the counting.
+constexpr int TCP_THREADS = 1024;
+
 template <int TAPS>
-__global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs p) {
+__global__ __launch_bounds__(TCP_THREADS) void ternary_conv_planes_kernel(const TernArgs p) {
     __shared__ double s_red[2][32];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs
         }
     const float qs = exp2f((float)(p.bits_i - 1));
     const int HW = p.H * p.W;
-    const int stride = gridDim.x * 4;
+    const int stride = gridDim.x * (TCP_THREADS / 64);
     const unsigned* planes = reinterpret_cast<const unsigned*>(p.planes);
     constexpr int NL = (TAPS + 1) / 2;                    // record loads per pixel
     auto fetch = [&](int m, unsigned (&v)[NL]) {          // m is wave-uniform
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(256) void ternary_conv_planes_kernel(const TernArgs
     };
     double d1 = 0.0, d2 = 0.0;
     unsigned vnext[NL];
-    int m = blockIdx.x * 4 + wave;
+    int m = blockIdx.x * (TCP_THREADS / 64) + wave;
     if (m < p.M) fetch(m, vnext);
     for (; m < p.M; m += stride) {
         unsigned v[NL];
@@ -492,11 +496,11 @@ hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
         int gp = (a.M + 7) / 8;
         if (gp > 8 * num_cus) gp = 8 * num_cus;
         hipLaunchKernelGGL(ternary_planes_kernel, dim3(gp), dim3(256), 0, s, a);
-        int gx = (a.M + 3) / 4;
-        if (gx > 8 * num_cus) gx = 8 * num_cus;
+        int gx = (a.M + TCP_THREADS / 64 - 1) / (TCP_THREADS / 64);
+        if (gx > num_cus) gx = num_cus;
         const dim3 grid(gx, (a.O + 31) / 32);
-        if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_planes_kernel<9>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((ternary_conv_planes_kernel<1>), grid, dim3(256), 0, s, a);
+        if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_planes_kernel<9>), grid, dim3(TCP_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((ternary_conv_planes_kernel<1>), grid, dim3(TCP_THREADS), 0, s, a);
         return hipGetLastError();
     }
     if ((a.C + 63) / 64 > (a.taps == 1 ? TC_MAXG1 : TC_MAXG9)) return hipErrorInvalidValue;
