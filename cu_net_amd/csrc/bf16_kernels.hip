@@ -409,7 +409,7 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
             if (OUTF32 && p.mse_tgt != nullptr) {           // heat-map head with the pixelwise MSE fused in (see conv_kernel)
                 const float ginv = (float)(2.0 * p.mse_inv);
                 const bool colok = col < p.Nout;
-                const bool padcol = !colok && col < p.ldy;
+                const bool padcol = !colok && col < p.mse_ldd;
                 float tv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
                         const float v = acc[nt][r];
                         p.y[(size_t)mm * p.ldy + col] = v;
                         const float d = v - tv[r];
-                        if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, d * ginv);
-                        else p.mse_dout[(size_t)mm * p.ldy + col] = d * ginv;
+                        if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.mse_ldd + col, d * ginv);
+                        else p.mse_dout[(size_t)mm * p.mse_ldd + col] = d * ginv;
                         s1 = fmaf(d, d, s1);
                     } else if (padcol) {
                         if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, 0.f);
@@ -888,6 +888,206 @@ __global__ __launch_bounds__(576) void conv3x3_tapsplit_bf16_kernel(const ConvAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 forward on a ring of activated image rows, bf16 (128 -> 32 channels at 64 x 64 and 32 x 32; the bf16 twin of
+// conv3x3_ring_kernel).  Both other bf16 kernels read every input row through nine shifted taps from L2 -- 226 MB of L2 -> CU traffic
+// per 64 x 64 launch at batch 24 against 25 MB of input: 43 us where the bytes need 6.  Here a 4-wave workgroup walks image rows in
+// steps of RB = 4 tiles' worth (2 rows of 64 pixels / 4 rows of 32): every row enters LDS ONCE -- BatchNorm + ReLU in fp32 and
+// re-rounded on the way in, pixel pitch 136 bf16 (272 bytes: conflict-free 16-byte fragment reads), zero border columns -- and stays
+// for the three output rows that need it.  The whole weight operand (72 KB) sits in LDS as well, so a wave computes a complete
+// 32-pixel x 32-channel tile by itself: 72 MFMAs 32x32x16 whose A fragments are ds_read_b128 of row (y + dy) at pixel (x + dx) --
+// no cross-wave reduction.  The next step's rows are requested from HBM before this step's MFMAs and committed after them.
+constexpr int R16_PITCH = 136;          // bf16 elements per pixel in the ring
+
+template <int WT>                        // W = 32 * WT pixels per image row (WT = 1, 2)
+__global__ __launch_bounds__(256) void conv3x3_ring_bf16_kernel(const ConvArgs p, int steps_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 128;
+    constexpr int W = 32 * WT;
+    constexpr int RB = 4 / WT;                                    // output rows per step (one tile per wave)
+    constexpr int S = RB + 2;                                     // ring slots
+    constexpr int SLOT = (W + 2) * R16_PITCH;                     // elements per slot
+    uint4* Bs = reinterpret_cast<uint4*>(smem);                   // [9][16][32] 16-byte pieces
+    float* sc = reinterpret_cast<float*>(Bs + 9 * 16 * 32);       // [K]
+    float* sh = sc + K;
+    double* redbuf = reinterpret_cast<double*>(sh + K);           // [32][2]
+    u16* ring = reinterpret_cast<u16*>(redbuf + 64);              // S slots
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const Seg sg = p.seg[0];
+    const u16* xin = reinterpret_cast<const u16*>(sg.x);
+    const u16* wB = reinterpret_cast<const u16*>(p.wB);
+    const int H = p.H;
+    const int NH = p.M / W;                                       // image rows in the batch
+
+    {   // weights [tap][K/8][Npad = 32][8] -> LDS, 18 pieces per thread, all requested before the first is stored
+        uint4 v[18];
+#pragma unroll
+        for (int u = 0; u < 18; ++u) v[u] = ldg16(wB + (size_t)(tid + 256 * u) * 8);
+#pragma unroll
+        for (int u = 0; u < 18; ++u) Bs[tid + 256 * u] = v[u];
+    }
+    for (int c = tid; c < K; c += 256) {
+        double mean, istd;
+        if (p.training) {
+            mean = sg.stats[c] / sg.count;
+            double var = sg.stats[sg.C + c] / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            istd = 1.0 / sqrt(var + (double)BN_EPS);
+        } else {
+            mean = (double)p.rmean[c];
+            istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+        }
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+    }
+    if (tid < 64) redbuf[tid] = 0.0;
+    for (int i = tid; i < S * 2 * 17; i += 256) {                 // the two border pixels of every slot stay zero (17 pieces of 16 bytes each)
+        const int slot = i / 34, r = i - slot * 34;
+        const int pix = r < 17 ? 0 : W + 1;
+        reinterpret_cast<uint4*>(ring + (size_t)slot * SLOT + (size_t)pix * R16_PITCH)[r % 17] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    // staging plan: a row is W * 16 pieces of 8 channels; thread t takes pieces t, t + 256, ...: its 8 channels never change
+    const int c8 = tid & 15;
+    float s8[8], h8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s8[e] = sc[8 * c8 + e]; h8[e] = sh[8 * c8 + e]; }
+    constexpr int PPR = W * 16 / 256;                             // pieces per thread and row (4 / 2)
+    constexpr int NLD = PPR * RB;                                 // = 8 loads per thread and step
+    uint4 xv[NLD];
+    auto issue_rows = [&](int g0, int nrows) {                    // rows g0 .. g0 + nrows - 1 (nrows <= RB); rows outside the batch are skipped
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < PPR; ++j) {
+                const int g = g0 + r;
+                const bool ok = r < nrows && g >= 0 && g < NH;
+                const int pix = (tid >> 4) + 16 * j;
+                xv[r * PPR + j] = ldg16(xin + ((size_t)(ok ? g : 0) * W + pix) * sg.ld + 8 * c8);
+            }
+    };
+    auto commit_rows = [&](int g0, int nrows) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int g = g0 + r;
+            if (!(r < nrows && g >= 0 && g < NH)) continue;       // (block-uniform)
+            u16* slot = ring + (size_t)(((g % S) + S) % S) * SLOT;
+#pragma unroll
+            for (int j = 0; j < PPR; ++j) {
+                const uint4 x = xv[r * PPR + j];
+                uint4 t;
+                t.x = pack_bf16(fmaxf(fmaf(bf16_lo(x.x), s8[0], h8[0]), 0.f), fmaxf(fmaf(bf16_hi(x.x), s8[1], h8[1]), 0.f));
+                t.y = pack_bf16(fmaxf(fmaf(bf16_lo(x.y), s8[2], h8[2]), 0.f), fmaxf(fmaf(bf16_hi(x.y), s8[3], h8[3]), 0.f));
+                t.z = pack_bf16(fmaxf(fmaf(bf16_lo(x.z), s8[4], h8[4]), 0.f), fmaxf(fmaf(bf16_hi(x.z), s8[5], h8[5]), 0.f));
+                t.w = pack_bf16(fmaxf(fmaf(bf16_lo(x.w), s8[6], h8[6]), 0.f), fmaxf(fmaf(bf16_hi(x.w), s8[7], h8[7]), 0.f));
+                const int pix = (tid >> 4) + 16 * j;
+                *reinterpret_cast<uint4*>(slot + (size_t)(pix + 1) * R16_PITCH + 8 * c8) = t;
+            }
+        }
+    };
+
+    const int g_begin = blockIdx.x * steps_per_wg * RB;
+    int g_end = g_begin + steps_per_wg * RB;
+    if (g_end > NH) g_end = NH;
+    // the first step needs rows g_begin - 1 .. g_begin + RB: two staging rounds
+    issue_rows(g_begin - 1, 2); commit_rows(g_begin - 1, 2);
+    issue_rows(g_begin + 1, RB); commit_rows(g_begin + 1, RB);
+    __syncthreads();
+
+    const int trow = WT == 2 ? (wave >> 1) : wave;                // this wave's output row within the step ...
+    const int tcol = WT == 2 ? (wave & 1) * 32 : 0;               // ... and first pixel
+    double dsum = 0.0, dsq = 0.0;
+    for (int g0 = g_begin; g0 < g_end; g0 += RB) {
+        const bool more = g0 + RB < g_end;
+        if (more) issue_rows(g0 + RB + 1, RB);                    // rows g0 + RB + 1 .. g0 + 2 RB: in flight across this step's MFMAs
+        const int g = g0 + trow;
+        if (g < g_end) {                                          // (wave-uniform)
+            const int y = g % H;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                if (y + dy < 0 || y + dy >= H) continue;          // zero padding is post-activation: the tap contributes nothing
+                const u16* srow = ring + (size_t)(((g + dy) % S + S) % S) * SLOT;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int tap = (dy + 1) * 3 + (dx + 1);
+                    const u16* ap = srow + (size_t)(tcol + li + dx + 1) * R16_PITCH + 8 * hi;
+                    const uint4* bp = Bs + (size_t)(tap * 16 + hi) * 32 + li;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(ap + 16 * j);
+                        const uint4 b = bp[(size_t)(2 * j) * 32];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+                    }
+                }
+            }
+            // C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            u16* yo = reinterpret_cast<u16*>(p.y) + ((size_t)g * W + tcol) * p.ldy + li;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const unsigned q = pack_bf16(acc[r], 0.f);
+                yo[(size_t)row * p.ldy] = (u16)(q & 0xffffu);
+                const float vr = bf16_lo(q);                      // statistics of what the consumers will read
+                s1 += vr;
+                s2 = fmaf(vr, vr, s2);
+            }
+            dsum += (double)s1;
+            dsq += (double)s2;
+        }
+        __syncthreads();                                          // everyone is done with the rows this step no longer shares
+        if (more) commit_rows(g0 + RB + 1, RB);
+        __syncthreads();
+    }
+    if (p.ystats != nullptr) {
+        const double a1 = dsum + shfl_xor_d16(dsum);
+        const double b1 = dsq + shfl_xor_d16(dsq);
+        if (hi == 0) {
+            atomicAdd(&redbuf[li * 2 + 0], a1);
+            atomicAdd(&redbuf[li * 2 + 1], b1);
+        }
+        __syncthreads();
+        if (tid < 32 && tid < p.Nout) {
+            __hip_atomic_fetch_add(p.ystats + tid, redbuf[tid * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static bool conv3x3_ring_bf16_supported(const ConvArgs& a, int out_f32) {
+    return !out_f32 && a.taps == 9 && a.nseg == 1 && a.K == 128 && a.Kpad == 128 && a.Nout == 32 && a.Npad == 32 && !a.seg[0].ups &&
+           a.seg[0].C == 128 && a.seg[0].ld % 8 == 0 && (a.W == 64 || a.W == 32) && a.M % a.W == 0 && a.ldy >= 32;
+}
+
+static hipError_t launch_conv3x3_ring_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
+    const int WT = a.W / 32, RB = 4 / WT;
+    const int NH = a.M / a.W;
+    const int nsteps = (NH + RB - 1) / RB;
+    int spw = (nsteps + num_cus - 1) / num_cus;                    // steps per workgroup: one workgroup per CU
+    if (spw < 1) spw = 1;
+    const int grid = (nsteps + spw - 1) / spw;
+    const size_t smem = (size_t)9 * 16 * 32 * 16 + (size_t)2 * 128 * 4 + 64 * 8 + (size_t)(RB + 2) * (a.W + 2) * R16_PITCH * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (WT == 2) hipLaunchKernelGGL(conv3x3_ring_bf16_kernel<2>, dim3(grid), dim3(256), smem, s, a, spw);
+    else hipLaunchKernelGGL(conv3x3_ring_bf16_kernel<1>, dim3(grid), dim3(256), smem, s, a, spw);
+    return hipGetLastError();
+}
+
 static hipError_t launch_conv3x3_tapsplit_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
     const int ntiles = a.M / 32;
     static const int bpc = tune_int("CUNET_B16_TS_BPC", 2);         // blocks per CU (38 KB of LDS, 9 waves each)
@@ -990,6 +1190,10 @@ hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStre
         if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
     const int ntiles = a.M / 32;
     // 3x3 (128 -> 32) up to 12 tiles per CU (64 x 64 at batch 24): one tap per wave (tuning builds: CUNET_B16_TS = tiles per CU, 0 = off)
+    // 3x3 (128 -> 32) at 64 x 64 / 32 x 32 with at least two image rows per CU: rows through an LDS ring (tuning builds: CUNET_B16_RING = 0 off)
+    static const int use_ring = tune_int("CUNET_B16_RING", 1);
+    if (use_ring && conv3x3_ring_bf16_supported(a, out_f32) && a.M / a.W >= (a.ring_min_rows > 0 ? a.ring_min_rows : 512))
+        return launch_conv3x3_ring_bf16(a, num_cus, s);
     static const int use_ts = tune_int("CUNET_B16_TS", 12);
     if (use_ts && a.taps == 9 && !out_f32 && a.nseg == 1 && a.K == 128 && a.Nout == 32 && a.Npad == 32 && !a.seg[0].ups && a.ldy % 2 == 0 &&
         ntiles <= (long)use_ts * num_cus)

@@ -78,6 +78,7 @@ struct ConvArgs {
     double* mse_acc;
     double mse_inv;        // 1 / (M * Nout)
     int mse_gbf16;
+    int mse_ldd;           // leading dimension of mse_dout (elements): ldy, or the padded K of a bf16 head gradient (see head_grad_ld)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
                            // planner option conv3x3_ring_min_rows; 0 = the default 512)
     int dbg;               // timing experiments only (CUNET_CONV_DBG): 1 no stats atomics, 4 no MFMA, 32 no B preload,

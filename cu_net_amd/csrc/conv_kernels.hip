@@ -470,7 +470,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
             if (EP == EP_FWD && p.mse_tgt != nullptr) {
                 // heat-map head with the pixelwise MSE fused in (uniform branch): the target values are requested first
                 const float ginv = (float)(2.0 * p.mse_inv);
-                const bool padcol = !colok && col < p.ldy;      // pad columns of d(loss)/d(out) must read as zero downstream
+                const bool padcol = !colok && col < p.mse_ldd;      // pad columns of d(loss)/d(out) must read as zero downstream
                 float tv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -486,8 +486,8 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
                             const float v = acc[nt][r];
                             p.y[(size_t)mm * p.ldy + col] = v;
                             const float d = v - tv[r];
-                            if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, d * ginv);
-                            else p.mse_dout[(size_t)mm * p.ldy + col] = d * ginv;
+                            if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.mse_ldd + col, d * ginv);
+                            else p.mse_dout[(size_t)mm * p.mse_ldd + col] = d * ginv;
                             s1 = fmaf(d, d, s1);
                         } else if (padcol) {
                             if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, 0.f);

@@ -558,16 +558,17 @@ hipError_t launch_transpose(const float* src, float* dst, int N, int C, int HW, 
 template <int GB>      // GB = 1: d(loss)/d(out) is stored as bf16
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                   float* __restrict__ dout, double* loss_acc,
-                                                  long rows, int C, int ld) {
+                                                  long rows, int C, int ld, int ldd) {      // ldd >= ld: pitch of dout, pad columns zero
     __shared__ double wsum[4];
-    const long total = rows * ld;
+    const long total = rows * ldd;
     const double inv = 1.0 / ((double)rows * C);
     const float ginv = (float)(2.0 * inv);
     double acc = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % ld);
+        const long r = i / ldd;
+        const int c = (int)(i - r * ldd);
         float d = 0.f;
-        if (c < C) d = out[i] - tgt[i];
+        if (c < C) d = out[r * ld + c] - tgt[r * ld + c];
         stx1<GB>(dout, (size_t)i, d * ginv);
         acc += (double)d * d;
     }
@@ -583,12 +584,13 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out,
 
 __global__ void loss_finalize_kernel(const double* acc, float* loss) { *loss = (float)(*acc); }
 
-hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld,
+hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld, int ldd,
                       int grad_bf16, int num_cus, hipStream_t s) {
-    long gx = (rows * ld + 255) / 256;
+    if (ldd < ld) ldd = ld;
+    long gx = (rows * ldd + 255) / 256;
     if (gx > 4L * num_cus) gx = 4L * num_cus;
-    if (grad_bf16) hipLaunchKernelGGL(mse_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld);
-    else hipLaunchKernelGGL(mse_kernel<0>, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld);
+    if (grad_bf16) hipLaunchKernelGGL(mse_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld, ldd);
+    else hipLaunchKernelGGL(mse_kernel<0>, dim3((unsigned)gx), dim3(256), 0, s, out, tgt, dout, loss_acc, rows, C, ld, ldd);
     return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t
 hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_stem_bwd(const PoolArgs& a, int pass, float* dgamma, float* dbeta, int num_cus, hipStream_t s);
 hipError_t launch_transpose(const float* src, float* dst, int N, int C, int HW, int ld, int to_nhwc, hipStream_t s);
-hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld,
+hipError_t launch_mse(const float* out, const float* tgt, float* dout, double* loss_acc, long rows, int C, int ld, int ldd,
                       int grad_bf16, int num_cus, hipStream_t s);
 hipError_t launch_loss_finalize(const double* acc, float* loss, hipStream_t s);
 hipError_t launch_running_update(const RunStatEntry* tab, int n, const double* stats_base, float* buffers,

@@ -380,6 +380,16 @@ bool Plan::build(const cunet_cfg& c) {
         }
     }
 
+    // bf16 gradient storage: a head's gradient tensor is padded to the 32-multiple of channels its bf16 MFMA data gradient
+    // contracts over when that fits the tensor's fp32 slot (2 * ld bf16 elements), e.g. K = 68 -> 96
+    for (auto& t : tensors) t.gld16 = t.ld;
+    for (auto& n : nodes)
+        if (n.type == N_CONV && n.head >= 0) {
+            const int kp = convs[n.conv].KpadB;
+            TensorInfo& o = tensors[n.out];
+            if (kp % 8 == 0 && 2 * o.ld >= kp) o.gld16 = kp;
+        }
+
     layout_workspace();
     describe();
     return true;
@@ -574,7 +584,7 @@ void Plan::describe() {
     for (size_t i = 0; i < tensors.size(); ++i) {
         const TensorInfo& t = tensors[i];
         o << (i ? "," : "") << "{\"id\":" << i << ",\"name\":\"" << t.name << "\",\"N\":" << t.N << ",\"H\":" << t.H
-          << ",\"W\":" << t.W << ",\"C\":" << t.C << ",\"ld\":" << t.ld << ",\"act\":" << t.act
+          << ",\"W\":" << t.W << ",\"C\":" << t.C << ",\"ld\":" << t.ld << ",\"gld16\":" << t.gld16 << ",\"act\":" << t.act
           << ",\"grad\":" << t.grad << ",\"stats\":" << t.stats << "}";
     }
     o << "],\"nodes\":[";

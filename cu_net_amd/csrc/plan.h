@@ -28,6 +28,7 @@ struct TensorInfo {
     int64_t act = -1;         // float offset in workspace
     int64_t grad = -1;        // float offset in workspace (training)
     int64_t stats = -1;       // double offset in the zeroed region ([2][C]) or -1
+    int gld16 = 0;            // leading dimension of the gradient tensor when gradient tensors are stored as bf16 (heads: K padded to a 32-multiple)
     int cfirst = 0, ccount = 0;   // slice of Plan::contribs: the conv nodes that read this tensor (backward gather)
 };
 

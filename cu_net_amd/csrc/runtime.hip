@@ -392,6 +392,15 @@ struct Exec {
 
 }  // namespace
 
+// Leading dimension (elements) of the gradient tensor of heat-map head `n`.  fp32 gradients: the tensor's own ld.  bf16 gradient
+// tensors: the K = class_num channels padded with zeros to the 32-multiple the bf16 MFMA data gradient contracts over (68 -> 96), when
+// that fits the tensor's fp32 slot (2 * ld bf16 elements): the head's data gradient then runs on dgrad_bf16_kernel instead of the fp32
+// kernel with its predicated 4-byte loads (84 us per head at 64 x 64, bs 24).
+static int head_grad_ld(const Plan& P, const Node& n, int grad_bf16) {
+    const TensorInfo& o = P.tensors[n.out];
+    return (grad_bf16 && n.head >= 0) ? o.gld16 : o.ld;
+}
+
 // Heat-map head with the pixelwise MSE fused into its epilogue (cunet_loss_mse_fused): target staged in the workspace (NHWC),
 // d(loss)/d(out) into the head's gradient tensor, the squared error into the loss accumulator.
 static void set_fused_mse(cunet_plan* h, const Exec& E, const Node& n, ConvArgs& a) {
@@ -402,6 +411,7 @@ static void set_fused_mse(cunet_plan* h, const Exec& E, const Node& n, ConvArgs&
     a.mse_acc = E.zero + P.loss_acc;
     a.mse_inv = 1.0 / ((double)o.rows() * o.C);
     a.mse_gbf16 = 0;
+    a.mse_ldd = o.ld;
 }
 
 // Gradient of tensor `t`: one gather over the dz slices of the conv nodes that read it (all of them have
@@ -496,15 +506,17 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
             a.training = 1;
             a.xbf16 = E.xmode;
             a.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
-            a.a = E.grad(n.out); a.lda = o.ld;
+            const int gld = head_grad_ld(P, n, E.xmode == 2);      // (a padded bf16 head gradient: see head_grad_ld)
+            a.a = E.grad(n.out); a.lda = gld;
             a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
             a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             static const int dg16 = tune_int("CUNET_NO_DGRAD_BF16", 0) ? 0 : 1;
             bool done = false;
-            if (E.xmode == 2 && dg16 && n.head < 0) {      // bf16 gradient tensors: bf16 MFMA data gradient where the shape allows
+            if (E.xmode == 2 && dg16 && (n.head < 0 || gld != o.ld)) {      // bf16 gradient tensors: bf16 MFMA data gradient where the shape allows
                 ConvArgs b16 = a;
                 b16.wB = reinterpret_cast<const float*>(E.a16 + c.wB);
+                if (n.head >= 0) b16.K = c.KpadB;             // the zero-padded channels are contracted too (zero weights behind them)
                 int slot_;
                 HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3D16 : PC_C1D16, s, slot_));
                 const hipError_t e = launch_dgrad_bf16(b16, cus, s);
@@ -523,7 +535,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
         }
         if (parts & BWD_WGRAD) {   // weight gradient
             WgradArgs w{};
-            w.dy = E.grad(n.out); w.lddy = o.ld; w.Cout = c.Cout;
+            w.dy = E.grad(n.out); w.lddy = head_grad_ld(P, n, E.xmode == 2); w.Cout = c.Cout;
             w.nseg = E.fill_segs(n, w.seg); w.Ccat = n.Ccat;
             w.gamma = h->params + b.gamma; w.beta = h->params + b.beta;
             w.taps = c.taps; w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
@@ -704,7 +716,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
                 t.planes = reinterpret_cast<uint64_t*>(h->ws + P.off_planes);
                 PROF(PC_TERN, 0.0, 4.0 * (double)a.M * (a.K + a.Nout), launch_ternary_conv(t, cus, s));
                 if (fuse_mse)       // (the AND-popcount kernel has no loss epilogue: this head's MSE is its own launch)
-                    HIPCHK(launch_mse(E.act(n.out), E.wsf + P.target_off, E.grad(n.out), E.zero + P.loss_acc, (long)o.rows(), o.C, o.ld, 0, cus, s));
+                    HIPCHK(launch_mse(E.act(n.out), E.wsf + P.target_off, E.grad(n.out), E.zero + P.loss_acc, (long)o.rows(), o.C, o.ld, o.ld, 0, cus, s));
             } else {
                 PROF(c.taps == 9 ? PC_C3F : PC_C1F, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + a.Nout),
                      launch_conv(a, c.taps == 9 ? LD_3X3 : LD_SEG, EP_FWD, cus, s));
@@ -802,9 +814,11 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
             a.ldy = o.ld; a.Nout = c.Cout; a.ystats = (training && !is_head) ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
             if (is_head && training && h->fused_loss_out != nullptr) {
                 set_fused_mse(h, E, n, a);
                 a.mse_gbf16 = training == 2;             // bf16 gradient tensors
+                a.mse_ldd = head_grad_ld(P, n, training == 2);
             }
             int slot_;
             HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3F16 : PC_C1F16, s, slot_));
@@ -848,9 +862,10 @@ int cunet_loss_mse(cunet_plan_t* h, const float* target, float* loss, void* stre
     HIPCHK(launch_transpose(target, tgt, t0.N, t0.C, t0.H * t0.W, t0.ld, 1, s));
     double* acc = E.zero + P.loss_acc;
     HIPCHK(hipMemsetAsync(acc, 0, 8, s));
-    for (int ht : P.head_tensors) {
-        const TensorInfo& t = P.tensors[ht];
-        HIPCHK(launch_mse(E.act(ht), tgt, E.grad(ht), acc, (long)t.rows(), t.C, t.ld, E.xmode == 2, h->num_cus, s));
+    for (const Node& n : P.nodes) {
+        if (n.head < 0) continue;
+        const TensorInfo& t = P.tensors[n.out];
+        HIPCHK(launch_mse(E.act(n.out), tgt, E.grad(n.out), acc, (long)t.rows(), t.C, t.ld, head_grad_ld(P, n, E.xmode == 2), E.xmode == 2, h->num_cus, s));
     }
     HIPCHK(launch_loss_finalize(acc, loss, s));
     h->loss_done = 1;

@@ -150,7 +150,8 @@ class _BoundPlan:
         off = self.handle.tensor_offset(name, 1 if grad else 0)
         rows = t['N'] * t['H'] * t['W']
         if grad and self.grad_bf16 and self._grad_is_bf16(d, t):       # a bf16 gradient tensor sits in the first half of its slot
-            flat = self.workspace[off: off + rows * t['ld'] * 2].view(torch.bfloat16).view(t['N'], t['H'], t['W'], t['ld'])
+            gld = t.get('gld16', t['ld'])                               # (heads: K padded to a 32-multiple, zeros behind it)
+            flat = self.workspace[off: off + rows * gld * 2].view(torch.bfloat16).view(t['N'], t['H'], t['W'], gld)
         else:
             flat = self.workspace[off: off + rows * t['ld'] * 4].view(torch.float32).view(t['N'], t['H'], t['W'], t['ld'])
         flat.zero_()
@@ -172,7 +173,9 @@ class _BoundPlan:
         rows = t['N'] * t['H'] * t['W']
         if grad and self.grad_bf16 and self._grad_is_bf16(d, t):
             off = self.handle.tensor_offset(name, 1)
-            flat = self.workspace[off: off + rows * t['ld'] * 2].view(torch.bfloat16).float()
+            gld = t.get('gld16', t['ld'])
+            flat = self.workspace[off: off + rows * gld * 2].view(torch.bfloat16).float()
+            return flat.view(t['N'], t['H'], t['W'], gld)[..., :t['C']].permute(0, 3, 1, 2).contiguous()
         elif self.bf16 and not grad and self._in_bf16_arena(d, t):
             base = (self.handle.workspace_bytes(self.training_ws) + 255) // 256 * 256      # where the bf16 arena starts
             flat = self.workspace[base + 2 * t['act']: base + 2 * (t['act'] + rows * t['ld'])].view(torch.bfloat16).float()

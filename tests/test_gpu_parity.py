@@ -482,3 +482,40 @@ def test_bf16_activation_train_step_tracks_fp32():
         assert abs(b[0] - a[0]) <= 2e-2 * a[0], (mode, a[0], b[0])
         assert b[-1] < b[0]
         assert abs((b[0] - b[-1]) - (a[0] - a[-1])) <= 0.1 * (a[0] - a[-1]), (mode, a, b)
+
+
+def test_bf16_3x3_row_ring_agrees_with_the_other_bf16_kernels(ring_3x3_everywhere):
+    """bf16 storage: the 3x3 forward of the 64- and 32-pixel-wide levels on conv3x3_ring_bf16_kernel (rows through an LDS ring, the
+    whole weight operand in LDS, a wave per tile) against the tap-split / weight-stationary bf16 kernels on the same state, N = 3
+    (192 image rows: ragged last workgroup).  Same bf16 operands, fp32 accumulation in another order: an output within summation
+    noise of a bf16 rounding boundary may round the other way -- at most one bf16 step on a small fraction of the elements; the
+    batch statistics that ride on the epilogue agree to fp32 accuracy."""
+    from cu_net_amd._lib import set_planner_option
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=53)
+    x, _ = O.synthetic_batch(4, 16, 256, seed=54)        # (the bf16 kernels need 32-row tiles at the neck: N * 16 rows)
+    outs = {}
+    for mode in ('ring', 'plain'):
+        set_planner_option('conv3x3_ring_min_rows', 2 if mode == 'ring' else 1 << 30)
+        net = cu_net_amd.create_cu_net(**cfg)
+        net.load_state_dict(st)
+        net = net.cuda().train()
+        plan = net._get_plan(4, 256, 256, True, bf16=True)
+        plan.forward_bf16(x.cuda(), 1, want_outputs=False)
+        torch.cuda.synchronize()
+        desc = plan.handle.describe()
+        got = {}
+        for wdt in (64, 32):
+            nd = [n for n in desc['nodes'] if n['op'] == 'conv' and n['taps'] == 9 and desc['tensors'][n['out']]['W'] == wdt][0]
+            got[wdt] = plan.debug_tensor(desc['tensors'][nd['out']]['name']).cpu()
+        outs[mode] = (got, {k: v.clone().cpu() for k, v in net.state_dict().items() if 'running' in k})
+    for wdt in (64, 32):
+        a, b = outs['ring'][0][wdt], outs['plain'][0][wdt]
+        mag = float(b.abs().max())
+        d = (a - b).abs()
+        assert float(d.max()) <= 2 ** -7 * mag, (wdt, float(d.max()), mag)
+        if wdt == 64:       # the first 3x3 node: identical inputs on both sides
+            assert float((d > 0).float().mean()) <= 2e-3, (wdt, float((d > 0).float().mean()))
+    for k, v in outs['plain'][1].items():
+        assert float((outs['ring'][1][k] - v).norm() / (v.norm() + 1e-12)) <= 2e-2, k
