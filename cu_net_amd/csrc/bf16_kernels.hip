@@ -427,8 +427,8 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
                         else p.mse_dout[(size_t)mm * p.mse_ldd + col] = d * ginv;
                         s1 = fmaf(d, d, s1);
                     } else if (padcol) {
-                        if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.ldy + col, 0.f);
-                        else p.mse_dout[(size_t)mm * p.ldy + col] = 0.f;
+                        if (p.mse_gbf16) stx1<1>(p.mse_dout, (size_t)mm * p.mse_ldd + col, 0.f);
+                        else p.mse_dout[(size_t)mm * p.mse_ldd + col] = 0.f;
                     }
                 }
             } else if (col < p.Nout) {

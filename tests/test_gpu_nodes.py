@@ -201,8 +201,11 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
             gamma = st[nd['bn'] + '.weight'].clone().requires_grad_(True)
             beta = st[nd['bn'] + '.bias'].clone().requires_grad_(True)
             wt = st[nd['conv'] + '.weight'].clone()
-            if gb and nd.get('head', -1) < 0:
-                wt = wt.bfloat16().float()              # the bf16-MFMA data gradient contracts with bf16-rounded weights
+            head_on_bf16 = nd.get('head', -1) >= 0 and T[nd['out']].get('gld16', T[nd['out']]['ld']) != T[nd['out']]['ld']
+            if gb and (nd.get('head', -1) < 0 or head_on_bf16):
+                # the bf16-MFMA data gradient contracts with bf16-rounded weights (heads: when their gradient tensor is padded to
+                # the MFMA's K, i.e. whenever it fits the tensor's slot -- the operand their bf16 forward multiplied as well)
+                wt = wt.bfloat16().float()
             wt.requires_grad_(True)
             act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
             if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
