@@ -13,15 +13,21 @@ import sys
 
 import pandas as pd
 
-CLASSES = [
+CLASSES = [      # first match wins: the bf16-MFMA kernels carry bench.py's *_bf16 class names
     (r'wgrad3_stem_kernel', 'stem_bwd_weight'),
-    (r'wgrad3_3x3_kernel|wgrad3_3x3_bf16_kernel', 'conv3x3_bwd_weight'),
-    (r'wgrad3_kernel|wgrad3_bf16_kernel', 'conv1x1_bwd_weight'),
+    (r'wgrad3_3x3_bf16_kernel', 'conv3x3_bwd_weight_bf16'),
+    (r'wgrad3_bf16_kernel', 'conv1x1_bwd_weight_bf16'),
+    (r'wgrad3_3x3_kernel', 'conv3x3_bwd_weight'),
+    (r'wgrad3_kernel', 'conv1x1_bwd_weight'),
     (r'wgrad_reduce_kernel', 'wgrad_partial_reduce'),
     (r'wgrad2_stem_kernel', 'stem_bwd_weight'),
     (r'wgrad2_kernel', 'conv1x1_bwd_weight'),
     (r'wgrad_kernel<\(?cunet::\)?1|wgrad_kernel<1,', 'conv3x3_bwd_weight'),
     (r'wgrad_kernel<2,', 'stem_bwd_weight'),
+    (r'dgrad_bf16_kernel<1,', 'conv1x1_bwd_data_bf16'),
+    (r'dgrad_bf16_kernel<9,', 'conv3x3_bwd_data_bf16'),
+    (r'conv3x3_tapsplit_bf16_kernel|conv3x3_ring_bf16_kernel|conv_bf16_kernel<9,', 'conv3x3_fwd_bf16'),
+    (r'conv_bf16_kernel<1,', 'conv1x1_fwd_bf16'),
     (r'conv3x3_tapsplit_kernel|conv3x3_ring_kernel', 'conv3x3_fwd'),
     (r'conv_kernel<0, 0,|conv1x1_splitk_kernel', 'conv1x1_fwd'),
     (r'conv_kernel<1, 0,', 'conv3x3_fwd'),
@@ -29,8 +35,9 @@ CLASSES = [
     (r'conv_kernel<2, 1,', 'conv1x1_bwd_data'),
     (r'conv_kernel<3, 1,', 'conv3x3_bwd_data'),
     (r'grad_gather_kernel', 'bn_bwd_apply'),
-    (r'pool_fwd_kernel<0>', 'pool_fwd'),
+    (r'pool_fwd_kernel<0>|pool_bf16_kernel', 'pool_fwd'),
     (r'pool_bwd_kernel', 'pool_bwd'),
+    (r'ternary_conv_planes_kernel|ternary_planes_kernel|ternary_conv_kernel', 'conv_fwd_popcount'),
 ]
 
 
@@ -50,6 +57,14 @@ def load(d, counter):
     return cc.groupby('cls').Counter_Value.agg(['mean', 'size'])
 
 
+def step_total(d, counter):
+    """Sum of the counter over every kernel of the run / number of steps (one repack_kernel launch per step)."""
+    cc = pd.read_csv(glob.glob(d + '/*counter_collection.csv')[0])
+    cc = cc[cc.Counter_Name == counter]
+    steps = int(cc['Kernel_Name'].str.contains('repack_kernel').sum()) or 1
+    return float(cc.Counter_Value.sum()) * 1024.0 / steps, steps
+
+
 rd = load(sys.argv[1], 'FETCH_SIZE')
 wr = load(sys.argv[2], 'WRITE_SIZE')
 out = {}
@@ -61,6 +76,11 @@ for cls in rd.index:
 meta = {'source': 'rocprofv3 --pmc FETCH_SIZE (KiB, x2 on gfx950) and --pmc WRITE_SIZE (KiB), separate passes, '
                   'bench.py --steps 3 --warmup 2 --no-also', 'workload': sys.argv[4] if len(sys.argv) > 4 else '2,68,24,f32',
         'commit': sys.argv[5] if len(sys.argv) > 5 else 'unknown', 'classes': out}
+ft, fs = step_total(sys.argv[1], 'FETCH_SIZE')
+wt, wsteps = step_total(sys.argv[2], 'WRITE_SIZE')
+meta['step_total'] = {'fetch_bytes_per_step': round(2.0 * ft), 'write_bytes_per_step': round(wt), 'hbm_bytes_per_step': round(2.0 * ft + wt),
+                      'steps_sampled': fs, 'note': 'every kernel of the step (FETCH_SIZE x2), incl. warm-up steps'}
+print(f"whole step: fetch {2.0 * ft / 1e9:.2f} GB + write {wt / 1e9:.2f} GB = {(2.0 * ft + wt) / 1e9:.2f} GB over {fs} steps sampled")
 json.dump(meta, open(sys.argv[3], 'w'), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch']):
     print(f"{k:22s} fetch {v['fetch_bytes_per_launch'] / 1e6:9.2f} MB  write {v['write_bytes_per_launch'] / 1e6:9.2f} MB  per launch ({v['launches_sampled']} launches)")
