@@ -28,7 +28,9 @@ def main():
     from cu_net_amd.parallel import shard_batch
     from cu_net_amd.trainer import FusedTrainer
     from oracle import cunet_ref as O
-    from tests.test_gpu_dp import CFG, GLOBAL_BATCH, HW, make_inputs
+    from tests.test_gpu_dp import CASES, make_inputs
+    case = os.environ.get('CUNET_DP_CASE', 'toy')
+    CFG, GLOBAL_BATCH, HW = CASES[case]
     spec = O.Spec(**CFG)
     st = O.init_state(spec, seed=61 + 7 * rank)           # rank 1 starts from other parameters: the broadcast must fix that
     net = cu_net_amd.create_cu_net(**CFG)
@@ -37,7 +39,7 @@ def main():
     tr = FusedTrainer(net, process_group=dist.group.WORLD, overlap=True)
     tr.broadcast_parameters(0)
     p0 = net._param_arena.detach().cpu().clone()
-    x, t = make_inputs()
+    x, t = make_inputs(case)
     lo, hi = shard_batch(GLOBAL_BATCH, rank, world)
     loss = tr.step(x[lo:hi].to(dev), t[lo:hi].to(dev))
     torch.cuda.synchronize(dev)
