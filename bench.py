@@ -4,6 +4,7 @@
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher: bench.py starts the N ranks itself through torch.distributed.run)
 
 A "step" is the reference's training iteration (cu-net.py:171-183): forward of
 create_cu_net(4, 32, 128, K, L, order, loss_num), sum of per-head pixelwise MSE, backward, RMSprop
@@ -18,8 +19,10 @@ stream.  `roofline` describes the dominant kernel class (chosen from
 achieved = algorithmic FLOPs of its launches / their HIP-event time measured inside the timed region on the
 launch stream.  `cpu_baseline` times the CPU oracle (oracle/cunet_ref.py, a restatement of the reference pinned
 bit-exact to it) on this host for a bounded sample.  At N=1 the same run also times the other single-GPU
-headline configurations of BASELINE.json -- config 3 (CU-Net-8, bf16 storage) and config 5 (CU-Net-16, binary
-weights) -- and attaches them as `also: [...]` (BASELINE's metric names "CU-Net-2 and CU-Net-8").
+headline configurations of BASELINE.json -- config 3 (CU-Net-8, bf16 storage), config 5 (CU-Net-16, binary weights; MFMA and
+AND-popcount forward) -- and the forward-only (inference) rates, attached as `also: [...]` (BASELINE's metric names "CU-Net-2 and
+CU-Net-8"); at N > 1 the `also` entries are BASELINE config 4 (CU-Net-8, K = 16, 24 images per rank, RCCL all-reduce).
+It measures the SHIPPED library only (CUNET_LIB_PATH is refused; the loaded path is printed and reported as `library_path`).
 """
 import argparse
 import json
