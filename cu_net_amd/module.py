@@ -400,7 +400,17 @@ class CUNet(nn.Module):
         self._check_aliasing()
         x = x.contiguous()
         n, _, h, w = x.shape
-        return self._get_plan(n, h, w, False, bf16=True).forward_bf16(x)
+        # the bf16 kernels work on whole 32-row tiles at every level: N * (H/64) * (W/64) must be a multiple of 32 at the neck.  In
+        # eval mode images do not interact (running statistics), so a batch that does not satisfy it -- e.g. ONE 256 x 256 image --
+        # is padded with zero images and the extra heat maps are dropped
+        per = (h // 64) * (w // 64)
+        pad = 0
+        while ((n + pad) * per) % 32:
+            pad += 1
+        if pad:
+            x = torch.cat([x, x.new_zeros((pad,) + tuple(x.shape[1:]))], 0)
+        outs = self._get_plan(n + pad, h, w, False, bf16=True).forward_bf16(x)
+        return [o[:n] for o in outs] if pad else outs
 
     def forward(self, x):
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:

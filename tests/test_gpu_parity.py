@@ -519,3 +519,22 @@ def test_bf16_3x3_row_ring_agrees_with_the_other_bf16_kernels(ring_3x3_everywher
             assert float((d > 0).float().mean()) <= 2e-3, (wdt, float((d > 0).float().mean()))
     for k, v in outs['plain'][1].items():
         assert float((outs['ring'][1][k] - v).norm() / (v.norm() + 1e-12)) <= 2e-2, k
+
+
+def test_bf16_inference_of_a_single_image():
+    """`net.forward_bf16` on ONE 256 x 256 image: the bf16 kernels need whole 32-row tiles at the 4 x 4 neck (N * 16 rows), so the
+    binding pads the batch with a zero image and drops its heat maps -- eval-mode images do not interact, the result equals the
+    first image's heat maps in a batch of two."""
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=55)
+    x, _ = O.synthetic_batch(2, 16, 256, seed=56)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        one = net.forward_bf16(x[:1].cuda())
+        two = net.forward_bf16(x.cuda())
+    assert len(one) == 2 and tuple(one[0].shape) == (1, 16, 64, 64)
+    for a, b in zip(one, two):
+        assert torch.equal(a[0], b[0])
