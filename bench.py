@@ -177,10 +177,12 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
                 f.write('\n'.join(lines) + '\n')
 
     # ---- timed region: exactly `steps` steps; HIP events only around the dominant class, one event per step
-    # A timed HIP event is a 3.4 us marker kernel on the stream: around every launch of a main-stream class that is
-    # ~1.2 ms per CU-Net-8 step.  The dominant class is therefore bracketed in every EVENT_STRIDE-th step only (its
-    # average launch duration is still measured live, inside the timed region, on the stream the kernel runs on).
-    EVENT_STRIDE = 4
+    # A timed HIP event is a marker packet on the stream and the kernel behind it waits for it to retire: ~6 us per event when the
+    # class runs on the caller's stream (the 1x1 data gradient: 47 launches x 2 events = 0.5 ms of a 7.2 ms CU-Net-2 step, ~1.2 ms
+    # of a CU-Net-8 step).  The dominant class is therefore bracketed in TWO steps of the timed region only (the first and the
+    # middle one): its average launch duration is still measured live, inside the timed region, on the stream the kernel runs on,
+    # over ~100 - 500 launches, and `value` is not taxed by the measurement.
+    EVENT_STRIDE = max(4, steps // 2)
     plan.handle.profile_reset()
     cls_index = plan.handle.profile_class_index(dominant)
     use_events = not os.environ.get('CUNET_BENCH_NO_CLASS_EVENTS')      # (tools only: how much do the per-launch events cost?)
