@@ -251,7 +251,7 @@ hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H
 constexpr int B16_MAX_WAVES = 16;        // <= 128 VGPRs per lane (the widest variant uses 118)
 
 template <int TAPS, int NT, int OUTF32>
-__global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;
     const int kq8 = p.Kpad >> 3;
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
-    int bx = blockIdx.x, by = blockIdx.y, gxd = gridDim.x;      // see conv_kernel: column slices of a row block on one XCD
+    int bx = bidx, by = bidy, gxd = gdimx;      // see conv_kernel: column slices of a row block on one XCD
     if (p.xcd_gx > 0) {
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int L = bidx, xcd = L & 7, slot = L >> 3;
         by = slot % p.xcd_gy;
         bx = (slot / p.xcd_gy) * 8 + xcd;
         gxd = p.xcd_gx;
@@ -487,6 +487,16 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
     }
 }
 
+template <int TAPS, int NT, int OUTF32>
+__global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const ConvArgs p) {
+    conv_bf16_body<TAPS, NT, OUTF32>(p, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// two problems of one shape in one launch (the ahead / skip adapters: see conv_pair_kernel)
+template <int TAPS, int NT, int OUTF32>
+__global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_pair_kernel(const ConvPair q) {
+    conv_bf16_body<TAPS, NT, OUTF32>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Data gradient with bf16 MFMA (bf16 gradient-tensor storage, FusedTrainer(bf16_grads=True)):
 //   dz[m][c] = relu'(BN(x)[m][c]) * sum_{tap, n} dY[m + tap][n] * W[n][c][flip(tap)]
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const Con
 struct Grp16 { const u16* ptr; int ld; int ups; };
 
 template <int TAPS, int NT>
-__global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const ConvArgs p) {
+__device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;
     const int kq8 = p.Kpad >> 3;
@@ -518,9 +528,9 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
-    int bx = blockIdx.x, by = blockIdx.y, gxd = gridDim.x;      // see conv_kernel: column slices of a row block on one XCD
+    int bx = bidx, by = bidy, gxd = gdimx;      // see conv_kernel: column slices of a row block on one XCD
     if (p.xcd_gx > 0) {
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int L = bidx, xcd = L & 7, slot = L >> 3;
         by = slot % p.xcd_gy;
         bx = (slot / p.xcd_gy) * 8 + xcd;
         gxd = p.xcd_gx;
@@ -761,6 +771,15 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const Co
             }
         }
     }
+}
+
+template <int TAPS, int NT>
+__global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const ConvArgs p) {
+    dgrad_bf16_body<TAPS, NT>(p, blockIdx.x, blockIdx.y, gridDim.x);
+}
+template <int TAPS, int NT>
+__global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_pair_kernel(const ConvPair q) {
+    dgrad_bf16_body<TAPS, NT>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1102,7 +1121,30 @@ static size_t dgrad_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
 }
 
 template <int TAPS, int NT>
-static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
+static hipError_t launch_dg16_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    if constexpr (TAPS == 1) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_pair_kernel<TAPS, NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        ConvPair q;
+        q.a[0] = a;
+        q.a[1] = b;
+        copy_launch_geometry(q.a[1], a);
+        grid.z = 2;
+        hipLaunchKernelGGL((dgrad_bf16_pair_kernel<TAPS, NT>), grid, dim3(threads), smem, s, q);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+template <int TAPS, int NT>
+static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* pb = nullptr) {
+    if (pb) return launch_dg16_pair_inst<TAPS, NT>(a, *pb, grid, threads, smem, s);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_kernel<TAPS, NT>),
@@ -1129,7 +1171,16 @@ static bool dgrad_bf16_plan(int NT, int taps, int Kpad, int Ccat, int& bpc, size
     return false;
 }
 
-hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
+static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, int num_cus_all, hipStream_t s);
+hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) { return launch_dgrad_bf16_impl(a, nullptr, num_cus, s); }
+// a and b in one launch; hipErrorNotSupported (nothing launched) when they cannot share one
+hipError_t launch_dgrad_bf16_pair(const ConvArgs& a, const ConvArgs& b, int num_cus, hipStream_t s) {
+    if (!conv_pairable(a, b) || a.taps != 1) return hipErrorNotSupported;
+    return launch_dgrad_bf16_impl(a, &b, num_cus, s);
+}
+
+static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, int num_cus_all, hipStream_t s) {
+    const int num_cus = pb ? num_cus_all / 2 : num_cus_all;      // a pair: each problem on half of the chip
     if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9) || (a.W & 3) || a.lda % 8 || a.Nout % 8 || a.ldy % 8) return hipErrorInvalidValue;
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
@@ -1162,8 +1213,8 @@ hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s) {
     dim3 grid1 = grid;
     b.xcd_gx = b.xcd_gy = 0;
     if (gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid1 = dim3(8 * ((gx + 7) / 8) * gy, 1); }
-    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(b, grid1, threads, smem, s) : launch_dg16_inst<1, 1>(b, grid1, threads, smem, s);
-    return NT == 2 ? launch_dg16_inst<9, 2>(b, grid1, threads, smem, s) : launch_dg16_inst<9, 1>(b, grid1, threads, smem, s);
+    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(b, grid1, threads, smem, s, pb) : launch_dg16_inst<1, 1>(b, grid1, threads, smem, s, pb);
+    return NT == 2 ? launch_dg16_inst<9, 2>(b, grid1, threads, smem, s, pb) : launch_dg16_inst<9, 1>(b, grid1, threads, smem, s, pb);
 }
 
 static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
@@ -1171,7 +1222,30 @@ static size_t conv_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
 }
 
 template <int TAPS, int NT, int OUTF32>
-static hipError_t launch_b16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
+static hipError_t launch_b16_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    if constexpr (TAPS == 1 && OUTF32 == 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_pair_kernel<TAPS, NT, OUTF32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        ConvPair q;
+        q.a[0] = a;
+        q.a[1] = b;
+        copy_launch_geometry(q.a[1], a);
+        grid.z = 2;
+        hipLaunchKernelGGL((conv_bf16_pair_kernel<TAPS, NT, OUTF32>), grid, dim3(threads), smem, s, q);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+template <int TAPS, int NT, int OUTF32>
+static hipError_t launch_b16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* pb = nullptr) {
+    if (pb) return launch_b16_pair_inst<TAPS, NT, OUTF32>(a, *pb, grid, threads, smem, s);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TAPS, NT, OUTF32>),
@@ -1184,7 +1258,16 @@ static hipError_t launch_b16_inst(const ConvArgs& a, dim3 grid, int threads, siz
 }
 
 // a.seg[*].x, a.wB: bf16 data behind float-typed pointers; a.y: bf16 (out_f32 = 0) or fp32 (out_f32 = 1)
-hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStream_t s) {
+static hipError_t launch_conv_bf16_impl(const ConvArgs& a, const ConvArgs* pb, int out_f32, int num_cus_all, hipStream_t s);
+hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStream_t s) { return launch_conv_bf16_impl(a, nullptr, out_f32, num_cus, s); }
+// a and b (1x1, bf16 out) in one launch; hipErrorNotSupported (nothing launched) when they cannot share one
+hipError_t launch_conv_bf16_pair(const ConvArgs& a, const ConvArgs& b, int num_cus, hipStream_t s) {
+    if (!conv_pairable(a, b) || a.taps != 1) return hipErrorNotSupported;
+    return launch_conv_bf16_impl(a, &b, 0, num_cus, s);
+}
+
+static hipError_t launch_conv_bf16_impl(const ConvArgs& a, const ConvArgs* pb, int out_f32, int num_cus_all, hipStream_t s) {
+    const int num_cus = pb ? num_cus_all / 2 : num_cus_all;      // a pair: each problem on half of the chip
     if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
@@ -1227,7 +1310,7 @@ hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStre
     if (xcd_fwd && gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid = dim3(8 * ((gx + 7) / 8) * gy, 1); }
     const int threads = (waves < 4 ? 4 : waves) * 64;
 #define CUNET_B16(T, N) \
-    if (a.taps == T && NT == N) return out_f32 ? launch_b16_inst<T, N, 1>(b, grid, threads, smem, s) : launch_b16_inst<T, N, 0>(b, grid, threads, smem, s);
+    if (a.taps == T && NT == N) return out_f32 ? launch_b16_inst<T, N, 1>(b, grid, threads, smem, s, pb) : launch_b16_inst<T, N, 0>(b, grid, threads, smem, s, pb);
     CUNET_B16(1, 1) CUNET_B16(1, 2) CUNET_B16(1, 4) CUNET_B16(9, 1) CUNET_B16(9, 2) CUNET_B16(9, 4)
 #undef CUNET_B16
     return hipErrorInvalidValue;

@@ -86,6 +86,25 @@ struct ConvArgs {
                            // element loop is a branch around a load and serialises it)
 };
 
+// two problems of one shape for one launch (the *_pair_kernel variants: blockIdx.z picks the element)
+struct ConvPair { ConvArgs a[2]; };
+
+// fields the launcher derives (a pair shares them: the two problems have one shape)
+inline void copy_launch_geometry(ConvArgs& b, const ConvArgs& a) {
+    b.wshift = a.wshift; b.hwshift = a.hwshift; b.any_ups = a.any_ups; b.xcd_gx = a.xcd_gx; b.xcd_gy = a.xcd_gy; b.dbg = a.dbg;
+}
+
+// Two problems can share a launch when everything that shapes the grid, the LDS layout and the code path agrees.
+inline bool conv_pairable(const ConvArgs& a, const ConvArgs& b) {
+    if (a.nseg != b.nseg || a.Ccat != b.Ccat || a.K != b.K || a.taps != b.taps || a.Kpad != b.Kpad || a.Npad != b.Npad || a.Nout != b.Nout ||
+        a.M != b.M || a.H != b.H || a.W != b.W || a.xbf16 != b.xbf16 || a.qin_bits != b.qin_bits || a.training != b.training || a.lda != b.lda ||
+        a.mse_tgt || b.mse_tgt)
+        return false;
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C != b.seg[i].C || a.seg[i].ld != b.seg[i].ld || a.seg[i].ups != b.seg[i].ups) return false;
+    return true;
+}
+
 struct WgradArgs {
     const float* dy;       // [M][lddy]
     int lddy;

@@ -29,8 +29,10 @@ namespace cunet {
 
 constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
 
-template <int LD, int EP, int NT, bool FAST, int XBG = 0>      // EP_BWD only: 1 = x of the concat is bf16, 2 = x, dY and dz are bf16
-__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
+// (the body is a device function of (arguments, block coordinates): conv_kernel runs it on one problem, conv_pair_kernel on the
+// problem blockIdx.z selects out of two)
+template <int LD, int EP, int NT, bool FAST, int XBG>           // XBG, EP_BWD only: 1 = x of the concat is bf16, 2 = x, dY and dz are bf16
+__device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
     constexpr int XB = XBG != 0;                     // storage of x
     constexpr int GB = (XBG == 2 && (LD == LD_PLAIN || LD == LD_PLAIN3)) ? 1 : 0;      // storage of the gradient tensors
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,9 +59,9 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     const int li = lane & 31;
     const int hi = lane >> 5;
     // block -> (row block bx of gxd, column slice by).  With xcd_gx > 0 the launch is 1-D and the slices of a row block sit on one XCD.
-    int bx = blockIdx.x, by = blockIdx.y, gxd = gridDim.x;
+    int bx = bidx, by = bidy, gxd = gdimx;
     if (p.xcd_gx > 0) {
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int L = bidx, xcd = L & 7, slot = L >> 3;
         by = slot % p.xcd_gy;
         bx = (slot / p.xcd_gy) * 8 + xcd;
         gxd = p.xcd_gx;
@@ -571,6 +573,19 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
     }
 }
 
+template <int LD, int EP, int NT, bool FAST, int XBG = 0>
+__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
+    conv_body<LD, EP, NT, FAST, XBG>(p, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// Two convolutions of ONE shape in one launch -- the ahead and the skip adapter of a down block read the same concat
+// (models/cu_net.py:139-142), and their data gradients are adjacent in the backward: gridDim.z = 2, blockIdx.z picks the problem
+// (its own weights, BatchNorm, output and statistics), each on half of the workgroups a single launch would use.
+template <int LD, int EP, int NT, bool FAST, int XBG = 0>
+__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_pair_kernel(const ConvPair q) {
+    conv_body<LD, EP, NT, FAST, XBG>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 forward, tap-split (models/cu_net.py:45-48,62: norm2 -> relu2 -> conv2, 128 -> 32 channels).
 // The weight-stationary kernel above walks all 9 taps x K/32 chunks in ONE wave: 36 dependent
@@ -918,7 +933,7 @@ static hipError_t launch_conv3x3_ring(const ConvArgs& a, int num_cus, hipStream_
 // <= 48 MFMAs, and the four partial tiles meet in LDS, where wave 0 adds them, stores the tile and the output statistics.
 constexpr int SK_MAXCH = 3;             // chunks per wave: K <= 384
 
-__global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv1x1_splitk_body(const ConvArgs& p, const int bidx, const int bidy) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                 // [3][1024]
     float* sc = part + 3 * 1024;                                  // [Ccat]
@@ -928,9 +943,9 @@ __global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const ConvArgs p) {
     const int wave = tid >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = bidx, by = bidy;
     if (p.xcd_gx > 0) {                                           // column slices of a row tile on one XCD (see conv_kernel)
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int L = bidx, xcd = L & 7, slot = L >> 3;
         by = slot % p.xcd_gy;
         bx = (slot / p.xcd_gy) * 8 + xcd;
         if (bx >= p.xcd_gx) return;
@@ -1036,6 +1051,9 @@ __global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const ConvArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const ConvArgs p) { conv1x1_splitk_body(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void conv1x1_splitk_pair_kernel(const ConvPair q) { conv1x1_splitk_body(q.a[blockIdx.z], blockIdx.x, blockIdx.y); }
+
 static bool conv1x1_splitk_supported(const ConvArgs& a, int num_cus) {
     if (a.taps != 1 || a.K % 32 || a.K != a.Kpad || a.K < 128 || a.K > 32 * 4 * SK_MAXCH || a.M % 32 || a.qin_bits || a.xbf16 || a.mse_tgt) return false;
     for (int i = 0; i < a.nseg; ++i)
@@ -1044,7 +1062,7 @@ static bool conv1x1_splitk_supported(const ConvArgs& a, int num_cus) {
     return blocks <= 3L * num_cus;                                // everything resident at once: the launch is one round of blocks
 }
 
-static hipError_t launch_conv1x1_splitk(const ConvArgs& a_in, hipStream_t s) {
+static hipError_t launch_conv1x1_splitk(const ConvArgs& a_in, hipStream_t s, const ConvArgs* b_in = nullptr) {
     ConvArgs a = a_in;
     set_geometry_shifts(a);
     const int gx = a.M / 32, gy = (a.Nout + 31) / 32;
@@ -1052,7 +1070,16 @@ static hipError_t launch_conv1x1_splitk(const ConvArgs& a_in, hipStream_t s) {
     a.xcd_gx = a.xcd_gy = 0;
     if (gy > 1) { a.xcd_gx = gx; a.xcd_gy = gy; grid = dim3(8 * ((gx + 7) / 8) * gy, 1); }
     const size_t smem = (size_t)3 * 1024 * 4 + (size_t)a.Ccat * 8;
-    hipLaunchKernelGGL(conv1x1_splitk_kernel, grid, dim3(256), smem, s, a);
+    if (b_in) {
+        ConvPair q;
+        q.a[0] = a;
+        q.a[1] = *b_in;
+        copy_launch_geometry(q.a[1], a);
+        grid.z = 2;
+        hipLaunchKernelGGL(conv1x1_splitk_pair_kernel, grid, dim3(256), smem, s, q);
+    } else {
+        hipLaunchKernelGGL(conv1x1_splitk_kernel, grid, dim3(256), smem, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -1067,8 +1094,32 @@ constexpr size_t CONV_TEPI_TILE = 32 * 36 * 4;             // per wave: the data
 
 constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 
+// pairs exist for the shapes the adapters take: the nothing-ragged 1x1 forward and its fp32 data gradient
+template <int LD, int EP, int NT, bool FAST, int XB>
+static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
+    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && NT == 1 && XB == 0))) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<LD, EP, NT, FAST, XB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BUDGET);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        ConvPair q;
+        q.a[0] = a;
+        q.a[1] = b;
+        copy_launch_geometry(q.a[1], a);
+        grid.z = 2;
+        hipLaunchKernelGGL((conv_pair_kernel<LD, EP, NT, FAST, XB>), grid, dim3(threads), smem, s, q);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <int LD, int EP, int NT, bool FAST, int XB = 0>      // XB: 0 / 1 / 2 as ConvArgs::xbf16
-static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s) {
+static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* b = nullptr) {
+    if (b) return launch_pair_inst<LD, EP, NT, FAST, XB>(a, *b, grid, threads, smem, s);
     static bool attr_done = false;
     if (!attr_done) {       // dynamic LDS above 64 KB has to be opted into, once per instantiation
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<LD, EP, NT, FAST, XB>),
@@ -1081,44 +1132,56 @@ static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t 
 }
 
 template <int LD, int EP>
-static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int threads, size_t smem, hipStream_t s) {
+static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* b = nullptr) {
     if (EP == EP_BWD && a.xbf16) {            // bf16 activations (and gradients): the one-tile variants only
         if (NT != 1) return hipErrorInvalidValue;
         constexpr int B = (EP == EP_BWD) ? 1 : 0;
         if (a.xbf16 == 2) {
-            if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), 2 * B>(a, grid, threads, smem, s);
-            return launch_inst<LD, EP, 1, false, 2 * B>(a, grid, threads, smem, s);
+            if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), 2 * B>(a, grid, threads, smem, s, b);
+            return launch_inst<LD, EP, 1, false, 2 * B>(a, grid, threads, smem, s, b);
         }
-        if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), B>(a, grid, threads, smem, s);
-        return launch_inst<LD, EP, 1, false, B>(a, grid, threads, smem, s);      // heads: K = class_num
+        if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), B>(a, grid, threads, smem, s, b);
+        return launch_inst<LD, EP, 1, false, B>(a, grid, threads, smem, s, b);      // heads: K = class_num
     }
     if (fast && LD != LD_STEM) {
         switch (NT) {
-            case 1: return launch_inst<LD, EP, 1, (LD != LD_STEM)>(a, grid, threads, smem, s);
-            case 2: return launch_inst<LD, EP, 2, (LD != LD_STEM)>(a, grid, threads, smem, s);
-            case 3: return launch_inst<LD, EP, 3, (LD != LD_STEM)>(a, grid, threads, smem, s);
-            default: return launch_inst<LD, EP, 4, (LD != LD_STEM)>(a, grid, threads, smem, s);
+            case 1: return launch_inst<LD, EP, 1, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
+            case 2: return launch_inst<LD, EP, 2, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
+            case 3: return launch_inst<LD, EP, 3, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
+            default: return launch_inst<LD, EP, 4, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
         }
     }
     switch (NT) {
-        case 1: return launch_inst<LD, EP, 1, false>(a, grid, threads, smem, s);
-        case 2: return launch_inst<LD, EP, 2, false>(a, grid, threads, smem, s);
-        case 3: return launch_inst<LD, EP, 3, false>(a, grid, threads, smem, s);
-        default: return launch_inst<LD, EP, 4, false>(a, grid, threads, smem, s);
+        case 1: return launch_inst<LD, EP, 1, false>(a, grid, threads, smem, s, b);
+        case 2: return launch_inst<LD, EP, 2, false>(a, grid, threads, smem, s, b);
+        case 3: return launch_inst<LD, EP, 3, false>(a, grid, threads, smem, s, b);
+        default: return launch_inst<LD, EP, 4, false>(a, grid, threads, smem, s, b);
     }
 }
 
 // Host launcher.  Picks the channel tile NT (all output channels per block when the node is big
 // and its weights fit the LDS, fewer when there are too few 32-row tiles to fill the chip), the
 // waves per block and the grid.
-hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) {
+static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, int load, int epi, int num_cus_all, hipStream_t s);
+
+hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hipStream_t s) { return launch_conv_impl(a_in, nullptr, load, epi, num_cus, s); }
+
+// a_in and b_in in one launch (see conv_pair_kernel); hipErrorNotSupported (and nothing launched): the caller launches them one by one
+hipError_t launch_conv_pair(const ConvArgs& a_in, const ConvArgs& b_in, int load, int epi, int num_cus, hipStream_t s) {
+    if (!conv_pairable(a_in, b_in) || a_in.taps != 1) return hipErrorNotSupported;
+    return launch_conv_impl(a_in, &b_in, load, epi, num_cus, s);
+}
+
+static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, int load, int epi, int num_cus_all, hipStream_t s) {
+    const int num_cus = b_in ? num_cus_all / 2 : num_cus_all;      // a pair: each problem on half of the chip
     static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 32);      // 3x3 forward on the LDS row ring at this width and above (64 and 32: +0.4 % over 64 only)
-    if (load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= (a_in.ring_min_rows > 0 ? a_in.ring_min_rows : 512))
+    if (!b_in && load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= (a_in.ring_min_rows > 0 ? a_in.ring_min_rows : 512))
         return launch_conv3x3_ring(a_in, num_cus, s);
     static const int use_sk = tune_int("CUNET_CONV_SPLITK", 1);
-    if (use_sk && load == LD_SEG && epi == EP_FWD && conv1x1_splitk_supported(a_in, num_cus)) return launch_conv1x1_splitk(a_in, s);
+    // (a pair: one round of one-tile blocks for both problems together)
+    if (use_sk && load == LD_SEG && epi == EP_FWD && conv1x1_splitk_supported(a_in, num_cus)) return launch_conv1x1_splitk(a_in, s, b_in);
     static const int use_ts = tune_int("CUNET_CONV_TS", 1);
-    if (use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
+    if (!b_in && use_ts && load == LD_3X3 && epi == EP_FWD && a_in.nseg == 1 && a_in.K == 128 && a_in.Kpad == 128 && a_in.Nout == 32 &&
         a_in.Npad == 32 && a_in.M % 32 == 0 && a_in.seg[0].ld % 4 == 0 && !a_in.seg[0].ups &&
         a_in.qin_bits == 0 && a_in.M / 32 <= use_ts * 4 * num_cus)      // beyond ~4 tiles per CU the barrier-free kernel is ahead (93 vs 106 us at 64x64, bs 24)
         return launch_conv3x3_tapsplit(a_in, num_cus, s);
@@ -1189,7 +1252,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
     // never fewer than 4 waves: idle waves still help copying B into LDS and building the BN tables
     const int threads = (waves < 4 ? 4 : waves) * 64;
 #define CUNET_CASE(L, E) \
-    if (load == L && epi == E) return launch_nt<L, E>(a, NT, fast, grid, threads, smem, s);
+    if (load == L && epi == E) return launch_nt<L, E>(a, NT, fast, grid, threads, smem, s, b_in);
     CUNET_CASE(LD_SEG, EP_FWD)
     CUNET_CASE(LD_3X3, EP_FWD)
     CUNET_CASE(LD_STEM, EP_FWD)

@@ -7,6 +7,9 @@ namespace cunet {
 enum WgLoadSel { WGL_SEG = 0, WGL_3X3 = 1, WGL_STEM = 2 };
 
 hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStream_t s);
+// two convolutions of one shape in ONE launch (the ahead / skip adapters of a down block, forward and data gradient);
+// hipErrorNotSupported with nothing launched when the shapes differ or the shape has no pair kernel
+hipError_t launch_conv_pair(const ConvArgs& a, const ConvArgs& b, int load, int epi, int num_cus, hipStream_t s);
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
 bool wgrad3_supported(const WgradArgs& a);
 hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
@@ -34,8 +37,10 @@ hipError_t launch_rmsprop(float* p, const float* g, float* v, long n, float lr, 
 hipError_t launch_cvt_bf16(const float* src, void* dst, double* ystats, long rows, int C, int num_cus, hipStream_t s);
 hipError_t launch_repack_bf16(const RepackEntry* tab, int n, const float* params, void* arena, int with_backward, hipStream_t s);
 hipError_t launch_dgrad_bf16(const ConvArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_dgrad_bf16_pair(const ConvArgs& a, const ConvArgs& b, int num_cus, hipStream_t s);      // as launch_conv_pair
 hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H, int W, int C, int num_cus, hipStream_t s);
 hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStream_t s);
+hipError_t launch_conv_bf16_pair(const ConvArgs& a, const ConvArgs& b, int num_cus, hipStream_t s);       // as launch_conv_pair (bf16 out)
 hipError_t launch_render_targets(const double* pts, const float* patch, int half, float* out, int NK, int H, int W, hipStream_t s);
 hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, float* out, int N, int K, int H, int W, hipStream_t s);
 hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,

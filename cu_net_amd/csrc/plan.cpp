@@ -286,6 +286,7 @@ bool Plan::build(const cunet_cfg& c) {
             const std::string ps = prefix + ".adapters_skip." + std::to_string(i);
             skip = conv_node(ps + ".adapter_conv", ps + ".adapter_norm", ps + ".adapter_conv", segs, 1, true, H, W, -1, true);
             if (skip < 0) return false;
+            if (opts.pair_adapters) nodes[nodes.size() - 2].pair = 1;      // (conv_node appended the two adapters back to back)
         }
         return true;
     };
@@ -596,7 +597,7 @@ void Plan::describe() {
         if (n.conv >= 0) o << ",\"conv\":\"" << convs[n.conv].name << "\",\"taps\":" << n.taps;
         o << ",\"head\":" << n.head << ",\"wg3\":" << n.wg3_S << ",\"wg3_rows\":" << n.wg3_rows << ",\"wg3_bf16\":" << n.wg3_S16
           << ",\"wg3_rows_bf16\":" << n.wg3_rows16 << ",\"wg3_wpi\":" << n.wg3_wpi << ",\"wg3_part\":" << n.wg3_part
-          << ",\"wg3_numel\":" << (n.wg3_S > 0 ? wg3_numel(n) : 0) << ",\"bucket\":" << n.bucket << ",\"segs\":[";
+          << ",\"wg3_numel\":" << (n.wg3_S > 0 ? wg3_numel(n) : 0) << ",\"bucket\":" << n.bucket << ",\"pair\":" << n.pair << ",\"segs\":[";
         for (size_t s = 0; s < n.segs.size(); ++s)
             o << (s ? "," : "") << "{\"t\":" << n.segs[s].tensor << ",\"ups\":" << n.segs[s].ups
               << "}";

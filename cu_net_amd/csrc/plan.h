@@ -72,6 +72,8 @@ struct Node {
     int64_t red = -1;         // double offset in the zeroed region: [2][Ccat] backward reductions
     int bucket = 0;           // gradient bucket this node's parameters live in
     int64_t dz = -1;          // float offset of this node's own [M][Ccat] dz buffer (training)
+    int pair = 0;             // 1: this node (the ahead adapter of a down block) and the NEXT node (the skip adapter over the same
+                              // concat, models/cu_net.py:139-142) may run as one launch, forward and data gradient
     // LDS-staged 1x1 weight gradient (wgrad3): pixel splits, rows per split, float offset of the [S][Cout][Ccat]
     // partial tiles inside the per-bucket partial region, index into the reduce table; wg3_S == 0: not eligible
     int wg3_S = 0, wg3_rows = 0, wg3_entry = -1;
@@ -80,7 +82,7 @@ struct Node {
     int64_t wg3_part = -1;
 };
 
-struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 96, wgrad3_stem = 1, conv3x3_ring_min_rows = 512, wgrad_fork_group = 4, fwd_fork_min_w = 0; };
+struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 96, wgrad3_stem = 1, conv3x3_ring_min_rows = 512, wgrad_fork_group = 4, fwd_fork_min_w = 0, pair_adapters = 1; };
 PlannerOptions& planner_options();
 
 struct Plan {

@@ -110,6 +110,13 @@ static hipError_t prof_end(cunet_plan* h, int slot, double flops, double bytes, 
     h->prof_pending[slot].bytes = bytes;
     return hipEventRecord(h->prof_pending[slot].b, s);
 }
+// the launch behind prof_begin did not happen: withdraw its record (the newest one only)
+static void prof_cancel(cunet_plan* h, int slot) {
+    if (slot < 0 || slot != (int)h->prof_pending.size() - 1) return;
+    h->prof_pool.push_back(h->prof_pending[slot].a);
+    h->prof_pool.push_back(h->prof_pending[slot].b);
+    h->prof_pending.pop_back();
+}
 #define PROF_ON(st, cls, flops, bytes, expr)               \
     do {                                                   \
         int slot_;                                         \
@@ -148,6 +155,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "conv3x3_ring_min_rows") o.conv3x3_ring_min_rows = value;
     else if (n == "wgrad_fork_group") o.wgrad_fork_group = value;
     else if (n == "fwd_fork_min_w") o.fwd_fork_min_w = value;
+    else if (n == "pair_adapters") o.pair_adapters = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -488,35 +496,77 @@ static int reduce_wgrad3(cunet_plan* h, int first, int count, int max_numel, hip
 enum { BWD_MAIN = 1, BWD_WGRAD = 2 };
 static bool node_has_wgrad(const Node& n) { return n.type == N_CONV || n.type == N_STEM_CONV; }
 
+// arguments of a conv node's data gradient (+ ReLU mask + BatchNorm reductions)
+static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index) {
+    Plan& P = h->plan;
+    const ConvInfo& c = P.convs[n.conv];
+    const BnInfo& b = P.bns[n.bn];
+    const TensorInfo& o = P.tensors[n.out];
+    ConvArgs a{};
+    a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+    a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+    a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+    a.training = 1;
+    a.xbf16 = E.xmode;
+    a.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
+    a.a = E.grad(n.out); a.lda = head_grad_ld(P, n, E.xmode == 2);      // (a padded bf16 head gradient: see head_grad_ld)
+    a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
+    a.y = n.dz >= 0 ? E.wsf + n.dz : nullptr; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = E.zero + n.red;
+    a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+    return a;
+}
+
+// the same for dgrad_bf16_kernel (bf16 gradient tensors): the bf16 backward operand
+static ConvArgs dgrad_args_bf16(cunet_plan* h, Exec& E, const Node& n, const ConvArgs& a) {
+    const ConvInfo& c = h->plan.convs[n.conv];
+    ConvArgs b16 = a;
+    b16.wB = reinterpret_cast<const float*>(E.a16 + c.wB);
+    if (n.head >= 0) b16.K = c.KpadB;             // the zero-padded channels are contracted too (zero weights behind them)
+    return b16;
+}
+
+// Data gradients of an adapter pair (nodes k0 = ahead and k1 = skip, Node::pair) in one launch.  1: launched; 0: no pair kernel for
+// this shape / storage (nothing launched, the caller runs them one by one); < 0: error.
+static int bwd_dgrad_pair(cunet_plan* h, int k0, int k1, hipStream_t s, int& rc_out) {
+    Exec E(h);
+    Plan& P = h->plan;
+    const Node& n0 = P.nodes[k0];
+    const Node& n1 = P.nodes[k1];
+    const ConvArgs a0 = dgrad_args(h, E, n0, k0), a1 = dgrad_args(h, E, n1, k1);
+    static const int dg16 = tune_int("CUNET_NO_DGRAD_BF16", 0) ? 0 : 1;
+    const bool on16 = E.xmode == 2 && dg16;
+    int slot_;
+    rc_out = CUNET_OK;
+#define PAIRCHK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc_out = fail(CUNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); return -1; } } while (0)
+    PAIRCHK(prof_begin(h, on16 ? PC_C1D16 : PC_C1D, s, slot_));
+    hipError_t e;
+    if (on16) e = launch_dgrad_bf16_pair(dgrad_args_bf16(h, E, n0, a0), dgrad_args_bf16(h, E, n1, a1), h->num_cus, s);
+    else e = launch_conv_pair(a0, a1, LD_PLAIN, EP_BWD, h->num_cus, s);
+    if (e == hipErrorNotSupported || e == hipErrorInvalidValue) {
+        prof_cancel(h, slot_);
+        return 0;
+    }
+    PAIRCHK(e);
+    PAIRCHK(prof_end(h, slot_, 2.0 * 2.0 * a0.M * a0.K * a0.Nout, 2.0 * (on16 ? 2.0 : 4.0) * (double)a0.M * (a0.K + 2.0 * a0.Nout), s));
+#undef PAIRCHK
+    return 1;
+}
+
 static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s, hipStream_t ws, int parts) {
     Exec E(h);
     Plan& P = h->plan;
     const int cus = h->num_cus;
-    float* dz = n.dz >= 0 ? E.wsf + n.dz : nullptr;
     const TensorInfo& o = P.tensors[n.out];
     if (n.type == N_CONV) {
         const ConvInfo& c = P.convs[n.conv];
         const BnInfo& b = P.bns[n.bn];
-        double* red = E.zero + n.red;
         if (parts & BWD_MAIN) {   // data gradient + ReLU mask + BN reductions
-            ConvArgs a{};
-            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
-            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-            a.training = 1;
-            a.xbf16 = E.xmode;
-            a.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
-            const int gld = head_grad_ld(P, n, E.xmode == 2);      // (a padded bf16 head gradient: see head_grad_ld)
-            a.a = E.grad(n.out); a.lda = gld;
-            a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
-            a.y = dz; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = red;
-            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+            const ConvArgs a = dgrad_args(h, E, n, node_index);
+            const int gld = a.lda;
             static const int dg16 = tune_int("CUNET_NO_DGRAD_BF16", 0) ? 0 : 1;
             bool done = false;
             if (E.xmode == 2 && dg16 && (n.head < 0 || gld != o.ld)) {      // bf16 gradient tensors: bf16 MFMA data gradient where the shape allows
-                ConvArgs b16 = a;
-                b16.wB = reinterpret_cast<const float*>(E.a16 + c.wB);
-                if (n.head >= 0) b16.K = c.KpadB;             // the zero-padded channels are contracted too (zero weights behind them)
+                const ConvArgs b16 = dgrad_args_bf16(h, E, n, a);
                 int slot_;
                 HIPCHK(prof_begin(h, c.taps == 9 ? PC_C3D16 : PC_C1D16, s, slot_));
                 const hipError_t e = launch_dgrad_bf16(b16, cus, s);
@@ -619,6 +669,47 @@ static int fork_wgrads(cunet_plan* h, std::vector<int>& pending, hipStream_t s) 
     return CUNET_OK;
 }
 
+// arguments of a conv node's fp32 forward ([concat -> BatchNorm -> ReLU (-> QuanInput)] -> conv)
+static ConvArgs conv_fwd_args(cunet_plan* h, Exec& E, const Node& n, int node_index, int training) {
+    Plan& P = h->plan;
+    const ConvInfo& c = P.convs[n.conv];
+    const BnInfo& b = P.bns[n.bn];
+    const TensorInfo& o = P.tensors[n.out];
+    ConvArgs a{};
+    a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+    a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+    a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+    a.training = training;
+    a.K = n.Ccat; a.taps = c.taps; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
+    a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
+    a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+    a.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
+    a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
+    return a;
+}
+
+// the same for the bf16 forward: inputs, weights and (except heads) the output in the bf16 arena
+static ConvArgs conv_fwd_args_bf16(cunet_plan* h, Exec& E, const Node& n, unsigned short* a16, int training) {
+    Plan& P = h->plan;
+    const ConvInfo& c = P.convs[n.conv];
+    const BnInfo& b = P.bns[n.bn];
+    const TensorInfo& o = P.tensors[n.out];
+    ConvArgs a{};
+    a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
+    for (int i = 0; i < a.nseg; ++i)       // the bf16 copies of the inputs
+        a.seg[i].x = reinterpret_cast<const float*>(a16 + P.tensors[n.segs[i].tensor].act);
+    a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+    a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
+    a.training = training ? 1 : 0;
+    a.K = n.Ccat; a.taps = c.taps; a.wB = reinterpret_cast<const float*>(a16 + c.wF); a.Kpad = c.KpadF; a.Npad = c.NpadF;
+    const int is_head = n.head >= 0;
+    a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
+    a.ldy = o.ld; a.Nout = c.Cout; a.ystats = (training && !is_head) ? E.stats(n.out) : nullptr;
+    a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+    a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
+    return a;
+}
+
 extern "C" {
 
 int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int training, void* stream) {
@@ -651,6 +742,21 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
         for (const SegRef& sr : n.segs) {
             const int pn = h->pending[sr.tensor];
             if (pn >= 0) { HIPCHK(hipStreamWaitEvent(s_main, h->done_ev[pn], 0)); h->pending[sr.tensor] = -1; }
+        }
+        // the ahead and the skip adapter of a down block read the same concat: one launch for both where the shape has a pair kernel
+        if (n.pair && ni + 1 < P.nodes.size()) {
+            const Node& n2 = P.nodes[ni + 1];
+            const ConvArgs a0 = conv_fwd_args(h, E, n, (int)ni, training), a1 = conv_fwd_args(h, E, n2, (int)ni + 1, training);
+            int slot_;
+            HIPCHK(prof_begin(h, PC_C1F, s, slot_));
+            const hipError_t e = launch_conv_pair(a0, a1, LD_SEG, EP_FWD, cus, s);
+            if (e == hipSuccess) {
+                HIPCHK(prof_end(h, slot_, 2.0 * 2.0 * a0.M * a0.K * a0.Nout, 2.0 * 4.0 * (double)a0.M * (a0.K + a0.Nout), s));
+                ++ni;
+                continue;
+            }
+            prof_cancel(h, slot_);
+            if (e != hipErrorNotSupported) HIPCHK(e);
         }
         // fork: the skip adapter of a down block is consumed only on the way up (models/cu_net.py:257,267),
         // so it runs on the side stream next to the ahead adapter / pool / next block
@@ -686,17 +792,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             }
         } else {  // N_CONV
             const ConvInfo& c = P.convs[n.conv];
-            const BnInfo& b = P.bns[n.bn];
-            ConvArgs a{};
-            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
-            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-            a.training = training;
-            a.K = n.Ccat; a.taps = c.taps; a.wB = E.wsf + c.wF; a.Kpad = c.KpadF; a.Npad = c.NpadF;
-            a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
-            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            a.qin_bits = h->qin_bits ? h->node_qin[ni] : 0;
-            a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
+            ConvArgs a = conv_fwd_args(h, E, n, (int)ni, training);
             const bool on_popcount = a.qin_bits && h->node_tern[ni] && h->tern_live;
             const bool fuse_mse = n.head >= 0 && training && h->fused_loss_out != nullptr;
             if (fuse_mse && !on_popcount) set_fused_mse(h, E, n, a);
@@ -801,20 +897,21 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             HIPCHK(e);
         } else {  // N_CONV
             const ConvInfo& c = P.convs[n.conv];
-            const BnInfo& b = P.bns[n.bn];
-            ConvArgs a{};
-            a.nseg = E.fill_segs(n, a.seg); a.Ccat = n.Ccat;
-            for (int i = 0; i < a.nseg; ++i)       // the bf16 copies of the inputs
-                a.seg[i].x = reinterpret_cast<const float*>(a16 + P.tensors[n.segs[i].tensor].act);
-            a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
-            a.rmean = h->buffers + b.rmean; a.rvar = h->buffers + b.rvar;
-            a.training = training ? 1 : 0;
-            a.K = n.Ccat; a.taps = c.taps; a.wB = reinterpret_cast<const float*>(a16 + c.wF); a.Kpad = c.KpadF; a.Npad = c.NpadF;
+            if (n.pair && ni + 1 < P.nodes.size()) {      // ahead + skip adapter of a down block in one launch (see cunet_forward)
+                const ConvArgs a0 = conv_fwd_args_bf16(h, E, n, a16, training), a1 = conv_fwd_args_bf16(h, E, P.nodes[ni + 1], a16, training);
+                int slotp;
+                HIPCHK(prof_begin(h, PC_C1F16, s, slotp));
+                const hipError_t ep = launch_conv_bf16_pair(a0, a1, cus, s);
+                if (ep == hipSuccess) {
+                    HIPCHK(prof_end(h, slotp, 2.0 * 2.0 * a0.M * a0.K * a0.Nout, 2.0 * 2.0 * (double)a0.M * (a0.K + a0.Nout), s));
+                    ++ni;
+                    continue;
+                }
+                prof_cancel(h, slotp);
+                if (ep != hipErrorNotSupported && ep != hipErrorInvalidValue) HIPCHK(ep);
+            }
+            ConvArgs a = conv_fwd_args_bf16(h, E, n, a16, training);
             const int is_head = n.head >= 0;
-            a.y = is_head ? E.act(n.out) : reinterpret_cast<float*>(a16 + o.act);
-            a.ldy = o.ld; a.Nout = c.Cout; a.ystats = (training && !is_head) ? E.stats(n.out) : nullptr;
-            a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
-            a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
             if (is_head && training && h->fused_loss_out != nullptr) {
                 set_fused_mse(h, E, n, a);
                 a.mse_gbf16 = training == 2;             // bf16 gradient tensors
@@ -961,19 +1058,34 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             cur_bucket = n.bucket;
             bucket_hi = k + 1;
         }
-        if (P.tensors[n.out].ccount > 0) {  // d(loss)/d(out): gather from the consumers (heads get theirs from the loss)
-            const int rcg = gather_tensor_grad(h, n.out, -1, s);
-            if (rcg != CUNET_OK) return rcg;
-        }
-        if (node_has_wgrad(n)) {           // (its d(loss)/d(out) is enqueued: the weight gradient may start once that has run)
-            pending.push_back(k);
-            if (pending.size() >= group || k == 0) {
-                const int rcf = fork_wgrads(h, pending, s);
-                if (rcf != CUNET_OK) return rcf;
+        // the skip adapter of a pair (Node::pair on the node in front of it): both adapters' gradients are gathered first, then
+        // their data gradients share a launch
+        const bool paired = k >= 1 && P.nodes[k - 1].pair && P.nodes[k - 1].bucket == n.bucket;
+        for (int q = k; q >= (paired ? k - 1 : k); --q) {
+            const Node& nq = P.nodes[q];
+            if (P.tensors[nq.out].ccount > 0) {  // d(loss)/d(out): gather from the consumers (heads get theirs from the loss)
+                const int rcg = gather_tensor_grad(h, nq.out, -1, s);
+                if (rcg != CUNET_OK) return rcg;
+            }
+            if (node_has_wgrad(nq)) {          // (its d(loss)/d(out) is enqueued: the weight gradient may start once that has run)
+                pending.push_back(q);
+                if ((pending.size() >= group && q == (paired ? k - 1 : k)) || q == 0) {
+                    const int rcf = fork_wgrads(h, pending, s);
+                    if (rcf != CUNET_OK) return rcf;
+                }
             }
         }
-        const int rc = bwd_node(h, n, k, s, s, BWD_MAIN);
-        if (rc != CUNET_OK) return rc;
+        int launched = 0;
+        if (paired) {
+            int rcp = CUNET_OK;
+            launched = bwd_dgrad_pair(h, k - 1, k, s, rcp);
+            if (launched < 0) return rcp;
+        }
+        for (int q = k; !launched && q >= (paired ? k - 1 : k); --q) {
+            const int rc = bwd_node(h, P.nodes[q], q, s, s, BWD_MAIN);
+            if (rc != CUNET_OK) return rc;
+        }
+        if (paired) --k;
     }
     {
         const int rcf = fork_wgrads(h, pending, s);
@@ -1112,8 +1224,21 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
         const int rcf = fork_wgrads(h, one, s);
         if (rcf != CUNET_OK) return rcf;
     }
-    const int rc = bwd_node(h, n, node, s, s, BWD_MAIN);
-    if (rc != CUNET_OK) return rc;
+    // an adapter of a pair (Node::pair): its data gradient runs as cunet_backward runs it, in the pair's launch (the partner's
+    // d(loss)/d(out) is whatever the workspace holds; its dz / reductions are not read here)
+    const int k0 = n.pair ? node : ((node >= 1 && P.nodes[node - 1].pair) ? node - 1 : -1);
+    int launched = 0;
+    if (k0 >= 0) {
+        const Node& partner = P.nodes[k0 == node ? node + 1 : k0];
+        if (partner.red >= 0) HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * partner.red, 0, (size_t)16 * partner.Ccat, s));
+        int rcp = CUNET_OK;
+        launched = bwd_dgrad_pair(h, k0, k0 + 1, s, rcp);
+        if (launched < 0) return rcp;
+    }
+    if (!launched) {
+        const int rc = bwd_node(h, n, node, s, s, BWD_MAIN);
+        if (rc != CUNET_OK) return rc;
+    }
     if (n.wg3_S > 0) {
         const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, (int)P.wg3_numel(n), (h->use_side && h->side) ? h->side : s);
         if (rcr != CUNET_OK) return rcr;

@@ -246,6 +246,9 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        every hand-over is an event record on the caller's stream, i.e. a marker packet the next kernel waits
  *                        behind (6-7 us of bubble on the critical path each); 1 = one hand-over per node
  *   "fwd_fork_min_w"     forward: the down blocks' skip adapters run on the side stream at levels at least this wide (default 0: all)
+ *   "pair_adapters"      1 (default): the ahead and the skip adapter of a down block (two 1x1 convolutions over the same concat,
+ *                        models/cu_net.py:139-142) share ONE launch, forward and data gradient, where the shape has a pair kernel;
+ *                        0: one launch each (forward: the skip adapter on the side stream)
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 
@@ -270,7 +273,9 @@ int cunet_augment_batch(const void* table_dev, const void* table_host, int n, fl
 int64_t cunet_debug_tensor_offset(const cunet_plan_t* plan, const char* name, int which);
 /* Runs the backward of ONE node (index into the describe() node list) in isolation: clears the
  * node's reduction scratch and the whole gradient arena, then writes (never accumulates) the input
- * gradients.  The caller pokes d(loss)/d(output) into the workspace first.  Kernel unit tests. */
+ * gradients.  The caller pokes d(loss)/d(output) into the workspace first.  Kernel unit tests.
+ * An adapter of a pair ("pair": 1 in the node list, and the node after it) runs its data gradient as cunet_backward does, in
+ * the pair's launch when the shape has a pair kernel; the partner's results are not read. */
 int cunet_debug_run_node_backward(cunet_plan_t* plan, int node, void* stream);
 
 #ifdef __cplusplus

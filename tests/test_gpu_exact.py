@@ -224,3 +224,72 @@ def test_fused_head_loss_equals_the_separate_loss_pass(mode, class_num):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     ga, gb = res[True][2], res[False][2]
     assert float((ga - gb).norm() / gb.norm()) <= 1e-5
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16_grads'])
+def test_adapter_pair_launches_equal_the_single_launches(mode):
+    """The ahead and the skip adapter of a down block in ONE launch (conv_pair_kernel / conv1x1_splitk_pair_kernel /
+    conv_bf16_pair_kernel forward, conv_pair_kernel<LD_PLAIN, EP_BWD> / dgrad_bf16_pair_kernel data gradient; planner option
+    pair_adapters, models/cu_net.py:139-142) against one launch each on the same state: the bodies are the same device functions, so
+    the adapters' outputs agree to the order of the statistics atomics in front of them, and so do loss and parameter gradients.
+    The launch counts show that the pairs ran: 4 per U-Net fewer 1x1 forwards, and as many fewer 1x1 data gradients where the
+    storage mode has a pair kernel (fp32 and bf16 gradient tensors; bf16 activations with fp32 gradients run them one by one)."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    L = 2
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=L, order=1, loss_num=L)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=71)
+    x, target = O.synthetic_batch(4, 16, 256, seed=72)
+    res = {}
+    try:
+        for pair in (1, 0):
+            set_planner_option('pair_adapters', pair)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(4, 256, 256, True, bf16=mode != 'fp32')
+            desc = plan.handle.describe()
+            assert sum(nd.get('pair', 0) for nd in desc['nodes']) == (4 * L if pair else 0)
+            plan.handle.profile_begin(1)
+            plan.handle.profile_reset()
+            loss = plan.stage_target(target.cuda())
+            if mode == 'fp32':
+                plan.forward(x.cuda(), True, want_outputs=False)
+            else:
+                plan.forward_bf16(x.cuda(), 2 if mode == 'bf16_grads' else 1, want_outputs=False)
+            torch.cuda.synchronize()
+            outs = {}
+            for nd in desc['nodes']:
+                if '.adapters_ahead.' in nd['name'] or '.adapters_skip.' in nd['name']:
+                    outs[nd['name']] = plan.debug_tensor(desc['tensors'][nd['out']]['name']).float().cpu()
+            plan.backward(None)
+            torch.cuda.synchronize()
+            counts = {k: v[0] for k, v in plan.handle.profile_collect().items()}
+            plan.handle.profile_begin(0)
+            res[pair] = (float(loss), outs, net._grad_arena.clone().cpu(), counts)
+    finally:
+        set_planner_option('pair_adapters', 1)
+    sfx = '' if mode == 'fp32' else '_bf16'
+    fwd = 'conv1x1_fwd' + sfx
+    assert res[0][3][fwd] - res[1][3][fwd] == 4 * L, (res[0][3][fwd], res[1][3][fwd])
+    bwd1 = sum(res[1][3].get(k, 0) for k in ('conv1x1_bwd_data', 'conv1x1_bwd_data_bf16'))
+    bwd0 = sum(res[0][3].get(k, 0) for k in ('conv1x1_bwd_data', 'conv1x1_bwd_data_bf16'))
+    assert bwd0 - bwd1 == (0 if mode == 'bf16' else 4 * L), (bwd0, bwd1)
+    assert abs(res[1][0] - res[0][0]) <= 1e-5 * abs(res[0][0])
+    first = sorted(res[0][1])[0]
+    for name, b in res[0][1].items():
+        a = res[1][1][name]
+        # (the first pair sees bit-identical inputs up to the statistics atomics of the nodes in front of it; bf16 outputs may
+        # round the other way at a rounding boundary: one bf16 step on a few elements)
+        tol = 1e-5 if mode == 'fp32' else 2 ** -7
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
+        if mode != 'fp32' and name == first:
+            assert float(((a - b).abs() > 0).float().mean()) <= 2e-3, name
+    # (gradients: the pair launcher picks its kernel for half of the chip -- at 32 x 32 the single launches run the split-K kernel,
+    # the pair the weight-stationary one -- so activations differ by summation order, ~1e-7 relative, and the ReLU masks of
+    # the elements that close to zero flip: a fraction f of flipped elements moves the gradient by ~sqrt(f) in relative L2.  The
+    # tight checks of the pair kernels are the node tests (cunet_debug_run_node_backward runs an adapter's data gradient in the
+    # pair's launch) and the composition tests of tests/test_gpu_nodes.py.)
+    ga, gb = res[1][2], res[0][2]
+    assert float((ga - gb).norm() / gb.norm()) <= (1e-2 if mode == 'fp32' else 3e-2)

@@ -110,3 +110,24 @@ def test_weight_gradient_partial_tile_plan(cfg, n, h, w):
         spans.sort()
         for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
             assert a1 <= b0, (b, a0, a1, b0, b1)
+
+
+def test_adapter_pairs_are_marked_on_the_down_blocks():
+    """Node::pair (plan.cpp): the ahead adapter of every down block is followed by the skip adapter over the same concat
+    (models/cu_net.py:139-142) and carries pair = 1 -- 4 per U-Net; planner option pair_adapters = 0 clears it."""
+    from cu_net_amd._lib import set_planner_option
+    try:
+        for on in (1, 0):
+            set_planner_option('pair_adapters', on)
+            d = PlanHandle(4, 32, 128, 16, 3, 1, 3, 2, 256, 256).describe()
+            nodes = d['nodes']
+            marked = [i for i, nd in enumerate(nodes) if nd.get('pair')]
+            assert len(marked) == (4 * 3 if on else 0)
+            for i in marked:
+                a, b = nodes[i], nodes[i + 1]
+                assert '.down_blocks.' in a['name'] and '.adapters_ahead.' in a['name']
+                assert b['name'] == a['name'].replace('.adapters_ahead.', '.adapters_skip.')
+                assert a['segs'] == b['segs'] and a['taps'] == b['taps'] == 1 and a['bucket'] == b['bucket']
+                assert d['tensors'][a['out']]['C'] == d['tensors'][b['out']]['C']
+    finally:
+        set_planner_option('pair_adapters', 1)
