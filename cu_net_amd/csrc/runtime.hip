@@ -156,6 +156,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "wgrad_fork_group") o.wgrad_fork_group = value;
     else if (n == "fwd_fork_min_w") o.fwd_fork_min_w = value;
     else if (n == "pair_adapters") o.pair_adapters = value;
+    else if (n == "heads_on_side") o.heads_on_side = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -760,7 +761,10 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
         }
         // fork: the skip adapter of a down block is consumed only on the way up (models/cu_net.py:257,267),
         // so it runs on the side stream next to the ahead adapter / pool / next block
-        const bool forked = fork_fwd && n.type == N_CONV && o.W >= P.opts.fwd_fork_min_w && n.name.find(".adapters_skip.") != std::string::npos;
+        // ... and so does a heat-map head in a training pass: nothing in the forward reads its output (the loss is finalised after
+        // the join below), and the side stream is idle in the forward
+        const bool forked = fork_fwd && n.type == N_CONV &&
+                            ((o.W >= P.opts.fwd_fork_min_w && n.name.find(".adapters_skip.") != std::string::npos) || (n.head >= 0 && P.opts.heads_on_side));
         if (forked) {
             HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
             HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[ni], 0));
@@ -863,6 +867,9 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
     HIPCHK(launch_repack(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, E.wsf, s));
     HIPCHK(launch_repack_bf16(reinterpret_cast<const RepackEntry*>(h->ws + P.off_repack_tab), (int)P.convs.size(), h->params, a16,
                               training == 2, s));
+    const bool fork_heads = training && h->use_side && h->side && !h->done_ev.empty() && P.opts.heads_on_side;
+    const hipStream_t s_main = s;
+    std::vector<int> forked_heads;
     for (size_t ni = 0; ni < P.nodes.size(); ++ni) {
         const Node& n = P.nodes[ni];
         const TensorInfo& o = P.tensors[n.out];
@@ -912,6 +919,12 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             }
             ConvArgs a = conv_fwd_args_bf16(h, E, n, a16, training);
             const int is_head = n.head >= 0;
+            const bool forked = is_head && fork_heads;      // a training pass: the head runs on the side stream (see cunet_forward)
+            if (forked) {
+                HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
+                HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[ni], 0));
+                s = h->side;
+            }
             if (is_head && training && h->fused_loss_out != nullptr) {
                 set_fused_mse(h, E, n, a);
                 a.mse_gbf16 = training == 2;             // bf16 gradient tensors
@@ -924,8 +937,14 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
                 return fail(CUNET_ERR_INVALID, "bf16 path: channel counts must be multiples of 32 and rows of 32 (node " + n.name + ")");
             HIPCHK(e);
             HIPCHK(prof_end(h, slot_, 2.0 * a.M * a.K * a.Nout * a.taps, 2.0 * (double)a.M * (a.K + a.Nout), s));
+            if (forked) {
+                HIPCHK(hipEventRecord(h->done_ev[ni], h->side));
+                forked_heads.push_back((int)ni);
+                s = s_main;
+            }
         }
     }
+    for (int ni : forked_heads) HIPCHK(hipStreamWaitEvent(s_main, h->done_ev[ni], 0));      // nothing may be left floating
     if (training)
         HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
                                      E.zero, h->buffers, h->counters, 0, s));
@@ -1036,6 +1055,26 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         }
     }
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
+    // The heads' backward depends on nothing but the loss gradient: all of it (data and weight gradient) goes to the side stream
+    // up front, last U-Net first (the order the caller's stream will want the results in), one hand-over for all of them; the
+    // caller's stream waits for head k's completion where head k's turn would have been.
+    std::vector<char> head_done(P.nodes.size(), 0);
+    if (h->use_side && h->side && P.opts.heads_on_side) {
+        int first = -1;
+        for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
+            const Node& n = P.nodes[k];
+            if (n.type != N_CONV || n.head < 0) continue;
+            if (first < 0) {
+                first = k;
+                HIPCHK(hipEventRecord(h->fork_ev[k], s));
+                HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[k], 0));
+            }
+            const int rc = bwd_node(h, n, k, h->side, h->side, BWD_MAIN | BWD_WGRAD);
+            if (rc != CUNET_OK) return rc;
+            HIPCHK(hipEventRecord(h->done_ev[k], h->side));
+            head_done[k] = 1;
+        }
+    }
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
     int bucket_hi = (int)P.nodes.size();                       // nodes [k+1, bucket_hi) belong to cur_bucket
     std::vector<int> pending;                                  // nodes whose weight gradient has not been forked yet
@@ -1057,6 +1096,10 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             }
             cur_bucket = n.bucket;
             bucket_hi = k + 1;
+        }
+        if (head_done[k]) {                // a head: its backward is on the side stream already
+            HIPCHK(hipStreamWaitEvent(s, h->done_ev[k], 0));
+            continue;
         }
         // the skip adapter of a pair (Node::pair on the node in front of it): both adapters' gradients are gathered first, then
         // their data gradients share a launch

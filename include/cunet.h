@@ -249,6 +249,9 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "pair_adapters"      1 (default): the ahead and the skip adapter of a down block (two 1x1 convolutions over the same concat,
  *                        models/cu_net.py:139-142) share ONE launch, forward and data gradient, where the shape has a pair kernel;
  *                        0: one launch each (forward: the skip adapter on the side stream)
+ *   "heads_on_side"      1 (default): in a training pass the heat-map heads (forward with the fused loss, data and weight gradient)
+ *                        run on the internal side stream -- nothing on the caller's stream reads a head's output before the loss
+ *                        is finalised, and its backward depends on the loss gradient only; 0: in node order on the caller's stream
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 

@@ -293,3 +293,49 @@ def test_adapter_pair_launches_equal_the_single_launches(mode):
     # pair's launch) and the composition tests of tests/test_gpu_nodes.py.)
     ga, gb = res[1][2], res[0][2]
     assert float((ga - gb).norm() / gb.norm()) <= (1e-2 if mode == 'fp32' else 3e-2)
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16_grads'])
+def test_heads_on_the_side_stream_equal_heads_in_node_order(mode):
+    """Planner option heads_on_side (default 1): in a training pass the heat-map heads run on the internal side stream -- forward
+    (with the fused loss) next to the following U-Net, data and weight gradient up front at the start of backward -- instead of in
+    node order on the caller's stream.  Same kernels, same arguments, only the stream differs: loss, every head's d(loss)/d(out)
+    and the parameter gradients agree to the order of the fp64 atomics.  Three U-Nets, three heads; repeated so that a missing
+    wait would have to hide three times."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=3, order=1, loss_num=3)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=81)
+    x, target = O.synthetic_batch(2, 16, 256, seed=82)
+    res = {}
+    try:
+        for side in (1, 0):
+            set_planner_option('heads_on_side', side)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(2, 256, 256, True, bf16=mode != 'fp32')
+            desc = plan.handle.describe()
+            heads = sorted((nd['head'], desc['tensors'][nd['out']]['name']) for nd in desc['nodes'] if nd.get('head', -1) >= 0)
+            runs = []
+            for rep in range(3 if side else 1):
+                loss = plan.stage_target(target.cuda())
+                if mode == 'fp32':
+                    plan.forward(x.cuda(), True, want_outputs=False)
+                else:
+                    plan.forward_bf16(x.cuda(), 2, want_outputs=False)
+                plan.backward(None)
+                torch.cuda.synchronize()
+                dout = [plan.debug_tensor(name, grad=True).float().cpu() for _, name in heads]
+                runs.append((float(loss), dout, net._grad_arena.clone().cpu()))
+            res[side] = runs
+    finally:
+        set_planner_option('heads_on_side', 1)
+    ref = res[0][0]
+    for got in res[1]:
+        assert abs(got[0] - ref[0]) <= 1e-5 * abs(ref[0])
+        for a, b in zip(got[1], ref[1]):
+            assert float((a - b).abs().max()) <= (1e-5 if mode == 'fp32' else 2 ** -7) * float(b.abs().max())
+        rel = float((got[2] - ref[2]).norm() / ref[2].norm())
+        assert rel <= (1e-3 if mode == 'fp32' else 3e-2), rel
