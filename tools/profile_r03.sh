@@ -2,6 +2,7 @@
 # Round-3 profiles (run from the repo root through gpurun):  profile_r03.sh <commit>
 #   config 2 (CU-Net-2, fp32): rocprofv3 --kernel-trace --stats overlapped and with CUNET_NO_SIDE_STREAM=1, FETCH_SIZE / WRITE_SIZE passes
 #   config 3 (CU-Net-8, bf16 storage): the same (kernel stats overlapped + serial, both PMC passes)
+#   both: one SQ-counter pass with the side stream off (wave / wait / MFMA-busy / vector-memory cycles per kernel)
 # Everything lands under gpurun_out/r03p_*; copy what should be judged into profiles/.
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
@@ -26,6 +27,18 @@ prof f32
 python tools/pmc_traffic.py $OUT/r03p_f32_rd $OUT/r03p_f32_wr $OUT/r03p_f32_traffic.json 2,68,24,f32 $COMMIT > $OUT/r03p_f32_traffic.txt 2>&1
 prof bf16 --layers 8 --bf16-grads
 python tools/pmc_traffic.py $OUT/r03p_bf16_rd $OUT/r03p_bf16_wr $OUT/r03p_bf16_traffic.json 8,68,24,bf16_grads $COMMIT > $OUT/r03p_bf16_traffic.txt 2>&1
+# SQ counters per kernel (side stream off: every kernel alone), the longest 16 launches' classes of either workload
+sq() {   # tag, bench args...
+  local tag=$1; shift
+  cd /tmp
+  CUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM \
+      --kernel-trace --output-format csv -d $OUT/r03p_${tag}_sq -o pmc -- python $ROOT/bench.py --no-cpu-baseline --no-also --no-alone "$@" --steps 2 --warmup 1 > /dev/null 2> $OUT/r03p_${tag}_sq.err
+  cd $ROOT
+  python tools/pmc_summary.py $OUT/r03p_${tag}_sq "" 16 > $OUT/r03p_${tag}_sq.txt 2>&1
+  rm -rf $OUT/r03p_${tag}_sq
+}
+sq f32
+sq bf16 --layers 8 --bf16-grads
 cat $OUT/r03p_f32_traffic.txt $OUT/r03p_bf16_traffic.txt
 tail -1 $OUT/r03p_f32_bench.json | cut -c1-300; tail -1 $OUT/r03p_bf16_bench.json | cut -c1-300
 rm -rf $OUT/r03p_f32 $OUT/r03p_f32_serial $OUT/r03p_f32_rd $OUT/r03p_f32_wr $OUT/r03p_bf16 $OUT/r03p_bf16_serial $OUT/r03p_bf16_rd $OUT/r03p_bf16_wr
