@@ -636,9 +636,27 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
         anext[0] = ldg16(rowptr);
         anext[1] = ldg16(rowptr + 16);
     };
+    // 1x1 (K <= 128): the waves of this kernel spend two thirds of their cycles waiting for their own loads (SQ_WAIT_ANY, round-3
+    // counters) -- a one-chunk look-ahead keeps 2 KB per wave in flight.  Here ALL pieces of a tile's dY rows (<= 8 per lane, 8 KB per
+    // wave) are requested together, and the next tile's right behind the epilogue's x requests.
+    constexpr bool FULLA = (TAPS == 1);
+    uint4 abuf[FULLA ? 8 : 1];
+    auto request_tile = [&](int t) {
+        set_tile(t);
+        const u16* rp = dY + (size_t)m * p.lda + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nck) {
+                abuf[(2 * c) % (FULLA ? 8 : 1)] = ldg16(rp + c * 32);
+                abuf[(2 * c + 1) % (FULLA ? 8 : 1)] = ldg16(rp + c * 32 + 16);
+            }
+    };
     const int tstride = gxd * nwaves;
     int tile = bx * nwaves + wave;
-    if (tile < ntiles) begin_tile(tile);
+    if (tile < ntiles) {
+        if constexpr (FULLA) request_tile(tile);
+        else begin_tile(tile);
+    }
     for (; tile < ntiles; tile += tstride) {
         f32x16 acc[NT];
 #pragma unroll
@@ -646,6 +664,23 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
+        if constexpr (FULLA) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nck) {
+                    const uint4* bb = Bs + (size_t)c * 4 * NB;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 av = __builtin_bit_cast(bf16x8, abuf[(2 * c + s) % (FULLA ? 8 : 1)]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else
         for (int ch = 0; ch < nchunks; ++ch) {
             uint4 acur[2] = {anext[0], anext[1]};
             const bool vthis = vcur;
@@ -707,7 +742,10 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
             }
             xp[j] = ldg16(pg.ptr + (size_t)row * pg.ld);
         }
-        if (tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
+        if (tile + tstride < ntiles) {      // the next tile's A: behind the x requests, ahead of the stores
+            if constexpr (FULLA) request_tile(tile + tstride);
+            else begin_tile(tile + tstride);
+        }
 #pragma unroll
         for (int j = 0; j < NPJ; ++j)
             *reinterpret_cast<uint4*>(T + (size_t)(pr0 + j * (64 / PPR)) * TP + 8 * pc8) = xp[j];
@@ -773,12 +811,15 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
     }
 }
 
+// waves per block: 16 (128 VGPRs) except the two-channel-tile 1x1 variant, whose whole-tile dY look-ahead needs the 168 of 12 waves
+constexpr int dg16_max_waves(int taps, int nt) { return (taps == 1 && nt == 2) ? 12 : B16_MAX_WAVES; }
+
 template <int TAPS, int NT>
-__global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(dg16_max_waves(TAPS, NT) * 64) void dgrad_bf16_kernel(const ConvArgs p) {
     dgrad_bf16_body<TAPS, NT>(p, blockIdx.x, blockIdx.y, gridDim.x);
 }
 template <int TAPS, int NT>
-__global__ __launch_bounds__(B16_MAX_WAVES * 64) void dgrad_bf16_pair_kernel(const ConvPair q) {
+__global__ __launch_bounds__(dg16_max_waves(TAPS, NT) * 64) void dgrad_bf16_pair_kernel(const ConvPair q) {
     dgrad_bf16_body<TAPS, NT>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
 }
 
@@ -1162,8 +1203,9 @@ static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, si
 // count the block may get at `bpc` blocks per CU.  Returns false when even one block per CU does not fit.
 static bool dgrad_bf16_plan(int NT, int taps, int Kpad, int Ccat, int& bpc, size_t& smem) {
     const size_t base = dgrad_bf16_smem(NT, taps, Kpad, Ccat);
+    const int maxw = dg16_max_waves(taps, NT);
     for (bpc = 3; bpc >= 1; --bpc) {
-        const int wmax = B16_MAX_WAVES / bpc < 4 ? 4 : B16_MAX_WAVES / bpc;
+        const int wmax = maxw / bpc < 4 ? 4 : maxw / bpc;
         smem = base + (size_t)wmax * 32 * (NT * 32 + 8) * 2;
         const size_t limit = bpc == 3 ? 50 * 1024 : (bpc == 2 ? 76 * 1024 : 150 * 1024);
         if (smem <= limit) return true;
@@ -1181,6 +1223,7 @@ hipError_t launch_dgrad_bf16_pair(const ConvArgs& a, const ConvArgs& b, int num_
 
 static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, int num_cus_all, hipStream_t s) {
     const int num_cus = pb ? num_cus_all / 2 : num_cus_all;      // a pair: each problem on half of the chip
+    if (a.taps == 1 && a.Kpad > 128) return hipErrorInvalidValue;      // (the 1x1 variants hold a whole tile's dY rows in 8 registers per lane)
     if (a.M % 32 || a.K % 32 || a.K != a.Kpad || (a.taps != 1 && a.taps != 9) || (a.W & 3) || a.lda % 8 || a.Nout % 8 || a.ldy % 8) return hipErrorInvalidValue;
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].C % 32 || a.seg[i].ld % 8) return hipErrorInvalidValue;
@@ -1201,7 +1244,8 @@ static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, 
     const int gy = (ncol32 + NT - 1) / NT;
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
-    if (waves > B16_MAX_WAVES / blocks_per_cu) waves = B16_MAX_WAVES / blocks_per_cu;
+    const int maxw = dg16_max_waves(a.taps, NT);
+    if (waves > maxw / blocks_per_cu) waves = maxw / blocks_per_cu;
     if (waves < 1) waves = 1;
     int gx = (ntiles + waves - 1) / waves;
     if (gx > max_blocks_x) gx = max_blocks_x;
