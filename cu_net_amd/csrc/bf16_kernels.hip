@@ -369,7 +369,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
         for (int ch = 0; ch < nchunks; ++ch) {
             uint4 acur[2] = {anext[0], anext[1]};
             const bool vthis = vcur;
-            if (ch + 1 < nchunks) {
+            if (ch + 1 < nchunks && !CUNET_DBG(p, 512)) {
                 if (++cl == ncs) { ++sidx; ++tap; enter(); }
                 vcur = tvalid;
                 anext[0] = ldg16(rowptr + cl * 32);
@@ -390,12 +390,15 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
                 a.y = pack_bf16(fmaxf(fmaf(bf16_lo(v.y), s0.z, h0.z), 0.f), fmaxf(fmaf(bf16_hi(v.y), s0.w, h0.w), 0.f));
                 a.z = pack_bf16(fmaxf(fmaf(bf16_lo(v.z), s1.x, h1.x), 0.f), fmaxf(fmaf(bf16_hi(v.z), s1.y, h1.y), 0.f));
                 a.w = pack_bf16(fmaxf(fmaf(bf16_lo(v.w), s1.z, h1.z), 0.f), fmaxf(fmaf(bf16_hi(v.w), s1.w, h1.w), 0.f));
+                if (CUNET_DBG(p, 4096)) a = v;                              // (timing experiments: no BatchNorm / ReLU arithmetic)
                 if (TAPS == 9 && !vthis) a = make_uint4(0, 0, 0, 0);        // zero padding is post-activation
                 const bf16x8 av = __builtin_bit_cast(bf16x8, a);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                    bf16x8 bv = av;
+                    if (!CUNET_DBG(p, 256)) bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);      // (256: no B reads)
+                    if (!CUNET_DBG(p, 1024)) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);      // (1024: no MFMA)
+                    else acc[nt][0] += bf16_lo(__builtin_bit_cast(uint4, bv).x) + bf16_lo(a.x);
                 }
             }
         }
@@ -431,7 +434,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
                         else p.mse_dout[(size_t)mm * p.mse_ldd + col] = 0.f;
                     }
                 }
-            } else if (col < p.Nout) {
+            } else if (col < p.Nout && !(CUNET_DBG(p, 2048) && acc[nt][0] != 1234.5f)) {      // (2048: no output stores)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1349,6 +1352,8 @@ static hipError_t launch_conv_bf16_impl(const ConvArgs& a, const ConvArgs* pb, i
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
     ConvArgs b = a;
+    static const int dbg16 = tune_int("CUNET_B16_DBG", 0);      // tuning builds only: work-skipping timing experiments (see the kernel)
+    b.dbg = dbg16;
     static const int xcd_fwd = tune_int("CUNET_CONV_XCD_FWD", 1);
     b.xcd_gx = b.xcd_gy = 0;
     if (xcd_fwd && gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid = dim3(8 * ((gx + 7) / 8) * gy, 1); }
