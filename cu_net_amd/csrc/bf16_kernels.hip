@@ -509,7 +509,7 @@ __global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_pair_kernel(cons
 // (= d beta, d gamma) in fp64.  Requirements: K (= Cout) and every segment multiples of 32, M of 32, W of 4.
 struct Grp16 { const u16* ptr; int ld; int ups; };
 
-template <int TAPS, int NT>
+template <int TAPS, int NT, int NCK = 0>       // NCK: 1x1 only, K / 32 as a compile-time constant (1 ... 4)
 __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;
@@ -527,7 +527,7 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the tile loop runs on scalar branches
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
@@ -642,17 +642,58 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
     // 1x1 (K <= 128): the waves of this kernel spend two thirds of their cycles waiting for their own loads (SQ_WAIT_ANY, round-3
     // counters) -- a one-chunk look-ahead keeps 2 KB per wave in flight.  Here ALL pieces of a tile's dY rows (<= 8 per lane, 8 KB per
     // wave) are requested together, and the next tile's right behind the epilogue's x requests.
+    // K / 32 is a template constant there: with a run-time chunk count the requests sit behind branches, the compiler loses count
+    // of what is outstanding and waits for vmcnt(0) -- i.e. for the look-ahead it has just issued -- before the epilogue's x.
     constexpr bool FULLA = (TAPS == 1);
-    uint4 abuf[FULLA ? 8 : 1];
+    static_assert(!FULLA || (NCK >= 1 && NCK <= 4), "1x1: K / 32 in 1 ... 4");
+    constexpr int NA = FULLA ? 2 * NCK : 1;
+    uint4 abuf[NA];
+    // the epilogue's x pieces (see below): this lane's piece column is the same for every tile
+    constexpr int PPR = NB / 8;                       // pieces per tile row
+    constexpr int NPJ = (32 * PPR) / 64;              // pieces per lane (4 for NB = 64, 2 for NB = 32)
+    const int pc8 = lane % PPR;                       // this lane's piece column ...
+    const int pr0 = lane / PPR;                       // ... and first row; further rows every 64 / PPR
+    const int pcol = n0 + 8 * pc8;
+    const bool pok = pcol < p.Nout;
+    Grp16 pg;
+    pg.ptr = dY; pg.ld = 0; pg.ups = 0;
+    if (pok) pg = grp[pcol >> 2];
+    uint4 xp[NPJ];
+    auto request_x = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            const int mm = t * 32 + pr0 + j * (64 / PPR);
+            int row = mm;
+            if (p.any_ups && pg.ups) {
+                int ni, yy, xx;
+                if (p.wshift >= 0) {
+                    ni = mm >> p.hwshift;
+                    const int rm = mm & (HW - 1);
+                    yy = rm >> p.wshift;
+                    xx = rm & (p.W - 1);
+                } else {
+                    ni = mm / HW;
+                    const int rm = mm - ni * HW;
+                    yy = rm / p.W;
+                    xx = rm - yy * p.W;
+                }
+                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            }
+            xp[j] = ldg16(pg.ptr + (size_t)row * pg.ld);
+        }
+    };
+    // 1x1: a tile's dY AND its x pieces go out together, after the previous tile's dz stores.  One round trip per tile (a wave
+    // with one tile -- every launch at 32 x 32 and below -- used to make two), the stores complete under it, and the request count
+    // is the same on the loop's entry and back edge, so the waits are exact (vmcnt is one in-order counter of loads and stores).
     auto request_tile = [&](int t) {
         set_tile(t);
         const u16* rp = dY + (size_t)m * p.lda + 8 * hi;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < nck) {
-                abuf[(2 * c) % (FULLA ? 8 : 1)] = ldg16(rp + c * 32);
-                abuf[(2 * c + 1) % (FULLA ? 8 : 1)] = ldg16(rp + c * 32 + 16);
-            }
+        for (int c = 0; c < (FULLA ? NCK : 0); ++c) {
+            abuf[(2 * c) % NA] = ldg16(rp + c * 32);
+            abuf[(2 * c + 1) % NA] = ldg16(rp + c * 32 + 16);
+        }
+        request_x(t);
     };
     const int tstride = gxd * nwaves;
     int tile = bx * nwaves + wave;
@@ -660,7 +701,7 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
         if constexpr (FULLA) request_tile(tile);
         else begin_tile(tile);
     }
-    for (; tile < ntiles; tile += tstride) {
+    while (tile < ntiles) {
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -669,17 +710,15 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
 
         if constexpr (FULLA) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < nck) {
-                    const uint4* bb = Bs + (size_t)c * 4 * NB;
+            for (int c = 0; c < NCK; ++c) {
+                const uint4* bb = Bs + (size_t)c * 4 * NB;
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const bf16x8 av = __builtin_bit_cast(bf16x8, abuf[(2 * c + s) % (FULLA ? 8 : 1)]);
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, abuf[(2 * c + s) % NA]);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
-                        }
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
                     }
                 }
             }
@@ -714,40 +753,9 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
         //      two-byte version issued 64 memory instructions per lane and tile next to 16 MFMAs; LDS takes the narrow ones.
         const int mrow0 = tile * 32;
         u16* T = tileT + (size_t)wave * 32 * TP;
-        constexpr int PPR = NB / 8;                       // pieces per tile row
-        constexpr int NPJ = (32 * PPR) / 64;              // pieces per lane (4 for NB = 64, 2 for NB = 32)
-        const int pc8 = lane % PPR;                       // this lane's piece column ...
-        const int pr0 = lane / PPR;                       // ... and first row; further rows every 64 / PPR
-        const int pcol = n0 + 8 * pc8;
-        const bool pok = pcol < p.Nout;
-        Grp16 pg;
-        pg.ptr = dY; pg.ld = 0; pg.ups = 0;
-        if (pok) pg = grp[pcol >> 2];
-        uint4 xp[NPJ];
-#pragma unroll
-        for (int j = 0; j < NPJ; ++j) {
-            const int mm = mrow0 + pr0 + j * (64 / PPR);
-            int row = mm;
-            if (p.any_ups && pg.ups) {
-                int ni, yy, xx;
-                if (p.wshift >= 0) {
-                    ni = mm >> p.hwshift;
-                    const int rm = mm & (HW - 1);
-                    yy = rm >> p.wshift;
-                    xx = rm & (p.W - 1);
-                } else {
-                    ni = mm / HW;
-                    const int rm = mm - ni * HW;
-                    yy = rm / p.W;
-                    xx = rm - yy * p.W;
-                }
-                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
-            }
-            xp[j] = ldg16(pg.ptr + (size_t)row * pg.ld);
-        }
-        if (tile + tstride < ntiles) {      // the next tile's A: behind the x requests, ahead of the stores
-            if constexpr (FULLA) request_tile(tile + tstride);
-            else begin_tile(tile + tstride);
+        if constexpr (!FULLA) {
+            request_x(tile);
+            if (tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
         }
 #pragma unroll
         for (int j = 0; j < NPJ; ++j)
@@ -762,16 +770,22 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
             if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
             float s1 = 0.f, s2 = 0.f;
             u16* tcol = T + nt * 32 + li;
+            // (three passes: a read next to a write of the same array is ordered by the compiler, which made this 16 dependent
+            // LDS round trips per column tile)
+            float xv[16];
+            u16 dq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = bf16_lo((unsigned)tcol[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * TP]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float xv = bf16_lo((unsigned)tcol[(size_t)rr * TP]);
-                const float z = fmaf(xv, csc, csh);
+                const float z = fmaf(xv[r], csc, csh);
                 const float dz = (colok && z > 0.f) ? acc[nt][r] : 0.f;
-                tcol[(size_t)rr * TP] = (u16)(pack_bf16(dz, 0.f) & 0xffffu);
+                dq[r] = (u16)(pack_bf16(dz, 0.f) & 0xffffu);
                 s1 += dz;
-                s2 = fmaf(dz, (xv - cmu) * cis, s2);
+                s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tcol[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * TP] = dq[r];
             dsum[nt] += (double)s1;
             dsq[nt] += (double)s2;
         }
@@ -787,6 +801,10 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
         __builtin_amdgcn_wave_barrier();
+        tile += tstride;
+        if constexpr (FULLA) {
+            if (tile < ntiles) request_tile(tile);
+        }
     }
 
     if (p.ystats != nullptr) {
@@ -817,13 +835,13 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
 // waves per block: 16 (128 VGPRs) except the two-channel-tile 1x1 variant, whose whole-tile dY look-ahead needs the 168 of 12 waves
 constexpr int dg16_max_waves(int taps, int nt) { return (taps == 1 && nt == 2) ? 12 : B16_MAX_WAVES; }
 
-template <int TAPS, int NT>
+template <int TAPS, int NT, int NCK = 0>
 __global__ __launch_bounds__(dg16_max_waves(TAPS, NT) * 64) void dgrad_bf16_kernel(const ConvArgs p) {
-    dgrad_bf16_body<TAPS, NT>(p, blockIdx.x, blockIdx.y, gridDim.x);
+    dgrad_bf16_body<TAPS, NT, NCK>(p, blockIdx.x, blockIdx.y, gridDim.x);
 }
-template <int TAPS, int NT>
+template <int TAPS, int NT, int NCK = 0>
 __global__ __launch_bounds__(dg16_max_waves(TAPS, NT) * 64) void dgrad_bf16_pair_kernel(const ConvPair q) {
-    dgrad_bf16_body<TAPS, NT>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
+    dgrad_bf16_body<TAPS, NT, NCK>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1164,12 +1182,12 @@ static size_t dgrad_bf16_smem(int NT, int taps, int Kpad, int Ccat) {
     return (size_t)taps * (Kpad / 8) * NT * 32 * 16 + (size_t)Ccat * 16 + (size_t)(Ccat / 4) * sizeof(Grp16) + (size_t)NT * 32 * 16 + 16;
 }
 
-template <int TAPS, int NT>
+template <int TAPS, int NT, int NCK = 0>
 static hipError_t launch_dg16_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
     if constexpr (TAPS == 1) {
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_pair_kernel<TAPS, NT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_pair_kernel<TAPS, NT, NCK>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_done = true;
@@ -1179,24 +1197,24 @@ static hipError_t launch_dg16_pair_inst(const ConvArgs& a, const ConvArgs& b, di
         q.a[1] = b;
         copy_launch_geometry(q.a[1], a);
         grid.z = 2;
-        hipLaunchKernelGGL((dgrad_bf16_pair_kernel<TAPS, NT>), grid, dim3(threads), smem, s, q);
+        hipLaunchKernelGGL((dgrad_bf16_pair_kernel<TAPS, NT, NCK>), grid, dim3(threads), smem, s, q);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;
     }
 }
 
-template <int TAPS, int NT>
+template <int TAPS, int NT, int NCK = 0>
 static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* pb = nullptr) {
-    if (pb) return launch_dg16_pair_inst<TAPS, NT>(a, *pb, grid, threads, smem, s);
+    if (pb) return launch_dg16_pair_inst<TAPS, NT, NCK>(a, *pb, grid, threads, smem, s);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_kernel<TAPS, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_kernel<TAPS, NT, NCK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((dgrad_bf16_kernel<TAPS, NT>), grid, dim3(threads), smem, s, a);
+    hipLaunchKernelGGL((dgrad_bf16_kernel<TAPS, NT, NCK>), grid, dim3(threads), smem, s, a);
     return hipGetLastError();
 }
 
@@ -1260,7 +1278,14 @@ static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, 
     dim3 grid1 = grid;
     b.xcd_gx = b.xcd_gy = 0;
     if (gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid1 = dim3(8 * ((gx + 7) / 8) * gy, 1); }
-    if (a.taps == 1) return NT == 2 ? launch_dg16_inst<1, 2>(b, grid1, threads, smem, s, pb) : launch_dg16_inst<1, 1>(b, grid1, threads, smem, s, pb);
+    if (a.taps == 1) {
+        switch (a.Kpad / 32) {
+#define CUNET_DG1(C) case C: return NT == 2 ? launch_dg16_inst<1, 2, C>(b, grid1, threads, smem, s, pb) : launch_dg16_inst<1, 1, C>(b, grid1, threads, smem, s, pb);
+            CUNET_DG1(1) CUNET_DG1(2) CUNET_DG1(3) CUNET_DG1(4)
+#undef CUNET_DG1
+            default: return hipErrorInvalidValue;
+        }
+    }
     return NT == 2 ? launch_dg16_inst<9, 2>(b, grid1, threads, smem, s, pb) : launch_dg16_inst<9, 1>(b, grid1, threads, smem, s, pb);
 }
 
