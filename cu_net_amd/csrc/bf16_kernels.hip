@@ -278,7 +278,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
     const int n0 = by * NB;
     const u16* wB = reinterpret_cast<const u16*>(p.wB);
 
-    {   // B operand -> LDS (8 loads in flight per thread)
+    if (!CUNET_DBG(p, 32)) {   // B operand -> LDS (8 loads in flight per thread)
         const int total = brows * NB;
         for (int base = tid; base < total; base += blockDim.x * 8) {
             uint4 v[8];
@@ -299,7 +299,8 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
             }
         }
     }
-    if (p.training) {          // batch statistics of each segment (fp64 sums written by the producers' epilogues)
+    if (CUNET_DBG(p, 64)) {    // (timing experiments: no BatchNorm table)
+    } else if (p.training) {          // batch statistics of each segment (fp64 sums written by the producers' epilogues)
         for (int sgi = 0; sgi < p.nseg; ++sgi) {
             const Seg sg = p.seg[sgi];
             for (int lc = tid; lc < sg.C; lc += blockDim.x) {
@@ -369,7 +370,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
         for (int ch = 0; ch < nchunks; ++ch) {
             uint4 acur[2] = {anext[0], anext[1]};
             const bool vthis = vcur;
-            if (ch + 1 < nchunks && !CUNET_DBG(p, 512)) {
+            if (ch + 1 < nchunks) {
                 if (++cl == ncs) { ++sidx; ++tap; enter(); }
                 vcur = tvalid;
                 anext[0] = ldg16(rowptr + cl * 32);
@@ -390,15 +391,12 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
                 a.y = pack_bf16(fmaxf(fmaf(bf16_lo(v.y), s0.z, h0.z), 0.f), fmaxf(fmaf(bf16_hi(v.y), s0.w, h0.w), 0.f));
                 a.z = pack_bf16(fmaxf(fmaf(bf16_lo(v.z), s1.x, h1.x), 0.f), fmaxf(fmaf(bf16_hi(v.z), s1.y, h1.y), 0.f));
                 a.w = pack_bf16(fmaxf(fmaf(bf16_lo(v.w), s1.z, h1.z), 0.f), fmaxf(fmaf(bf16_hi(v.w), s1.w, h1.w), 0.f));
-                if (CUNET_DBG(p, 4096)) a = v;                              // (timing experiments: no BatchNorm / ReLU arithmetic)
                 if (TAPS == 9 && !vthis) a = make_uint4(0, 0, 0, 0);        // zero padding is post-activation
                 const bf16x8 av = __builtin_bit_cast(bf16x8, a);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    bf16x8 bv = av;
-                    if (!CUNET_DBG(p, 256)) bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);      // (256: no B reads)
-                    if (!CUNET_DBG(p, 1024)) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);      // (1024: no MFMA)
-                    else acc[nt][0] += bf16_lo(__builtin_bit_cast(uint4, bv).x) + bf16_lo(a.x);
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bb[(2 * s + hi) * NB + nt * 32 + li]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
                 }
             }
         }

@@ -81,8 +81,8 @@ struct ConvArgs {
     int mse_ldd;           // leading dimension of mse_dout (elements): ldy, or the padded K of a bf16 head gradient (see head_grad_ld)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
                            // planner option conv3x3_ring_min_rows; 0 = the default 512)
-    int dbg;               // timing experiments only (CUNET_CONV_DBG; conv_bf16_kernel: CUNET_B16_DBG = 256 no B reads from LDS, 512 no A
-                           // loads after a tile's first chunk, 1024 no MFMA, 2048 no output stores, 4096 no BatchNorm / ReLU arithmetic):
+    int dbg;               // timing experiments only (CUNET_CONV_DBG; conv_bf16_kernel: CUNET_B16_DBG = 32 / 64 as below, 2048 no output
+                           // stores -- switches inside its chunk loop made the tuning build's kernel 3x slower and were removed):
                            // 1 no stats atomics, 4 no MFMA, 32 no B preload,
                            // 64 no BN table setup, 128 no tile loop (coarse flags only: a flag test inside an
                            // element loop is a branch around a load and serialises it)

@@ -179,9 +179,42 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     const int tstride = gxd * nwaves;
     int tile = bx * nwaves + wave;
     if (FAST && EARLY_NEXT && tile < ntiles) begin_tile(tile);
+    // TEPI: this lane's four 16-byte pieces of the tile's x (see the epilogue); the piece column does not depend on the tile
+    const int pc4 = lane & 7, pr0 = lane >> 3;          // piece column / first row (further rows + 8)
+    const int pcol = n0 + 4 * pc4;
+    const bool pok = pcol < p.Nout;
+    GrpEnt pg;
+    pg.ptr = p.a; pg.ld = 0; pg.ups = 0;                 // always a valid address
+    if (TEPI && pok) pg = grp[pcol >> 2];
+    float4 xp[TEPI ? 4 : 1];
     for (; tile < ntiles; tile += tstride) {
         if (!FAST) set_tile(tile);
         if (FAST && !EARLY_NEXT) begin_tile(tile);
+        if constexpr (TEPI) {
+            // requested HERE, in front of the tile's 64 MFMAs, not in the epilogue: x does not depend on them, and a wave that
+            // asks after its MFMAs sits out a full memory round trip per tile with nothing of its own to do
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mm = tile * 32 + pr0 + 8 * j;
+                int row = mm;
+                if (p.any_ups && pg.ups) {
+                    int ni, yy, xx;
+                    if (p.wshift >= 0) {
+                        ni = mm >> p.hwshift;
+                        const int rm = mm & (HW - 1);
+                        yy = rm >> p.wshift;
+                        xx = rm & (p.W - 1);
+                    } else {
+                        ni = mm / HW;
+                        const int rm = mm - ni * HW;
+                        yy = rm / p.W;
+                        xx = rm - yy * p.W;
+                    }
+                    row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+                }
+                xp[j] = ldg4(pg.ptr + (size_t)row * pg.ld);
+            }
+        }
 
         f32x16 acc[NT];
 #pragma unroll
@@ -336,34 +369,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             // into the wave's LDS tile T[32][36], the tile is read back in the accumulator layout, dz overwrites the x it came
             // from, and leaves as four 16-byte stores per lane.
             float* T = tileT + (size_t)wave * 32 * TEPI_PITCH;
-            const int pc4 = lane & 7, pr0 = lane >> 3;          // piece column / first row (further rows + 8)
-            const int pcol = n0 + 4 * pc4;
-            const bool pok = pcol < p.Nout;
-            GrpEnt pg;
-            pg.ptr = p.a; pg.ld = 0; pg.ups = 0;                 // always a valid address
-            if (pok) pg = grp[pcol >> 2];
-            float4 xp[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int mm = mrow0 + pr0 + 8 * j;
-                int row = mm;
-                if (p.any_ups && pg.ups) {
-                    int ni, yy, xx;
-                    if (p.wshift >= 0) {
-                        ni = mm >> p.hwshift;
-                        const int rm = mm & (HW - 1);
-                        yy = rm >> p.wshift;
-                        xx = rm & (p.W - 1);
-                    } else {
-                        ni = mm / HW;
-                        const int rm = mm - ni * HW;
-                        yy = rm / p.W;
-                        xx = rm - yy * p.W;
-                    }
-                    row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
-                }
-                xp[j] = ldg4(pg.ptr + (size_t)row * pg.ld);
-            }
             if (tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * TEPI_PITCH + 4 * pc4) = xp[j];
@@ -376,17 +381,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
                 if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
                 float s1 = 0.f, s2 = 0.f;
                 float* tcol = T + li;
+                // (three passes -- reads, arithmetic, writes: a read next to a write of the same array is ordered by the compiler,
+                // i.e. 16 dependent LDS round trips per tile)
+                float xv[16], dzv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float xv = tcol[rr * TEPI_PITCH];
-                    const float z = fmaf(xv, csc, csh);
+                    const float z = fmaf(xv[r], csc, csh);
                     // ReLU mask; with a QuanInput behind the ReLU also its straight-through mask (no gradient where z >= 1)
-                    const float dz = (colok && z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[0][r] : 0.f;
-                    tcol[rr * TEPI_PITCH] = dz;
-                    s1 += dz;
-                    s2 = fmaf(dz, colok ? (xv - cmu) * cis : 0.f, s2);
+                    dzv[r] = (colok && z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[0][r] : 0.f;
+                    s1 += dzv[r];
+                    s2 = fmaf(dzv[r], colok ? (xv[r] - cmu) * cis : 0.f, s2);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH] = dzv[r];
                 dsum[0] += (double)s1;
                 dsq[0] += (double)s2;
             }
