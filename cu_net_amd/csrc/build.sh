@@ -6,7 +6,9 @@ set -e
 cd "$(dirname "$0")"
 SRCS="augment_kernels.hip conv_kernels.hip wgrad_kernels.hip wgrad3_kernels.hip elementwise_kernels.hip quant_kernels.hip bf16_kernels.hip runtime.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function"
-if [ -n "${CUNET_PROBE_WG3_MIN_WAVES:-}" ]; then      # probe build (tools only): the fp32 wgrad3 kernels compiled for 3 waves per SIMD
+if [ -n "${CUNET_PROBE_DEFS:-}" ]; then      # probe build (tools only): the tuning library with extra -D switches, e.g. "-DCUNET_TEPI_WAVES=16"
+  OUT=../libcunet_hip_probe.so; BUILD=build_probe; FLAGS="$FLAGS -DCUNET_TUNING $CUNET_PROBE_DEFS"
+elif [ -n "${CUNET_PROBE_WG3_MIN_WAVES:-}" ]; then      # probe build (tools only): the fp32 wgrad3 kernels compiled for 3 waves per SIMD
   OUT=../libcunet_hip_probe.so; BUILD=build_probe; FLAGS="$FLAGS -DCUNET_TUNING -DCUNET_WG3_MIN_WAVES=$CUNET_PROBE_WG3_MIN_WAVES"
 elif [ -n "${CUNET_TUNING:-}" ]; then
   OUT=../libcunet_hip_tuning.so; BUILD=build_tuning; FLAGS="$FLAGS -DCUNET_TUNING"

@@ -28,6 +28,11 @@
 namespace cunet {
 
 constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
+#ifndef CUNET_TEPI_WAVES
+#define CUNET_TEPI_WAVES 12              // the fp32 1x1 / 3x3 data gradient with the LDS-tile epilogue (118 VGPRs: 16 would fit; probe builds)
+#endif
+template <int LD, int EP, int NT, bool FAST, int XBG>
+constexpr int conv_max_waves() { return (EP == EP_BWD && FAST && NT == 1 && XBG == 0) ? CUNET_TEPI_WAVES : CONV_MAX_WAVES; }
 
 // (the body is a device function of (arguments, block coordinates): conv_kernel runs it on one problem, conv_pair_kernel on the
 // problem blockIdx.z selects out of two)
@@ -583,7 +588,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
 }
 
 template <int LD, int EP, int NT, bool FAST, int XBG = 0>
-__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArgs p) {
+__global__ __launch_bounds__((conv_max_waves<LD, EP, NT, FAST, XBG>() * 64)) void conv_kernel(const ConvArgs p) {
     conv_body<LD, EP, NT, FAST, XBG>(p, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_kernel(const ConvArg
 // (models/cu_net.py:139-142), and their data gradients are adjacent in the backward: gridDim.z = 2, blockIdx.z picks the problem
 // (its own weights, BatchNorm, output and statistics), each on half of the workgroups a single launch would use.
 template <int LD, int EP, int NT, bool FAST, int XBG = 0>
-__global__ __launch_bounds__(CONV_MAX_WAVES * 64) void conv_pair_kernel(const ConvPair q) {
+__global__ __launch_bounds__((conv_max_waves<LD, EP, NT, FAST, XBG>() * 64)) void conv_pair_kernel(const ConvPair q) {
     conv_body<LD, EP, NT, FAST, XBG>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
 }
 
@@ -1233,10 +1238,12 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     if (smem > CONV_LDS_BUDGET) return hipErrorInvalidValue;   // weights of one 32-channel slice exceed the LDS
     const int gy = (ncol32 + NT - 1) / NT;
     int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
+    int maxw = CONV_MAX_WAVES;            // 16 waves for one-tile blocks (VGPR budget 128) measured 2-3 % slower
     if (epi == EP_BWD && fast && NT == 1 && a.xbf16 == 0) {      // + one epilogue tile per wave (TEPI instantiations of the kernel)
+        maxw = CUNET_TEPI_WAVES;
         const size_t base = smem;
         for (blocks_per_cu = 3; blocks_per_cu >= 1; --blocks_per_cu) {
-            const int wmax = CONV_MAX_WAVES / blocks_per_cu < 4 ? 4 : CONV_MAX_WAVES / blocks_per_cu;
+            const int wmax = maxw / blocks_per_cu < 4 ? 4 : maxw / blocks_per_cu;
             smem = base + (size_t)wmax * CONV_TEPI_TILE;
             if (smem <= (blocks_per_cu == 3 ? 52 * 1024 : (blocks_per_cu == 2 ? 80 * 1024 : CONV_LDS_BUDGET))) break;
         }
@@ -1244,7 +1251,6 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     }
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
-    const int maxw = CONV_MAX_WAVES;      // 16 waves for one-tile blocks (VGPR budget 128) measured 2-3 % slower
     if (waves > maxw / blocks_per_cu) waves = maxw / blocks_per_cu;
     if (waves < 1) waves = 1;
     int gx = (ntiles + waves - 1) / waves;

@@ -154,6 +154,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "wgrad3_stem") o.wgrad3_stem = value;
     else if (n == "conv3x3_ring_min_rows") o.conv3x3_ring_min_rows = value;
     else if (n == "wgrad_fork_group") o.wgrad_fork_group = value;
+    else if (n == "wgrad_fork_group_bf16") o.wgrad_fork_group_bf16 = value;
     else if (n == "fwd_fork_min_w") o.fwd_fork_min_w = value;
     else if (n == "pair_adapters") o.pair_adapters = value;
     else if (n == "heads_on_side") o.heads_on_side = value;
@@ -1078,7 +1079,8 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
     int bucket_hi = (int)P.nodes.size();                       // nodes [k+1, bucket_hi) belong to cur_bucket
     std::vector<int> pending;                                  // nodes whose weight gradient has not been forked yet
-    const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, P.opts.wgrad_fork_group) : 1;
+    // (bf16 gradient tensors: shorter kernels, the hand-over bubble weighs more -- 8 per group measured best there, 4 in fp32)
+    const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, E.xmode == 2 ? P.opts.wgrad_fork_group_bf16 : P.opts.wgrad_fork_group) : 1;
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued

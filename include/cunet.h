@@ -245,6 +245,7 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "wgrad_fork_group"   backward hands the weight gradients to the internal side stream in groups of this many nodes (default 4):
  *                        every hand-over is an event record on the caller's stream, i.e. a marker packet the next kernel waits
  *                        behind (6-7 us of bubble on the critical path each); 1 = one hand-over per node
+ *   "wgrad_fork_group_bf16"  the same when the gradient tensors are stored as bf16 (default 8)
  *   "fwd_fork_min_w"     forward: the down blocks' skip adapters run on the side stream at levels at least this wide (default 0: all)
  *   "pair_adapters"      1 (default): the ahead and the skip adapter of a down block (two 1x1 convolutions over the same concat,
  *                        models/cu_net.py:139-142) share ONE launch, forward and data gradient, where the shape has a pair kernel;
