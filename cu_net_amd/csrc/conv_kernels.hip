@@ -38,7 +38,11 @@ constexpr int conv_max_waves() { return (EP == EP_BWD && FAST && NT == 1 && XBG 
 // problem blockIdx.z selects out of two)
 template <int LD, int EP, int NT, bool FAST, int XBG>           // XBG, EP_BWD only: 1 = x of the concat is bf16, 2 = x, dY and dz are bf16
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
-    constexpr int XB = XBG != 0;                     // storage of x
+    constexpr int XB = (XBG == 1 || XBG == 2);       // storage of x
+    // XBG = 3 (EP_FWD only): the heat-map heads' fused MSE epilogue.  Its 16 target values per channel tile were live next to the
+    // accumulators in EVERY forward instantiation and cost the 128-column one 20 spilled registers, reloaded from scratch one by
+    // one in its store epilogue (rocm ISA, round 3); only the heads' kernels carry it now.
+    constexpr bool MSE = (EP == EP_FWD && XBG == 3);
     constexpr int GB = (XBG == 2 && (LD == LD_PLAIN || LD == LD_PLAIN3)) ? 1 : 0;      // storage of the gradient tensors
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
@@ -483,7 +487,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             const int col = n0 + nt * 32 + li;
             const bool colok = col < p.Nout;
             float s1 = 0.f, s2 = 0.f;
-            if (EP == EP_FWD && p.mse_tgt != nullptr) {
+            if (MSE) {
                 // heat-map head with the pixelwise MSE fused in (uniform branch): the target values are requested first
                 const float ginv = (float)(2.0 * p.mse_inv);
                 const bool padcol = !colok && col < p.mse_ldd;      // pad columns of d(loss)/d(out) must read as zero downstream
@@ -550,7 +554,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     }
     }
 
-    if (EP == EP_FWD && p.mse_tgt != nullptr) {      // fused MSE: sum of squared errors of the block -> one fp64 atomic
+    if (MSE) {      // fused MSE: sum of squared errors of the block -> one fp64 atomic
         double t = 0.0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) t += dsum[nt];
@@ -1133,7 +1137,17 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 gr
 
 template <int LD, int EP, int NT, bool FAST, int XB = 0>      // XB: 0 / 1 / 2 as ConvArgs::xbf16
 static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* b = nullptr) {
-    if (b) return launch_pair_inst<LD, EP, NT, FAST, XB>(a, *b, grid, threads, smem, s);
+    if constexpr (EP == EP_FWD && XB == 0 && LD == LD_SEG) {
+        if (a.mse_tgt != nullptr) {        // a head with the loss fused in: the instantiation that carries the MSE epilogue
+            if (b) return hipErrorInvalidValue;
+            return launch_inst<LD, EP, NT, FAST, 3>(a, grid, threads, smem, s, nullptr);
+        }
+    } else if constexpr (XB != 3) {
+        if (a.mse_tgt != nullptr) return hipErrorInvalidValue;      // (the fused loss exists for the 1x1 forward only)
+    }
+    if constexpr (XB != 3) {
+        if (b) return launch_pair_inst<LD, EP, NT, FAST, XB>(a, *b, grid, threads, smem, s);
+    }
     static bool attr_done = false;
     if (!attr_done) {       // dynamic LDS above 64 KB has to be opted into, once per instantiation
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<LD, EP, NT, FAST, XB>),
