@@ -90,7 +90,11 @@ int cunet_bind(cunet_plan_t* plan, float* params, float* grads, float* buffers, 
  *   heat[i]: N x class_num x H/4 x W/4 fp32 NCHW (device), i < loss_num; may be NULL to skip the copy-out
  *   training != 0: BatchNorm uses batch statistics and running stats / counters are updated
  *                  (once per BN; the reference's extra checkpoint-recompute update is applied
- *                  by cunet_backward, as in the reference where it happens inside backward()). */
+ *                  by cunet_backward, as in the reference where it happens inside backward()).
+ * Stream semantics of the hot path: every call only ENQUEUES work and never waits for the device.  A training forward and the
+ * backward also use a library-internal low-priority side stream (heat-map heads, skip adapters without a pair kernel, weight
+ * gradients); before cunet_forward / cunet_backward return, `stream` has been made to wait for everything they put there, so the
+ * caller only ever orders against / synchronises `stream` (cunet_backward_ex: see the bucket callback's contract below). */
 int cunet_forward(cunet_plan_t* plan, const float* x, float* const* heat, int training, void* stream);
 
 /* loss: replaces cu-net.py:175-178. Writes sum_k mean((out_k - target)^2) to *loss (device float)
