@@ -37,8 +37,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# classes cu_net_amd/csrc/runtime.hip launches on its internal side stream in a training step
-SIDE_STREAM_CLASSES = {'conv1x1_bwd_weight', 'conv3x3_bwd_weight', 'stem_bwd_weight', 'conv1x1_bwd_weight_bf16', 'conv3x3_bwd_weight_bf16'}
+# (which launches ran on the library's internal low-priority side stream -- weight gradients, heat-map heads of a training pass,
+# skip adapters without a pair kernel -- is recorded per launch by the library: cunet_profile_get_stream)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
@@ -70,23 +70,79 @@ def synthetic_batch(n, class_num, hw, seed, device):
     return x.to(device), t.to(device)
 
 
+def host_cpu():
+    """(model string, physical cores) of this host from /proc/cpuinfo; physical = distinct (package, core id) pairs."""
+    model, cores, phys, core = 'unknown', set(), None, None
+    try:
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name' and model == 'unknown':
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif k == '' and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    return model, n
+
+
 def cpu_baseline(layers, class_num, steps):
-    """CPU oracle (kind 'port': restatement of the reference, bit-exact to it on the golden vectors)
-    timed on this host: CU-Net-L order 1, bs=4, 256x256 (BASELINE.json configs[0]), full train step."""
+    """CPU oracle (kind 'port': restatement of the reference, bit-exact to it on the golden vectors) timed on this host:
+    CU-Net-L order 1, bs=4, 256x256 (BASELINE.json configs[0]), full train step -- with torch.set_num_threads(n) for
+    n = the host's physical cores (the headline `value` / `cores`) and n = 8 (comparable with SURVEY 8d's 8-vCPU probe)."""
     from oracle import cunet_ref as O
-    cores = torch.get_num_threads()
+    model, phys = host_cpu()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     spec = O.Spec(4, 32, 128, class_num, layers, 1, layers)
-    st = O.init_state(spec, seed=2)
     x, t = O.synthetic_batch(4, class_num, 256, seed=0)
-    opt = {}
-    O.train_step(spec, st, x, t, opt)            # warm-up (first step is several times slower)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.train_step(spec, st, x, t, opt)
-    dt = time.perf_counter() - t0
-    return {'value': round(4 * steps / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    saved = torch.get_num_threads()
+
+    def run(n):
+        torch.set_num_threads(n)
+        st = O.init_state(spec, seed=2)
+        opt = {}
+        O.train_step(spec, st, x, t, opt)            # warm-up (first step is several times slower)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            O.train_step(spec, st, x, t, opt)
+        return round(4 * steps / (time.perf_counter() - t0), 3)
+    try:
+        n_main = max(1, min(phys, usable))
+        v_main = run(n_main)
+        v8 = run(min(8, usable)) if n_main != min(8, usable) else v_main
+    finally:
+        torch.set_num_threads(saved)
+    return {'value': v_main, 'unit': 'images/sec', 'cores': n_main, 'kind': 'port',
+            'cpu_model': model, 'physical_cores': phys, 'logical_cpus_usable': usable,
+            'at_8_threads': {'value': v8, 'cores': min(8, usable)},
             'sample': f'CU-Net-{layers} order 1 K={class_num}, bs=4, 256x256 fp32, {steps} full train steps '
-                      f'(fwd+MSE+bwd+RMSprop) after 1 warm-up, torch CPU {torch.__version__}'}
+                      f'(fwd+MSE+bwd+RMSprop) after 1 warm-up at each thread count, torch CPU {torch.__version__}'}
+
+
+def load_mfma_busy(cls, workload_key):
+    """MFMA pipe utilisation of a kernel class, alone on the GPU, from the newest committed SQ-counter pass of THIS workload
+    (profiles/rNN_*mfma_busy.json, written by tools/pmc_summary.py --classes from a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+    ...` run with the side stream off): busy SIMD-cycles / (launch duration x 2.4 GHz x 1024 SIMDs)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_busy.json')), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        if tj.get('workload') != workload_key:
+            continue
+        ent = tj.get('classes', {}).get(cls)
+        if ent:
+            return ent, f'{os.path.basename(path)} (separate rocprofv3 --pmc pass at commit {tj.get("commit", "?")}, side stream off; not this run)'
+    return None, None
 
 
 def load_traffic(cls, workload_key):
@@ -106,6 +162,12 @@ def load_traffic(cls, workload_key):
             return ent['hbm_bytes_per_launch'], (f'{os.path.basename(path)} (FETCH_SIZE x2 + WRITE_SIZE per launch; '
                                                  f'separate rocprofv3 --pmc passes at commit {tj.get("commit", "r01")}, not this run)')
     return None, None
+
+
+def coll_device(pg, dev):
+    """Device of the small tensors handed to collectives: the GPU under RCCL, the host under gloo (the de-risking backend)."""
+    import torch.distributed as dist
+    return torch.device('cpu') if dist.get_backend(pg) == 'gloo' else dev
 
 
 def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0, forward_only=False, popcount=False,
@@ -164,17 +226,21 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
         loss = one_step()
     torch.cuda.synchronize(dev)
     prof_all = plan.handle.profile_collect()
+    prof_main = plan.handle.profile_collect(0)      # launches on the caller's stream only
+    prof_side = plan.handle.profile_collect(1)      # launches on the library's side stream only
     plan.handle.profile_begin(0)
     have_classes = any(v[0] for v in prof_all.values())
-    # The roofline class is the largest one ON THE CALLER'S STREAM -- the step's critical path.  The weight gradients run on the
-    # library's low-priority side stream, where a launch's duration includes the time it is switched out for the caller's kernels;
-    # when their inflated sum is the largest of the step it is reported next to the roofline as `largest_side_stream_class`.
-    on_path = {k: v for k, v in prof_all.items() if serial or k not in SIDE_STREAM_CLASSES}
-    dominant = force_class or max((on_path or prof_all).items(), key=lambda kv: kv[1][1])[0]
-    overall = max(prof_all.items(), key=lambda kv: kv[1][1])
+    # The roofline class is the largest one ON THE CALLER'S STREAM -- the step's critical path -- counted over the launches that
+    # really ran there (the library tags every record with its stream).  On the low-priority side stream a launch's duration
+    # includes the time it is switched out for the caller's kernels; when a class's inflated sum there is the largest of the step
+    # it is reported next to the roofline as `largest_side_stream_class`.
+    which = -1 if serial else 0
+    on_path = prof_all if serial else prof_main
+    dominant = force_class or max(on_path.items(), key=lambda kv: kv[1][1])[0]
+    side_top = max(prof_side.items(), key=lambda kv: kv[1][1])
     side_note = None
-    if overall[0] != dominant and not force_class:
-        side_note = {'kernel': overall[0], 'launches': overall[1][0], 'sum_ms_in_profiled_step': round(overall[1][1], 3),
+    if not serial and not force_class and side_top[1][1] > on_path[dominant][1]:
+        side_note = {'kernel': side_top[0], 'launches': side_top[1][0], 'sum_ms_in_profiled_step': round(side_top[1][1], 3),
                      'note': 'side-stream class with the largest summed HIP-event time of the profiled step (overlapped, low priority)'}
     if rank == 0 and have_classes and not serial:
         tot = sum(v[1] for v in prof_all.values())
@@ -209,12 +275,12 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
         evs[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
-    prof = plan.handle.profile_collect()
+    prof = plan.handle.profile_collect(which)
     plan.handle.profile_begin(0)
     per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     if pg is not None:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_device(pg, dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     res = {'dt': dt, 'final_loss': float(loss), 'per_step_ms': per_step}
@@ -245,11 +311,17 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
             if fl > 0:
                 roof['achieved_TFLOPs'] = round(fl / (ms * 1e-3) / 1e12, 2)
                 roof['arithmetic_intensity_flop_per_byte'] = round(ai, 1)
-        tb, src = load_traffic(dominant, f'{L},{K},{bs},{"f32" if not bf16 else mode}')
+        wkey = f'{L},{K},{bs},{"f32" if not bf16 else mode}'
+        tb, src = load_traffic(dominant, wkey)
         if tb is not None:
             roof['traffic'] = tb
             roof['traffic_source'] = src
             roof['algorithmic_bytes_per_launch'] = round(by / max(cnt, 1))
+        mb, msrc = load_mfma_busy(dominant, wkey)
+        if mb is not None:       # north_star: "MFMA utilisation against gfx950 peak" (counter-based; the live figure above is flop-based)
+            roof['mfma_busy'] = mb['mfma_busy']
+            roof['mfma_busy_detail'] = {k: v for k, v in mb.items() if k != 'mfma_busy'}
+            roof['mfma_busy_source'] = msrc
         if side_note:
             roof['largest_side_stream_class'] = side_note
     res['roofline'] = roof
@@ -330,18 +402,31 @@ def main():
                          '(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N) or run without a launcher')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # CUNET_BENCH_BACKEND=gloo (tests/test_gpu_dp.py::test_bench_two_ranks_end_to_end only): the N-rank code path of this file --
+    # self-launch, rank-0-only printing, the `also` entries of N > 1, the max-over-ranks clock -- on a box with FEWER GPUs than
+    # ranks: ranks share the GPUs round-robin and the gradient buckets travel over gloo staged through the host (parallel.py).
+    # The line it prints says so (`backend`) and is not a measurement; the driver's runs use RCCL.
+    backend = os.environ.get('CUNET_BENCH_BACKEND', 'nccl')
+    if backend not in ('nccl', 'gloo'):
+        raise SystemExit('CUNET_BENCH_BACKEND must be nccl (RCCL, default) or gloo')
+    ndev = torch.cuda.device_count()
+    if backend == 'nccl' and local_rank >= ndev:
+        raise SystemExit(f'bench.py: rank {local_rank} has no GPU of its own ({ndev} visible): RCCL needs one GPU per rank')
+    dev = torch.device('cuda', local_rank % ndev)
+    torch.cuda.set_device(dev)
     pg = None
     ranks_seen = 1
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run even one rank goes through RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
         pg = dist.group.WORLD
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one)                    # what RCCL itself saw: every rank contributes 1
+        one = torch.ones(1, device=coll_device(pg, dev))
+        dist.all_reduce(one)                    # what the collective library itself saw: every rank contributes 1
         ranks_seen = int(one.item())
 
     import cu_net_amd
@@ -382,6 +467,7 @@ def main():
             'ms_per_step_median': round(r['ms_per_step_median'], 3),
             'value_at_median': round(bs * world / r['ms_per_step_median'] * 1e3, 2),
             'ranks_seen_by_rccl': ranks_seen,
+            'backend': 'rccl' if backend == 'nccl' else 'gloo (host-staged; de-risking run, not a measurement)',
             'library': cu_net_amd._lib.lib().cunet_version().decode(),
             'library_path': os.path.relpath(cu_net_amd._lib.LIB_PATH, ROOT),
             'roofline': r['roofline'],

@@ -92,6 +92,8 @@ def lib():
         'cunet_profile_class_name': (C.c_char_p, [i32]),
         'cunet_profile_get': (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),
+        'cunet_profile_get_stream': (i32, [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)      # AttributeError here == the ABI in include/cunet.h is not exported
@@ -108,7 +110,7 @@ EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_flip_merge', 'cunet_augment_batch', 'cunet_render_targets',
             'cunet_debug_tensor_offset', 'cunet_quant_prepare', 'cunet_quant_restore', 'cunet_quant_grad',
             'cunet_ternary_pack', 'cunet_ternary_conv', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
-            'cunet_profile_num_classes', 'cunet_profile_class_name', 'cunet_profile_get']
+            'cunet_profile_num_classes', 'cunet_profile_class_name', 'cunet_profile_get', 'cunet_profile_get_stream']
 
 
 def check(rc: int, what: str = ''):
@@ -197,14 +199,15 @@ class PlanHandle:
     def profile_reset(self):
         check(lib().cunet_profile_reset(self.h), 'cunet_profile_reset')
 
-    def profile_collect(self):
-        """dict class name -> (launches, ms, algorithmic flops, algorithmic bytes); waits for the events."""
+    def profile_collect(self, which: int = -1):
+        """dict class name -> (launches, ms, algorithmic flops, algorithmic bytes); waits for the events.  which: -1 every launch,
+        0 only launches on the caller's stream, 1 only launches on the library's internal side stream (cunet_profile_get_stream)."""
         L = lib()
         check(L.cunet_profile_collect(self.h), 'cunet_profile_collect')
         out = {}
         cnt, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
         for i in range(L.cunet_profile_num_classes()):
-            check(L.cunet_profile_get(self.h, i, C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)), 'cunet_profile_get')
+            check(L.cunet_profile_get_stream(self.h, i, int(which), C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)), 'cunet_profile_get_stream')
             out[L.cunet_profile_class_name(i).decode()] = (int(cnt.value), float(ms.value), float(fl.value), float(by.value))
         return out
 

@@ -81,8 +81,7 @@ def _geometry(center, scale, rot, res, size, sh, sw):
         sf = 1
     else:
         if np.floor(max(sh, sw) / sf) < 2:
-            raise CUNetError('augment_batch: the person box is larger than the whole image can be shrunk to (HumanAug.crop returns the '
-                             'image unchanged there, :124-125)')
+            return None                                         # HumanAug.crop returns the image unchanged (:124-125)
         frac = 1 / sf                                           # imresize(img, size=1/scale_factor): int(W * frac) x int(H * frac)
         pre = (int(sh * frac), int(sw * frac))
     c = np.asarray(center, dtype=np.float64) / sf
@@ -133,6 +132,7 @@ def augment_batch(images, centers, scales, rots=None, flips=None, gains=None, re
     scales = np.asarray(scales, dtype=np.float64).reshape(-1)
     rec = np.zeros(n, dtype=_REC)
     keep = []
+    passthrough = []
     need = 0
 
     def take(nbytes):                     # scratch offsets (16-byte aligned) inside one caller-owned buffer
@@ -147,10 +147,20 @@ def augment_batch(images, centers, scales, rots=None, flips=None, gains=None, re
         img = img.contiguous()
         keep.append(img)
         rot = float(rots[i])
-        if rot != 0 and rot % 90.0 == 0:
-            raise CUNetError('augment_batch: rotations by multiples of 90 degrees take PIL\'s transpose path, which is not restated')
         sh, sw = int(img.shape[1]), int(img.shape[2])
-        ul, br, pad, pre = _geometry(centers[i], float(scales[i]), rot, res, size, sh, sw)
+        geo = _geometry(centers[i], float(scales[i]), rot, res, size, sh, sw)
+        if geo is None:
+            # The box is so large that the pre-shrink would leave fewer than 2 pixels: the reference's crop() hands the image back
+            # UNCHANGED (pylib/HumanAug.py:124-125) and the loader goes on with it.  That only yields a sample when the image
+            # already has the network's size (anything else fails in the reference's collate): passed through here the same way --
+            # flip, colour gains, clamp, no resampling -- after the batch's kernels; any other size is an error for THIS sample.
+            if (sh, sw) != (res, res):
+                raise CUNetError(f'augment_batch: sample {i}: person box too large to pre-shrink (HumanAug.crop returns the {sh} x {sw} '
+                                 f'image unchanged there, :124-125, which is not a {res} x {res} network input)')
+            passthrough.append(i)
+            geo = _geometry(centers[i], float(res) / size, 0.0, res, size, sh, sw)      # a valid dummy record (a res x res window); its output is overwritten below
+            rot = 0.0
+        ul, br, pad, pre = geo
         cw, ch = int(br[0] - ul[0]), int(br[1] - ul[1])
         rotated = 1 if rot != 0 else 0
         win_w, win_h = cw - 2 * pad * rotated, ch - 2 * pad * rotated
@@ -182,6 +192,9 @@ def augment_batch(images, centers, scales, rots=None, flips=None, gains=None, re
     tab = torch.from_numpy(host.copy()).to(dev)
     out = torch.empty((n, 3, res, res), dtype=torch.float32, device=dev)
     check(lib().cunet_augment_batch(_ptr(tab), C.c_void_p(host.ctypes.data), n, _ptr(out), int(res), _stream_ptr(dev)), 'cunet_augment_batch')
+    for i in passthrough:
+        im = keep[i].flip(2) if flips[i] else keep[i]
+        out[i] = (im * torch.as_tensor(gains[i], dtype=torch.float32, device=dev).view(3, 1, 1)).clamp_(0, 1)
     out._cunet_keepalive = (keep, tab, scratch)          # the launches are asynchronous: inputs and scratch must outlive them
     return out
 

@@ -475,7 +475,10 @@ void Plan::layout_workspace() {
                     wgred_maxnumel[b] = std::max(wgred_maxnumel[b], c.Cout * n.Ccat * 9);
                     continue;
                 }
-                bool ok = c.Cout == 128 && o.ld == 128 && n.Ccat % 32 == 0 && n.Ccat >= 128 && o.rows() >= min_m;
+                // (never a heat-map head: with heads_on_side its weight gradient is enqueued at the START of backward, ahead of
+                // the earlier-processed buckets' kernels that reuse the same partial region -- a class_num == 128 head would
+                // have its partial tiles overwritten before its bucket's reduce)
+                bool ok = n.head < 0 && c.Cout == 128 && o.ld == 128 && n.Ccat % 32 == 0 && n.Ccat >= 128 && o.rows() >= min_m;
                 for (auto& sr : n.segs) ok = ok && tensors[sr.tensor].C % 4 == 0 && tensors[sr.tensor].ld % 4 == 0;
                 if (!ok) continue;
                 const int64_t M = o.rows();

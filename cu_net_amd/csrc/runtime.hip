@@ -52,13 +52,15 @@ struct cunet_plan {
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     int prof_mode = 0;               // 0 off, 1 every class, 2 only prof_cls
     int prof_cls = -1;
-    struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+    struct ProfRec { hipEvent_t a, b; int cls, on_side; double flops, bytes; };
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
-    double prof_ms[CUNET_PROF_NCLS] = {0};
-    double prof_flops[CUNET_PROF_NCLS] = {0};
-    double prof_bytes[CUNET_PROF_NCLS] = {0};
-    long prof_count[CUNET_PROF_NCLS] = {0};
+    // [0]: launches on the caller's stream, [1]: launches on the internal low-priority side stream (their durations include the
+    // time they are switched out for the caller's kernels)
+    double prof_ms[2][CUNET_PROF_NCLS] = {{0}};
+    double prof_flops[2][CUNET_PROF_NCLS] = {{0}};
+    double prof_bytes[2][CUNET_PROF_NCLS] = {{0}};
+    long prof_count[2][CUNET_PROF_NCLS] = {{0}};
 };
 
 // Does node `n` take the LDS-staged partial-tile weight gradient in gradient-storage mode `xmode`?  (One predicate for the
@@ -100,6 +102,7 @@ static hipError_t prof_begin(cunet_plan* h, int cls, hipStream_t s, int& slot) {
         else { hipError_t er = hipEventCreate(e); if (er != hipSuccess) return er; }
     }
     r.cls = cls;
+    r.on_side = (h->side != nullptr && s == h->side) ? 1 : 0;
     h->prof_pending.push_back(r);
     slot = (int)h->prof_pending.size() - 1;
     return hipEventRecord(r.a, s);
@@ -758,13 +761,18 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
                 continue;
             }
             prof_cancel(h, slot_);
-            if (e != hipErrorNotSupported) HIPCHK(e);
+            // (no pair kernel for the shape, or the pair's configuration does not fit -- e.g. its LDS budget: the single launches below)
+            if (e != hipErrorNotSupported && e != hipErrorInvalidValue) HIPCHK(e);
         }
         // fork: the skip adapter of a down block is consumed only on the way up (models/cu_net.py:257,267),
         // so it runs on the side stream next to the ahead adapter / pool / next block
         // ... and so does a heat-map head in a training pass: nothing in the forward reads its output (the loss is finalised after
         // the join below), and the side stream is idle in the forward
-        const bool forked = fork_fwd && n.type == N_CONV &&
+        // (never a node of the AND-popcount forward: every popcount site shares ONE bit-plane scratch, `off_planes`, reused site
+        // after site in stream order -- a head on the side stream would still be reading its records while the next U-Net's 3x3
+        // site rewrites them on the caller's stream)
+        const bool popcount_node = n.type == N_CONV && h->qin_bits && h->tern_live && h->node_qin[ni] && h->node_tern[ni];
+        const bool forked = fork_fwd && n.type == N_CONV && !popcount_node &&
                             ((o.W >= P.opts.fwd_fork_min_w && n.name.find(".adapters_skip.") != std::string::npos) || (n.head >= 0 && P.opts.heads_on_side));
         if (forked) {
             HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
@@ -1315,7 +1323,8 @@ int cunet_profile_begin(cunet_plan_t* h, int mode, int cls) {
 
 int cunet_profile_reset(cunet_plan_t* h) {
     if (!h) return fail(CUNET_ERR_INVALID, "null argument");
-    for (int i = 0; i < CUNET_PROF_NCLS; ++i) { h->prof_ms[i] = h->prof_flops[i] = h->prof_bytes[i] = 0; h->prof_count[i] = 0; }
+    for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < CUNET_PROF_NCLS; ++i) { h->prof_ms[w][i] = h->prof_flops[w][i] = h->prof_bytes[w][i] = 0; h->prof_count[w][i] = 0; }
     return CUNET_OK;
 }
 
@@ -1325,7 +1334,8 @@ int cunet_profile_collect(cunet_plan_t* h) {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-        h->prof_ms[r.cls] += ms; h->prof_flops[r.cls] += r.flops; h->prof_bytes[r.cls] += r.bytes; h->prof_count[r.cls] += 1;
+        const int w = r.on_side;
+        h->prof_ms[w][r.cls] += ms; h->prof_flops[w][r.cls] += r.flops; h->prof_bytes[w][r.cls] += r.bytes; h->prof_count[w][r.cls] += 1;
         h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b);
     }
     h->prof_pending.clear();
@@ -1336,8 +1346,16 @@ int cunet_profile_num_classes(void) { return CUNET_PROF_NCLS; }
 const char* cunet_profile_class_name(int cls) { return (cls >= 0 && cls < CUNET_PROF_NCLS) ? kProfNames[cls] : ""; }
 
 int cunet_profile_get(const cunet_plan_t* h, int cls, int64_t* count, double* ms, double* flops, double* bytes) {
-    if (!h || cls < 0 || cls >= CUNET_PROF_NCLS || !count || !ms || !flops || !bytes) return fail(CUNET_ERR_INVALID, "bad argument");
-    *count = h->prof_count[cls]; *ms = h->prof_ms[cls]; *flops = h->prof_flops[cls]; *bytes = h->prof_bytes[cls];
+    return cunet_profile_get_stream(h, cls, -1, count, ms, flops, bytes);
+}
+
+int cunet_profile_get_stream(const cunet_plan_t* h, int cls, int which, int64_t* count, double* ms, double* flops, double* bytes) {
+    if (!h || cls < 0 || cls >= CUNET_PROF_NCLS || which < -1 || which > 1 || !count || !ms || !flops || !bytes) return fail(CUNET_ERR_INVALID, "bad argument");
+    *count = 0; *ms = *flops = *bytes = 0.0;
+    for (int w = 0; w < 2; ++w) {
+        if (which >= 0 && which != w) continue;
+        *count += h->prof_count[w][cls]; *ms += h->prof_ms[w][cls]; *flops += h->prof_flops[w][cls]; *bytes += h->prof_bytes[w][cls];
+    }
     return CUNET_OK;
 }
 

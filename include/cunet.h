@@ -209,6 +209,10 @@ int cunet_profile_collect(cunet_plan_t* plan);
 int cunet_profile_num_classes(void);
 const char* cunet_profile_class_name(int cls);
 int cunet_profile_get(const cunet_plan_t* plan, int cls, int64_t* count, double* ms, double* flops, double* bytes);
+/* the same split by the stream the launches ran on: which = 0 the caller's stream (the step's critical path), 1 the library's
+ * internal low-priority side stream (weight gradients, heat-map heads of a training pass: a launch's duration there includes
+ * the time it is switched out for the caller's kernels), -1 both (= cunet_profile_get). */
+int cunet_profile_get_stream(const cunet_plan_t* plan, int cls, int which, int64_t* count, double* ms, double* flops, double* bytes);
 
 /* full-resolution landmark decode: replaces pylib/Evaluation.py:108-132 final_preds for rot == 0
  * (quarter-pixel refinement, +0.5, inverse crop transform :152-187 with size 200, truncation).

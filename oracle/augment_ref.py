@@ -204,12 +204,13 @@ def pil_rotate_matrix(w, h, angle_deg):
 
 
 def pil_rotate_bilinear(img_u8, angle_deg):
-    """Image.rotate(angle, resample=BILINEAR) of an H x W x C uint8 image, angle not a multiple of 90 degrees."""
+    """Image.rotate(angle, resample=BILINEAR) of an H x W x C uint8 image.  Multiples of 90 degrees: PIL takes its transpose
+    shortcuts there (180 always, 90 / 270 on square images); with the matrix entries rounded to 15 decimals (exactly 0 / +-1)
+    the affine path below lands on pixel centres and gives the same bytes (tests/test_oracle_aux.py checks that against PIL)."""
     img = np.asarray(img_u8)
     h, w = img.shape[:2]
     if angle_deg % 360.0 == 0:
         return img.copy()
-    assert (angle_deg % 90.0) != 0, 'PIL special-cases multiples of 90 degrees (transpose); the loader draws from N(0, 30)'
     m = pil_rotate_matrix(w, h, angle_deg)
     ys, xs = np.mgrid[0:h, 0:w]
     xin = m[0] * (xs + 0.5) + m[1] * (ys + 0.5) + m[2]

@@ -65,6 +65,35 @@ def test_augment_identity_window_is_the_byte_scaled_window():
         assert np.array_equal(out[i], want)
 
 
+def test_right_angle_rotations_and_the_degenerate_box():
+    """(1) rotations by multiples of 90 degrees: PIL's transpose shortcuts equal its affine path there (tests/test_oracle_aux.py), so
+    the kernel's rotate stage covers them; (2) a person box too large to pre-shrink: HumanAug.crop returns the image unchanged
+    (pylib/HumanAug.py:124-125) -- passed through (flip, gains, clamp) when the image already has the network's size, a CUNetError for
+    that sample otherwise (the reference fails in its collate there)."""
+    rng = np.random.RandomState(5)
+    res = 48
+    imgs = [(rng.randint(0, 256, size=(3, 64, 72)) / 255.0).astype(np.float32) for _ in range(4)]
+    centers = np.array([[36.0, 30.0]] * 4)
+    scales = np.array([0.3, 0.26, 0.3, 0.62])
+    rots = np.array([90.0, 180.0, -90.0, 270.0])
+    flips = np.array([False, True, False, True])
+    gains = rng.uniform(0.6, 1.4, size=(4, 3))
+    out = cu_net_amd.augment_batch([torch.from_numpy(i).cuda() for i in imgs], centers, scales, rots, flips, gains, res=res).cpu().numpy()
+    for i in range(4):
+        ref = A.augment_sample(imgs[i], centers[i], float(scales[i]), float(rots[i]), bool(flips[i]), gains[i], res=res)
+        assert np.array_equal(out[i], ref), (i, int((out[i] != ref).sum()))
+    # degenerate: scale * 200 / res >= 2 and floor(max(H, W) / sf) < 2
+    sq = (rng.randint(0, 256, size=(3, res, res)) / 255.0).astype(np.float32)
+    big = 0.5 * res * res / 200.0 + 1.0                              # sf = scale * 200 / res > res / 2  ->  floor(res / sf) < 2
+    out = cu_net_amd.augment_batch([torch.from_numpy(sq).cuda(), torch.from_numpy(imgs[0]).cuda()], np.array([[24.0, 24.0], [36.0, 30.0]]),
+                                   np.array([big, 0.3]), flips=[True, False], gains=np.array([[1.3, 0.7, 1.0], [1.0, 1.0, 1.0]]), res=res).cpu().numpy()
+    ref0 = A.augment_sample(sq, np.array([24.0, 24.0]), big, 0.0, True, (1.3, 0.7, 1.0), res=res)
+    assert ref0.shape == (3, res, res) and np.array_equal(out[0], ref0)
+    assert np.array_equal(out[1], A.augment_sample(imgs[0], np.array([36.0, 30.0]), 0.3, 0.0, False, (1.0, 1.0, 1.0), res=res))
+    with pytest.raises(cu_net_amd.CUNetError):
+        cu_net_amd.augment_batch([torch.from_numpy(imgs[0]).cuda()], np.array([[36.0, 30.0]]), np.array([0.5 * 72 * res / 200.0 + 1.0]), res=res)
+
+
 def test_prepare_batch_is_the_loaders_getitem():
     """cu_net_amd.prepare_batch == oracle restatement of MPII.__getitem__ (data/mpii_for_mpii_22.py:86-145) sample by sample under the
     same numpy seed: network input (bit for bit, the reference's 8-bit resamplers), target heat maps (bit-exact renderer), meta."""

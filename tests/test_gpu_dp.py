@@ -178,3 +178,36 @@ def test_failing_bucket_callback_aborts_the_step():
     # and the plan is usable again
     tr = FusedTrainer(net)
     assert torch.isfinite(tr.step(x[:2].cuda(), t[:2].cuda()))
+
+
+def test_bench_two_ranks_end_to_end():
+    """De-risks the driver's first `bench.py --gpus N` run with N > 1 (cu-net.py:59's replacement under the bench contract): the whole
+    N-rank path of bench.py -- its self-launch through torch.distributed.run, one process per rank, the barrier + max-over-ranks
+    clock, rank-0-only printing, the BASELINE config-4 `also` entries of N > 1, a clean exit of both ranks -- executed with
+    world size 2.  With two GPUs visible it runs over RCCL exactly as the driver will; on a one-GPU box the ranks share cuda:0 and
+    CUNET_BENCH_BACKEND=gloo carries the gradient buckets through the host (the printed line says so; it is not a measurement)."""
+    import json
+    env = dict(os.environ)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    rccl = torch.cuda.device_count() >= 2
+    env['CUNET_BENCH_BACKEND'] = 'nccl' if rccl else 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--also-steps', '2',
+           '--no-cpu-baseline', '--no-alone']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]               # rank 0 prints ONE JSON line, rank 1 none
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen_by_rccl'] == 2 and out['steps'] == 3 and out['warmup'] == 1
+    assert out['config']['global_batch'] == 48 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
+    assert out['backend'].startswith('rccl' if rccl else 'gloo')
+    assert out['value'] > 0 and abs(out['value'] - 48 * 3 / (out['ms_per_step'] * 3e-3)) <= 1e-2 * out['value']
+    also = out['also']
+    assert len(also) == 2 and all('error' not in e for e in also), also
+    assert all('layer_num=8' in e['workload'] and '16 landmarks' in e['workload'] and e['n_gpus'] == 2 and e['value'] > 0 for e in also)
+    assert 'cpu_baseline' not in out
+    for key in ('roofline', 'final_loss', 'library_path'):
+        assert key in out

@@ -141,19 +141,21 @@ def test_every_node_backward_full_width_bf16_gradient_tensors():
     _check_all_nodes(cfg, st, x, bf16=2)
 
 
-def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0, only_ops=None):
+def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0, only_ops=None, check_forward=False):
     """wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
     False: the planner is told to keep them on the per-wave atomic kernel (wgrad2), which stays the path of narrow heads,
-    non-32-multiple concats and the stem and must remain covered at production widths."""
+    non-32-multiple concats and the stem and must remain covered at production widths.
+    check_forward: every conv / pool node's FORWARD output is compared too, with torch's on the GPU's own inputs (bf16 storage: on
+    the bf16-rounded operands the kernels multiply, output rounded as the kernel stores it)."""
     from cu_net_amd._lib import set_planner_option
     set_planner_option('wgrad3_min_rows', 0 if wgrad3_all else 1 << 30)
     try:
-        return _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops)
+        return _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops, check_forward)
     finally:
         set_planner_option('wgrad3_min_rows', 0)
 
 
-def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_ops=None):
+def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_ops=None, check_forward=False):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
@@ -221,6 +223,15 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
                 # exact gradient of that forward (straight-through here)
                 act = act + (act.bfloat16().float() - act).detach()
             y = F.conv2d(act, wt, None, 1, 1 if nd['taps'] == 9 else 0)
+            if check_forward:
+                with torch.no_grad():
+                    if bf16:      # bf16 MFMA: bf16-rounded activation x bf16-rounded weight, fp32 accumulation; stored as bf16 (heads: fp32)
+                        yf = F.conv2d(act.bfloat16().float(), wt.bfloat16().float(), None, 1, 1 if nd['taps'] == 9 else 0)
+                        if nd.get('head', -1) < 0:
+                            yf = yf.bfloat16().float()
+                        _close(f'{nd["name"]} forward', acts[oname], yf, bad, rtol=1e-2, l2=6e-3)
+                    else:
+                        _close(f'{nd["name"]} forward', acts[oname], y, bad)
             y.backward(dy)
             plan.debug_poke(oname, dy, grad=True)
             plan.debug_run_node_backward(k)
@@ -234,7 +245,10 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
         elif op == 'pool':
             nm = T[nd['segs'][0]['t']]['name']
             leaf = acts[nm].clone().requires_grad_(True)
-            F.max_pool2d(leaf, 2, 2).backward(dy)
+            yp = F.max_pool2d(leaf, 2, 2)
+            if check_forward:
+                assert torch.equal(acts[oname], yp.detach()), nd['name'] + ' forward'               # a selection: bit-exact in every storage mode
+            yp.backward(dy)
             plan.debug_poke(oname, dy, grad=True)
             plan.debug_run_node_backward(k)
             torch.cuda.synchronize()
@@ -331,13 +345,12 @@ def _check_composition(cfg, st, x, target, check_params=False, quan_bits_w=0, qu
                 from oracle.cunet_ref import _QuanInputFn
                 act = _QuanInputFn.apply(act, quan_input_bits)
             y = F.conv2d(act, wt, None, 1, 1 if nd['taps'] == 9 else 0)
-            if quan_input_bits:
-                # the forward itself, node by node on the GPU's own inputs: with ternary weights and 2^-7-grid activations the 3x3 / head
-                # convs are exact on both sides, elsewhere the fp32 tolerance applies
-                # (an activation within rounding of a quantiser step lands on the neighbouring 2^-7 level on one side only: with
-                # fan-in 1152 about 1 % of the outputs contain such a flip, 1/128 each -- hence the wider element tolerance there)
-                site = nd['taps'] == 9 or nd.get('head', -1) >= 0
-                _close(f'{nd["name"]} forward', acts[oname], y, bad_fwd, **(dict(rtol=3e-3, frac=2e-3) if site else {}))
+            # the forward itself, node by node on the GPU's own inputs, in EVERY configuration (fp32 tolerance).  Quantised inputs: with
+            # ternary weights and 2^-7-grid activations the 3x3 / head convs are exact on both sides
+            # (an activation within rounding of a quantiser step lands on the neighbouring 2^-7 level on one side only: with
+            # fan-in 1152 about 1 % of the outputs contain such a flip, 1/128 each -- hence the wider element tolerance there)
+            site = quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0)
+            _close(f'{nd["name"]} forward', acts[oname], y, bad_fwd, **(dict(rtol=3e-3, frac=2e-3) if site else {}))
             y.backward(dy)
             for l, s in zip(leaves, nd['segs']):
                 add(T[s['t']]['name'], l.grad)
@@ -351,22 +364,30 @@ def _check_composition(cfg, st, x, target, check_params=False, quan_bits_w=0, qu
         elif op == 'pool':
             nm = T[nd['segs'][0]['t']]['name']
             leaf = acts[nm].clone().requires_grad_(True)
-            F.max_pool2d(leaf, 2, 2).backward(dy)
+            yp = F.max_pool2d(leaf, 2, 2)
+            if not torch.equal(acts[oname], yp.detach()):
+                bad_fwd.append(f'{nd["name"]} forward: max-pool output is not the selection torch makes')
+            yp.backward(dy)
             add(nm, leaf.grad)
         elif op == 'stem_bnpool':
             nm = T[nd['segs'][0]['t']]['name']
             leaf = acts[nm].clone().requires_grad_(True)
             gamma = st[nd['bn'] + '.weight'].clone().requires_grad_(check_params)
             beta = st[nd['bn'] + '.bias'].clone().requires_grad_(check_params)
-            F.max_pool2d(F.relu(F.batch_norm(leaf, None, None, gamma, beta, True, 0.1, 1e-5)), 2, 2).backward(dy)
+            yp = F.max_pool2d(F.relu(F.batch_norm(leaf, None, None, gamma, beta, True, 0.1, 1e-5)), 2, 2)
+            _close(f'{nd["name"]} forward', acts[oname], yp, bad_fwd)
+            yp.backward(dy)
             add(nm, leaf.grad)
             if check_params:
                 pcheck(f'{nd["name"]} dgamma', nd['bn'] + '.weight', gamma.grad)
                 pcheck(f'{nd["name"]} dbeta', nd['bn'] + '.bias', beta.grad)
-        elif op == 'stem_conv' and check_params:
-            wt = st[nd['conv'] + '.weight'].clone().requires_grad_(True)
-            F.conv2d(x, wt, None, 2, 3).backward(dy)
-            pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad)
+        elif op == 'stem_conv':
+            wt = st[nd['conv'] + '.weight'].clone().requires_grad_(check_params)
+            ys = F.conv2d(x, wt, None, 2, 3)
+            _close(f'{nd["name"]} forward', acts[oname], ys, bad_fwd)
+            if check_params:
+                ys.backward(dy)
+                pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad)
     assert heads == cfg['loss_num']
     bad = []
     for nm, g in expect.items():
@@ -405,7 +426,23 @@ def test_whole_backward_composition_bench_batch():
     spec = O.Spec(**cfg)
     st = O.init_state(spec, seed=81)
     x, target = O.synthetic_batch(24, 68, 256, seed=82)
-    _check_composition(cfg, st, x, target, check_params=True)
+    _check_composition(cfg, st, x, target, check_params=True)      # (incl. every node's FORWARD at N = 24 against torch on the GPU's own inputs)
+
+
+@pytest.mark.parametrize('mode', [True, 2])
+def test_every_node_bench_batch_bf16(mode):
+    """BASELINE config 3's kernels in the regime bench.py runs them in -- bf16 storage (mode True: bf16 activations; 2: bf16 gradient
+    tensors too), N = 24 at production widths (CU-Net-2, K = 68: the same node shapes as CU-Net-8): at 64 x 64 a wave of
+    conv_bf16[_pair]_kernel / dgrad_bf16[_pair]_kernel walks three tiles (the cross-tile logic: next tile's dY behind the epilogue's x
+    requests, one-pass LDS epilogue), conv3x3_ring_bf16_kernel runs several strips per workgroup with ring reuse, the bf16 weight
+    gradients their steady-state loops.  Node by node against torch on identical (bf16-rounded) inputs: forward output, input
+    gradients, weight and BatchNorm parameter gradients (models/cu_net.py:11-17,43-48; cu-net.py:182)."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=85)
+    x, _ = O.synthetic_batch(24, 68, 256, seed=86)
+    _check_all_nodes(cfg, st, x, bf16=mode, wgrad3_all=True, check_forward=True)
 
 
 @pytest.mark.parametrize('mode', [False, 2])

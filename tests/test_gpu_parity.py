@@ -282,6 +282,39 @@ def test_full_width_eval_forward_matches_oracle():
         assert err <= RTOL_ACT * r.abs().max().item() + ATOL, (i, err, r.abs().max().item())
 
 
+@pytest.mark.parametrize('layer_num,class_num', [(8, 68), (16, 16)])
+def test_deep_eval_forward_matches_oracle(layer_num, class_num):
+    """north_star's 1e-4 on EVERY head of the deep configurations (BASELINE configs 3 / 4 / 5's networks: CU-Net-8 K = 68, CU-Net-16
+    K = 16, full width), where it is well defined: the eval-mode forward (models/cu_net.py:336-360 with running statistics -- no
+    batch-statistics feedback, so rounding is not amplified U-Net after U-Net as it is in train mode).  The running
+    statistics are first driven to this batch's own statistics by 40 train-mode forwards (1 - 0.9^40 = 0.985), so that every
+    BatchNorm output keeps unit scale through all 8 / 16 U-Nets; then HIP eval forward vs the oracle's eval forward on that state."""
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=class_num, layer_num=layer_num, order=1, loss_num=layer_num)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=90 + layer_num)
+    x, _ = O.synthetic_batch(2, class_num, 256, seed=92)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net.cuda().train()
+    xd = x.cuda()
+    with torch.no_grad():
+        for _ in range(40):
+            net(xd)
+    st1 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    assert int(st1['features.norm0.num_batches_tracked']) == 40
+    net.eval()
+    with torch.no_grad():
+        outs = net(xd)
+    refs = O.forward(spec, st1, x, training=False)
+    assert len(outs) == len(refs) == layer_num
+    lines, bad = [], []
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert r.abs().max().item() > 1e-3, (i, 'degenerate heat map')
+        _cmp(f'head {i}', o, r, RTOL_ACT, lines, bad)
+    _report(f'deep_eval_L{layer_num}K{class_num}', lines)
+    assert not bad, '\n'.join(lines)
+
+
 def test_get_preds_bit_exact():
     torch.manual_seed(3)
     s = torch.randn(3, 5, 64, 64)

@@ -157,6 +157,20 @@ def test_crop_resamplers_match_executed_reference():
     assert seen_pre >= 2 and seen_rot >= 3
 
 
+def test_rotate_restatement_equals_pil_at_multiples_of_90_degrees():
+    """Image.rotate takes transpose shortcuts at 180 (always) and 90 / 270 (square images); the oracle's affine restatement (the
+    arithmetic the HIP rotate kernel follows) gives the same bytes there, and away from them -- checked against the installed PIL,
+    which is what scipy.misc.imrotate called (pylib/HumanAug.py:162)."""
+    from PIL import Image
+    from oracle import augment_ref as A
+    rng = np.random.RandomState(11)
+    for (h, w) in [(37, 37), (64, 64), (40, 52), (53, 40)]:
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        for ang in (90.0, 180.0, 270.0, -90.0, 450.0, -180.0, 360.0, 33.0, -71.5):
+            ref = np.asarray(Image.fromarray(img).rotate(ang, resample=Image.BILINEAR))
+            assert np.array_equal(A.pil_rotate_bilinear(img, ang), ref), (h, w, ang)
+
+
 def test_train_sample_draws_follow_the_reference_order():
     """cu_net_amd.augment.draw_train_params / mpii_center_scale against the oracle's restatement of MPII.__getitem__
     (data/mpii_for_mpii_22.py:99-136): same numpy seed -> same scale jitter, rotation, flip decision, colour gains."""

@@ -8,44 +8,13 @@ WRITE_SIZE is taken as reported (uncalibrated).  Classes are the ones bench.py's
 """
 import glob
 import json
-import re
 import sys
 
 import pandas as pd
 
-CLASSES = [      # first match wins: the bf16-MFMA kernels carry bench.py's *_bf16 class names
-    (r'wgrad3_stem_kernel', 'stem_bwd_weight'),
-    (r'wgrad3_3x3_bf16_kernel', 'conv3x3_bwd_weight_bf16'),
-    (r'wgrad3_bf16_kernel', 'conv1x1_bwd_weight_bf16'),
-    (r'wgrad3_3x3_kernel', 'conv3x3_bwd_weight'),
-    (r'wgrad3_kernel', 'conv1x1_bwd_weight'),
-    (r'wgrad_reduce_kernel', 'wgrad_partial_reduce'),
-    (r'wgrad2_stem_kernel', 'stem_bwd_weight'),
-    (r'wgrad2_kernel', 'conv1x1_bwd_weight'),
-    (r'wgrad_kernel<\(?cunet::\)?1|wgrad_kernel<1,', 'conv3x3_bwd_weight'),
-    (r'wgrad_kernel<2,', 'stem_bwd_weight'),
-    (r'dgrad_bf16_kernel<1,', 'conv1x1_bwd_data_bf16'),
-    (r'dgrad_bf16_kernel<9,', 'conv3x3_bwd_data_bf16'),
-    (r'conv3x3_tapsplit_bf16_kernel|conv3x3_ring_bf16_kernel|conv_bf16_kernel<9,', 'conv3x3_fwd_bf16'),
-    (r'conv_bf16_kernel<1,', 'conv1x1_fwd_bf16'),
-    (r'conv3x3_tapsplit_kernel|conv3x3_ring_kernel', 'conv3x3_fwd'),
-    (r'conv_kernel<0, 0,|conv1x1_splitk_kernel', 'conv1x1_fwd'),
-    (r'conv_kernel<1, 0,', 'conv3x3_fwd'),
-    (r'conv_kernel<4, 0,', 'stem_conv_fwd'),
-    (r'conv_kernel<2, 1,', 'conv1x1_bwd_data'),
-    (r'conv_kernel<3, 1,', 'conv3x3_bwd_data'),
-    (r'grad_gather_kernel', 'bn_bwd_apply'),
-    (r'pool_fwd_kernel<0>|pool_bf16_kernel', 'pool_fwd'),
-    (r'pool_bwd_kernel', 'pool_bwd'),
-    (r'ternary_conv_planes_kernel|ternary_planes_kernel|ternary_conv_kernel', 'conv_fwd_popcount'),
-]
-
-
-def classify(name):
-    for pat, cls in CLASSES:
-        if re.search(pat, name):
-            return cls
-    return None
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic_classes import classify      # noqa: E402
 
 
 def load(d, counter):
