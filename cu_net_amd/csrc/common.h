@@ -79,6 +79,13 @@ struct ConvArgs {
     double mse_inv;        // 1 / (M * Nout)
     int mse_gbf16;
     int mse_ldd;           // leading dimension of mse_dout (elements): ldy, or the padded K of a bf16 head gradient (see head_grad_ld)
+    int col_slices;        // set by the launcher: column slices of the launch (gridDim.y, or xcd_gy on the 1-D grid).  The fp32 data gradient
+                           // with the LDS-tile epilogue deals the 32-column tiles of the output to the slices as evenly as they go:
+    int sl_rem, sl_gx_big, sl_gx_small;      // its first sl_rem slices carry one tile more than the others and get sl_gx_big row blocks each,
+                           // the others sl_gx_small -- row blocks in proportion to the tiles, so that every block does the same work
+                           // (sl_gx_small > 0 selects this decoding of the 1-D grid, see conv_body)
+    int dgrad_nt;          // EP_BWD, fp32: most 32-column tiles of dz a wave owns per row tile (the plan's snapshot of planner option
+                           // dgrad_nt; 0 = the default 4, 1 = one tile per wave as in rounds 2-3)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
                            // planner option conv3x3_ring_min_rows; 0 = the default 512)
     int dbg;               // timing experiments only (CUNET_CONV_DBG; conv_bf16_kernel: CUNET_B16_DBG = 32 / 64 as below, 2048 no output
@@ -93,7 +100,8 @@ struct ConvPair { ConvArgs a[2]; };
 
 // fields the launcher derives (a pair shares them: the two problems have one shape)
 inline void copy_launch_geometry(ConvArgs& b, const ConvArgs& a) {
-    b.wshift = a.wshift; b.hwshift = a.hwshift; b.any_ups = a.any_ups; b.xcd_gx = a.xcd_gx; b.xcd_gy = a.xcd_gy; b.dbg = a.dbg;
+    b.wshift = a.wshift; b.hwshift = a.hwshift; b.any_ups = a.any_ups; b.xcd_gx = a.xcd_gx; b.xcd_gy = a.xcd_gy; b.dbg = a.dbg; b.col_slices = a.col_slices;
+    b.sl_rem = a.sl_rem; b.sl_gx_big = a.sl_gx_big; b.sl_gx_small = a.sl_gx_small;
 }
 
 // Two problems can share a launch when everything that shapes the grid, the LDS layout and the code path agrees.

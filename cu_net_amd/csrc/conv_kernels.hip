@@ -20,6 +20,7 @@
 // Per-channel batch statistics of the OUTPUT (sum, sum of squares) are produced in the
 // epilogue in fp64 so every consumer BatchNorm reuses them (a BN over a concat is per channel).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_common.h"
@@ -32,7 +33,11 @@ constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
 #define CUNET_TEPI_WAVES 12              // the fp32 1x1 / 3x3 data gradient with the LDS-tile epilogue (118 VGPRs: 16 would fit; probe builds)
 #endif
 template <int LD, int EP, int NT, bool FAST, int XBG>
-constexpr int conv_max_waves() { return (EP == EP_BWD && FAST && NT == 1 && XBG == 0) ? CUNET_TEPI_WAVES : CONV_MAX_WAVES; }
+constexpr int conv_max_waves() {
+    // the fp32 data gradient with the LDS-tile epilogue: 3 or 4 channel tiles per wave hold 48 / 64 accumulators next to the A chunks in
+    // flight and the epilogue's pieces -- two waves per SIMD (256 VGPRs) instead of three
+    return (EP == EP_BWD && FAST && XBG == 0) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
+}
 
 // (the body is a device function of (arguments, block coordinates): conv_kernel runs it on one problem, conv_pair_kernel on the
 // problem blockIdx.z selects out of two)
@@ -55,9 +60,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     float* mu = sh + p.Ccat;
     float* is = mu + p.Ccat;
     double* redbuf = reinterpret_cast<double*>(is + p.Ccat);   // [NB][2]
-    // fp32 data gradient, one channel tile per wave, nothing ragged: the epilogue's x loads and dz stores go through a wave-private
-    // LDS tile (see below).  The other instantiations keep the element-wise epilogue.
-    constexpr bool TEPI = (EP == EP_BWD && FAST && NT == 1 && XBG == 0);
+    // fp32 data gradient, nothing ragged: the epilogue's x loads and dz stores go through a wave-private LDS tile, one 32-column
+    // tile of the slice after the other (see below).  The other instantiations keep the element-wise epilogue.
+    constexpr bool TEPI = (EP == EP_BWD && FAST && XBG == 0);
     constexpr int TEPI_PITCH = 36;                             // floats per tile row (16-byte aligned rows)
     float* tileT = reinterpret_cast<float*>(redbuf + NB * 2);  // TEPI: [waves][32][36]
 
@@ -69,14 +74,40 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     const int hi = lane >> 5;
     // block -> (row block bx of gxd, column slice by).  With xcd_gx > 0 the launch is 1-D and the slices of a row block sit on one XCD.
     int bx = bidx, by = bidy, gxd = gdimx;
-    if (p.xcd_gx > 0) {
+    if (TEPI && p.sl_gx_small > 0) {
+        // 1-D grid of the tiled-epilogue data gradient: eight consecutive workgroups = row blocks 8 g .. 8 g + 7 of one slice; the
+        // first sl_rem slices (one channel tile more) have sl_gx_big row blocks, the others sl_gx_small
+        const int xcd = bidx & 7, slot = bidx >> 3;
+        const int gb = (p.sl_gx_big + 7) >> 3, gs = (p.sl_gx_small + 7) >> 3;
+        if (slot < p.sl_rem * gb) {
+            by = slot / gb;
+            bx = (slot - by * gb) * 8 + xcd;
+            gxd = p.sl_gx_big;
+        } else {
+            const int s2 = slot - p.sl_rem * gb;
+            const int q = s2 / gs;
+            by = p.sl_rem + q;
+            bx = (s2 - q * gs) * 8 + xcd;
+            gxd = p.sl_gx_small;
+        }
+        if (bx >= gxd) return;                         // (padding blocks of a group of eight; before any barrier)
+    } else if (p.xcd_gx > 0) {
         const int L = bidx, xcd = L & 7, slot = L >> 3;
         by = slot % p.xcd_gy;
         bx = (slot / p.xcd_gy) * 8 + xcd;
         gxd = p.xcd_gx;
         if (bx >= gxd) return;                         // (padding blocks of the last group of eight; before any barrier)
     }
-    const int n0 = by * NB;
+    // Column slice of this block.  TEPI (round 4): the 32-column tiles of the output are dealt to the col_slices slices as evenly as
+    // they go -- slice `by` owns base or base + 1 consecutive tiles (5 tiles on 2 slices: 3 + 2; NT = the larger count) -- so a
+    // slice never contracts an all-zero tile; `ntl` = this block's live tiles (NT or NT - 1, block-uniform).
+    int n0 = by * NB, ntl = NT;
+    if (TEPI && p.col_slices > 0) {
+        const int nc32 = (p.Nout + 31) >> 5;
+        const int base = nc32 / p.col_slices, rem = nc32 - base * p.col_slices;
+        n0 = (by * base + (by < rem ? by : rem)) * 32;
+        ntl = base + (by < rem ? 1 : 0);
+    }
 
     // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
     if (!CUNET_DBG(p, 32)) {
@@ -184,29 +215,22 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
         vcur = tvalid;
         fetch(anext);
     };
-    constexpr bool EARLY_NEXT = NT <= 2;              // (NT = 4 holds 64 accumulators: 16 more live registers across its epilogue spill)
+    constexpr bool EARLY_NEXT = NT <= 2;              // (NT = 3 / 4 hold 48 / 64 accumulators: 16 more live registers across their epilogue spill)
     const int tstride = gxd * nwaves;
     int tile = bx * nwaves + wave;
     if (FAST && EARLY_NEXT && tile < ntiles) begin_tile(tile);
-    // TEPI: this lane's four 16-byte pieces of the tile's x (see the epilogue); the piece column does not depend on the tile
-    const int pc4 = lane & 7, pr0 = lane >> 3;          // piece column / first row (further rows + 8)
-    const int pcol = n0 + 4 * pc4;
-    const bool pok = pcol < p.Nout;
-    GrpEnt pg;
-    pg.ptr = p.a; pg.ld = 0; pg.ups = 0;                 // always a valid address
-    if (TEPI && pok) pg = grp[pcol >> 2];
+    // TEPI: this lane's four 16-byte pieces of a 32 x 32 tile of x (see the epilogue): piece column 4 * pc4 of the channel tile,
+    // rows pr0 + 8 j.  The group entry (segment pointer, pitch, up-sample flag) of a channel tile is re-read from LDS where it is needed
+    // (four registers per tile otherwise).
+    const int pc4 = lane & 7, pr0 = lane >> 3;
     float4 xp[TEPI ? 4 : 1];
-    for (; tile < ntiles; tile += tstride) {
-        if (!FAST) set_tile(tile);
-        if (FAST && !EARLY_NEXT) begin_tile(tile);
+    auto request_x = [&](const GrpEnt& g, int t, float4 (&o)[TEPI ? 4 : 1]) {      // row tile t, the channel tile g describes
         if constexpr (TEPI) {
-            // requested HERE, in front of the tile's 64 MFMAs, not in the epilogue: x does not depend on them, and a wave that
-            // asks after its MFMAs sits out a full memory round trip per tile with nothing of its own to do
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int mm = tile * 32 + pr0 + 8 * j;
+                const int mm = t * 32 + pr0 + 8 * j;
                 int row = mm;
-                if (p.any_ups && pg.ups) {
+                if (p.any_ups && g.ups) {                 // (a branch around arithmetic only: the load below stays unconditional)
                     int ni, yy, xx;
                     if (p.wshift >= 0) {
                         ni = mm >> p.hwshift;
@@ -221,8 +245,20 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
                     }
                     row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
                 }
-                xp[j] = ldg4(pg.ptr + (size_t)row * pg.ld);
+                o[j] = ldg4(g.ptr + (size_t)row * g.ld);
             }
+        }
+    };
+    for (; tile < ntiles; tile += tstride) {
+        if (!FAST) set_tile(tile);
+        if (FAST && !EARLY_NEXT) begin_tile(tile);
+        if constexpr (TEPI) {
+            // channel tile 0's pieces are requested HERE, in front of the row tile's MFMAs, not in the epilogue: x does not depend
+            // on them, and a wave that asks after its MFMAs sits out a full memory round trip per tile with nothing of its own to do
+            GrpEnt pg0;
+            pg0.ptr = p.a; pg0.ld = 0; pg0.ups = 0;      // always a valid address
+            if (n0 + 4 * pc4 < p.Nout) pg0 = grp[(n0 + 4 * pc4) >> 2];
+            request_x(pg0, tile, xp);
         }
 
         f32x16 acc[NT];
@@ -299,22 +335,29 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             }
         };
 
-        auto mfma_chunk = [&](int ch, const float4 (&acur)[4]) {
+        auto mfma_live = [&](int ch, const float4 (&acur)[4], auto ltag) {      // the first L channel tiles of the slice
+            constexpr int L = decltype(ltag)::value;
             const float4* bb = Bs + (size_t)ch * 8 * NB;     // chunk ch = (tap, c): rows (t*kq4 + c*8) ..+7
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float4 bv[NT];
+                float4 bv[L];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bb[(2 * q + hi) * NB + nt * 32 + li];
+                for (int nt = 0; nt < L; ++nt) bv[nt] = bb[(2 * q + hi) * NB + nt * 32 + li];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].x, bv[nt].x, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < L; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].x, bv[nt].x, acc[nt], 0, 0, 0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].y, bv[nt].y, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < L; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].y, bv[nt].y, acc[nt], 0, 0, 0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].z, bv[nt].z, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < L; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].z, bv[nt].z, acc[nt], 0, 0, 0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].w, bv[nt].w, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < L; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].w, bv[nt].w, acc[nt], 0, 0, 0);
             }
+        };
+        auto mfma_chunk = [&](int ch, const float4 (&acur)[4]) {
+            if constexpr (TEPI && NT > 1) {                  // (block-uniform: the slice that carries one tile fewer)
+                if (ntl < NT) { mfma_live(ch, acur, std::integral_constant<int, NT - 1>{}); return; }
+            }
+            mfma_live(ch, acur, std::integral_constant<int, NT>{});
         };
 
         if (FAST) {
@@ -377,48 +420,71 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             // lane requests FOUR 16-byte pieces of x (4 channels of one row; 8 lanes cover 128 contiguous bytes), the pieces go
             // into the wave's LDS tile T[32][36], the tile is read back in the accumulator layout, dz overwrites the x it came
             // from, and leaves as four 16-byte stores per lane.
+            // Round 4: a wave owns up to NT channel tiles of its 32 rows (the A operand -- dY -- is read once per NT * 32 output
+            // channels instead of once per 32, each A fragment feeds NT independent accumulator chains); the tiles go through T one
+            // after the other, the next tile's x pieces requested while the current one is worked on.
             float* T = tileT + (size_t)wave * 32 * TEPI_PITCH;
-            if (tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
+            if (EARLY_NEXT && tile + tstride < ntiles) begin_tile(tile + tstride);      // next tile's first A chunk: behind the x requests, ahead of the stores
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * TEPI_PITCH + 4 * pc4) = xp[j];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            {
-                const int col = n0 + li;
-                const bool colok = col < p.Nout;
-                float csc = 0.f, csh = 0.f, cmu = 0.f, cis = 0.f;
-                if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
-                float s1 = 0.f, s2 = 0.f;
-                float* tcol = T + li;
-                // (three passes -- reads, arithmetic, writes: a read next to a write of the same array is ordered by the compiler,
-                // i.e. 16 dependent LDS round trips per tile)
-                float xv[16], dzv[16];
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt < ntl) {                                           // block-uniform
+                    const int pcol = n0 + nt * 32 + 4 * pc4;
+                    const bool pok = pcol < p.Nout;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH];
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * TEPI_PITCH + 4 * pc4) = xp[j];
+                    if (nt + 1 < NT && nt + 1 < ntl) {                    // the next channel tile's pieces, into the registers just emptied
+                        GrpEnt g;
+                        g.ptr = p.a; g.ld = 0; g.ups = 0;
+                        int gi = (pcol + 32) >> 2;
+                        asm volatile("" : "+v"(gi));      // (recomputed here: hoisted out of the tile loop the address costs a spilled register)
+                        if (pcol + 32 < p.Nout) g = grp[gi];
+                        request_x(g, tile, xp);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const int col = n0 + nt * 32 + li;
+                        const bool colok = col < p.Nout;
+                        float csc = 0.f, csh = 0.f, cmu = 0.f, cis = 0.f;
+                        if (colok) { csc = sc[col]; csh = sh[col]; cmu = mu[col]; cis = is[col]; }
+                        float s1 = 0.f, s2 = 0.f;
+                        float* tcol = T + li;
+                        // (three passes -- reads, arithmetic, writes: a read next to a write of the same array is ordered by the compiler,
+                        // i.e. 16 dependent LDS round trips per tile)
+                        float xv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float z = fmaf(xv[r], csc, csh);
-                    // ReLU mask; with a QuanInput behind the ReLU also its straight-through mask (no gradient where z >= 1)
-                    dzv[r] = (colok && z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[0][r] : 0.f;
-                    s1 += dzv[r];
-                    s2 = fmaf(dzv[r], colok ? (xv[r] - cmu) * cis : 0.f, s2);
+                        for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float z = fmaf(xv[r], csc, csh);
+                            // ReLU mask; with a QuanInput behind the ReLU also its straight-through mask (no gradient where z >= 1)
+                            const float dz = (colok && z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[nt][r] : 0.f;
+                            s1 += dz;
+                            s2 = fmaf(dz, colok ? (xv[r] - cmu) * cis : 0.f, s2);
+                            xv[r] = dz;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH] = xv[r];
+                        // the BatchNorm reductions of this tile straight into the block's fp64 accumulators in LDS (no per-wave fp64
+                        // registers: with NT tiles they were 4 NT VGPRs held across the whole launch)
+                        if (colok) {
+                            atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], (double)s1);
+                            atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], (double)s2);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (pok) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int rr = pr0 + 8 * j;
+                            *reinterpret_cast<float4*>(p.y + (size_t)(mrow0 + rr) * p.ldy + pcol) = *reinterpret_cast<const float4*>(T + rr * TEPI_PITCH + 4 * pc4);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+                    __builtin_amdgcn_wave_barrier();
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH] = dzv[r];
-                dsum[0] += (double)s1;
-                dsq[0] += (double)s2;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (pok) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rr = pr0 + 8 * j;
-                    *reinterpret_cast<float4*>(p.y + (size_t)(mrow0 + rr) * p.ldy + pcol) = *reinterpret_cast<const float4*>(T + rr * TEPI_PITCH + 4 * pc4);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
-            __builtin_amdgcn_wave_barrier();
             continue;
         }
         // EP_BWD: rows of this lane's 16 accumulator registers, plain and through the nearest-upsample map.
@@ -567,21 +633,23 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     // ---- per-channel reductions: lanes (l, l+32) -> waves (serialised through LDS) -> one fp64
     //      atomic per channel per block
     if (p.ystats != nullptr && !CUNET_DBG(p, 1)) {
-        double a[NT], b[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            a[nt] = dsum[nt] + shfl_xor_d(dsum[nt], 32);
-            b[nt] = dsq[nt] + shfl_xor_d(dsq[nt], 32);
-        }
-        if (hi == 0) {                                  // LDS fp64 atomics: one barrier instead of one per wave
+        if constexpr (!TEPI) {                          // (TEPI: every tile has added its sums already)
+            double a[NT], b[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], a[nt]);
-                atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], b[nt]);
+                a[nt] = dsum[nt] + shfl_xor_d(dsum[nt], 32);
+                b[nt] = dsq[nt] + shfl_xor_d(dsq[nt], 32);
+            }
+            if (hi == 0) {                              // LDS fp64 atomics: one barrier instead of one per wave
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], a[nt]);
+                    atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], b[nt]);
+                }
             }
         }
         __syncthreads();
-        if (tid < NB) {
+        if (tid < ntl * 32) {                           // (a slice's dead tile belongs to its neighbour)
             const int col = n0 + tid;
             if (col < p.Nout) {
                 atomic_add_f64(p.ystats + col, redbuf[tid * 2 + 0]);
@@ -1115,7 +1183,7 @@ constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 // pairs exist for the shapes the adapters take: the nothing-ragged 1x1 forward and its fp32 data gradient
 template <int LD, int EP, int NT, bool FAST, int XB>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
-    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && NT == 1 && XB == 0))) {
+    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && XB == 0))) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<LD, EP, NT, FAST, XB>),
@@ -1187,6 +1255,61 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
     }
 }
 
+// Launch geometry of the fp32 data gradient with the LDS-tile epilogue (TEPI instantiations) when a wave owns up to `c` channel tiles.
+// `est`: modelled matrix-pipe time of the slowest SIMD in tile-times (row tiles per wave x channel tiles per wave x waves per SIMD):
+// with only 32-row tiles to deal, a choice that leaves the waves 2.5 tiles each runs as long as one that leaves them 3.
+struct TepiGeom {
+    bool ok = false;
+    int NT = 1, gy = 1, bpc = 1, waves = 4, maxw = CUNET_TEPI_WAVES, rem = 0, gbg = 0, gsm = 0, gx = 1;
+    size_t smem = 0;
+    long est = 0;
+};
+static TepiGeom tepi_geometry(const ConvArgs& a, int c, int ntiles, int ncol32, long target, int num_cus) {
+    TepiGeom g;
+    const int slices = (ncol32 + c - 1) / c;
+    g.NT = (ncol32 + slices - 1) / slices;
+    if (g.NT > 1 && (long)ntiles * slices < target) return g;        // too few wave-tiles to fill the chip
+    g.gy = (ncol32 + g.NT - 1) / g.NT;
+    g.maxw = g.NT <= 2 ? CUNET_TEPI_WAVES : 8;                        // (conv_max_waves of those instantiations)
+    const size_t base = conv_smem_bytes(g.NT, a.taps, a.Kpad, a.Ccat);
+    for (g.bpc = 3; g.bpc >= 1; --g.bpc) {
+        const int wmax = g.maxw / g.bpc < 4 ? 4 : g.maxw / g.bpc;
+        g.smem = base + (size_t)wmax * CONV_TEPI_TILE;                // + one epilogue tile per wave
+        if (g.smem <= (g.bpc == 3 ? 52 * 1024 : (g.bpc == 2 ? 80 * 1024 : CONV_LDS_BUDGET))) break;
+    }
+    if (g.bpc < 1) return g;
+    const int max_blocks_x = (g.bpc * num_cus + g.gy - 1) / g.gy;
+    g.waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
+    if (g.waves > g.maxw / g.bpc) g.waves = g.maxw / g.bpc;
+    if (g.waves < 1) g.waves = 1;
+    g.gx = (ntiles + g.waves - 1) / g.waves;
+    if (g.gx > max_blocks_x) g.gx = max_blocks_x;
+    if (g.gx < 1) g.gx = 1;
+    const int wpb = g.waves < 4 ? 4 : g.waves;                        // waves a block is launched with
+    const int per_simd = (g.bpc * wpb + 3) / 4;
+    auto tiles_per_wave = [&](int blocks) { const long w = (long)blocks * g.waves; return (int)((ntiles + w - 1) / w); };
+    if (g.NT == 1) {
+        g.est = (long)tiles_per_wave(g.gx) * per_simd;
+    } else {
+        // slices of NT and (when the tile count does not divide) NT - 1 tiles; row blocks in proportion to a slice's tiles, out of
+        // what the chip holds at once, so that every block does about the same work: 5 tiles = 3 + 2 on 512 blocks -> 307 + 204
+        const int base_t = ncol32 / g.gy;
+        g.rem = ncol32 - base_t * g.gy;
+        const long cap_blocks = (long)g.bpc * num_cus;
+        const int need = (ntiles + g.waves - 1) / g.waves;            // row blocks that give every wave at least one tile
+        g.gsm = (int)(cap_blocks * base_t / ncol32);
+        g.gbg = g.rem ? (int)(cap_blocks * (base_t + 1) / ncol32) : 0;
+        if (g.gsm > need) g.gsm = need;
+        if (g.gbg > need) g.gbg = need;
+        if (g.gsm < 1) g.gsm = 1;
+        if (g.rem > 0 && g.gbg < 1) g.gbg = 1;
+        const long ts = (long)tiles_per_wave(g.gsm) * base_t, tb = g.rem ? (long)tiles_per_wave(g.gbg) * (base_t + 1) : 0;
+        g.est = (ts > tb ? ts : tb) * per_simd;
+    }
+    g.ok = true;
+    return g;
+}
+
 // Host launcher.  Picks the channel tile NT (all output channels per block when the node is big
 // and its weights fit the LDS, fewer when there are too few 32-row tiles to fill the chip), the
 // waves per block and the grid.
@@ -1225,8 +1348,32 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     // last slice is padded with zero tiles, so the cost of a choice is slices * (NT + overhead) tile-times:
     // a 160-channel dgrad (5 tiles) runs 2 x 3 instead of 2 x 4, a 288-channel one 3 x 3 instead of 3 x 4.
     static const float nt_ovh = tune_float("CUNET_CONV_NT_OVH", 0.3f);
+    // fast path: nothing ragged (see the kernel)
+    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !tune_int("CUNET_CONV_GENERIC", 0);
+    if (load == LD_SEG) {
+        for (int i = 0; i < a.nseg; ++i) fast = fast && (a.seg[i].C % 32 == 0) && (a.seg[i].ld % 4 == 0);
+    }
+    // the fp32 data gradient with the LDS-tile epilogue (TEPI instantiations of the kernel)
+    const bool tepi = epi == EP_BWD && fast && a.xbf16 == 0;
     int NT = 1;
-    if (nt_ovh < 0.f) {                                  // powers of two only (first version of this launcher)
+    TepiGeom tg;
+    if (tepi) {
+        // Channel tiles per wave (planner option dgrad_nt = the most allowed): more tiles per wave read dY fewer times and give every A
+        // fragment more independent accumulator chains, but they are dealt in coarser units -- the candidate with the shortest modelled
+        // matrix-pipe time wins, the larger NT on a tie.  dgrad_nt = 10 + k: as many as fit up to k, whatever the model says (sweeps).
+        const int opt = a.dgrad_nt > 0 ? a.dgrad_nt : 4;
+        const bool greedy = opt > 10;
+        int cap = greedy ? opt - 10 : opt;
+        cap = load == LD_PLAIN ? (cap > 4 ? 4 : (cap < 1 ? 1 : cap)) : 1;
+        for (int c = cap; c >= 1; --c) {
+            const TepiGeom g = tepi_geometry(a, c, ntiles, ncol32, target, num_cus);
+            if (!g.ok) continue;
+            if (!tg.ok || g.est < tg.est) tg = g;
+            if (greedy) break;
+        }
+        if (!tg.ok) return hipErrorInvalidValue;
+        NT = tg.NT;
+    } else if (nt_ovh < 0.f) {                                  // powers of two only (first version of this launcher)
         NT = ncol32 >= 4 ? 4 : (ncol32 >= 2 ? 2 : 1);
         while (NT > 1 && ((long)ntiles * ((ncol32 + NT - 1) / NT) < target ||
                           conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET))
@@ -1243,26 +1390,13 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
             if (cost < best) { best = cost; NT = c; }
         }
     }
-    // fast path: nothing ragged (see the kernel)
-    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad) && !tune_int("CUNET_CONV_GENERIC", 0);
-    if (load == LD_SEG) {
-        for (int i = 0; i < a.nseg; ++i) fast = fast && (a.seg[i].C % 32 == 0) && (a.seg[i].ld % 4 == 0);
-    }
     size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat);
     if (smem > CONV_LDS_BUDGET) return hipErrorInvalidValue;   // weights of one 32-channel slice exceed the LDS
     const int gy = (ncol32 + NT - 1) / NT;
+    a.col_slices = gy;
     int blocks_per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);
     int maxw = CONV_MAX_WAVES;            // 16 waves for one-tile blocks (VGPR budget 128) measured 2-3 % slower
-    if (epi == EP_BWD && fast && NT == 1 && a.xbf16 == 0) {      // + one epilogue tile per wave (TEPI instantiations of the kernel)
-        maxw = CUNET_TEPI_WAVES;
-        const size_t base = smem;
-        for (blocks_per_cu = 3; blocks_per_cu >= 1; --blocks_per_cu) {
-            const int wmax = maxw / blocks_per_cu < 4 ? 4 : maxw / blocks_per_cu;
-            smem = base + (size_t)wmax * CONV_TEPI_TILE;
-            if (smem <= (blocks_per_cu == 3 ? 52 * 1024 : (blocks_per_cu == 2 ? 80 * 1024 : CONV_LDS_BUDGET))) break;
-        }
-        if (blocks_per_cu < 1) return hipErrorInvalidValue;
-    }
+    if (tepi) { maxw = tg.maxw; blocks_per_cu = tg.bpc; smem = tg.smem; }
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
     if (waves > maxw / blocks_per_cu) waves = maxw / blocks_per_cu;
@@ -1277,6 +1411,12 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     if (xcd_remap && gy > 1 && (epi == EP_BWD || xcd_fwd)) {        // column slices of a row block re-read the same A rows: keep them on one XCD
         a.xcd_gx = gx; a.xcd_gy = gy;
         grid = dim3(8 * ((gx + 7) / 8) * gy, 1);
+    }
+    a.sl_rem = a.sl_gx_big = a.sl_gx_small = 0;
+    if (tepi && NT > 1) {                 // row blocks in proportion to a slice's tiles (tepi_geometry), decoded from a 1-D grid
+        a.sl_rem = tg.rem; a.sl_gx_big = tg.gbg; a.sl_gx_small = tg.gsm;
+        a.xcd_gx = a.xcd_gy = 0;
+        grid = dim3(8 * (tg.rem * ((tg.gbg + 7) / 8) + (gy - tg.rem) * ((tg.gsm + 7) / 8)), 1);
     }
     // never fewer than 4 waves: idle waves still help copying B into LDS and building the BN tables
     const int threads = (waves < 4 ? 4 : waves) * 64;

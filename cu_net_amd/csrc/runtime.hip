@@ -161,6 +161,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "fwd_fork_min_w") o.fwd_fork_min_w = value;
     else if (n == "pair_adapters") o.pair_adapters = value;
     else if (n == "heads_on_side") o.heads_on_side = value;
+    else if (n == "dgrad_nt") o.dgrad_nt = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -518,6 +519,7 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.K = c.Cout; a.taps = c.taps; a.wB = E.wsf + c.wB; a.Kpad = c.KpadB; a.Npad = c.NpadB;
     a.y = n.dz >= 0 ? E.wsf + n.dz : nullptr; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = E.zero + n.red;
     a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
+    a.dgrad_nt = P.opts.dgrad_nt;
     return a;
 }
 

@@ -261,6 +261,9 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "heads_on_side"      1 (default): in a training pass the heat-map heads (forward with the fused loss, data and weight gradient)
  *                        run on the internal side stream -- nothing on the caller's stream reads a head's output before the loss
  *                        is finalised, and its backward depends on the loss gradient only; 0: in node order on the caller's stream
+ *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
+ *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
+ *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 

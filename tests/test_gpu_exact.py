@@ -295,6 +295,47 @@ def test_adapter_pair_launches_equal_the_single_launches(mode):
     assert float((ga - gb).norm() / gb.norm()) <= (1e-2 if mode == 'fp32' else 3e-2)
 
 
+def test_dgrad_channel_tiles_per_wave_agree():
+    """fp32 1x1 data gradient with 1, 2, 3 and 4 channel tiles of dz per wave (planner option dgrad_nt; 10 + k = "as many as fit up to
+    k" whatever the launcher's balance model prefers): the same MFMA chains over K per element, so dz is bit-identical; only the order
+    of the fp64 BatchNorm reductions differs.  BASELINE config 2's shapes (N = 24: below that the launcher keeps one tile per wave),
+    whole backward, every parameter gradient and the stem's input-side gradient tensor against the one-tile run.  Covers the slices of
+    unequal tile counts (5 tiles = 3 + 2: row blocks dealt in proportion), the pair launches of the adapters and the two-waves-per-SIMD
+    instantiations (models/cu_net.py:11-17 backward; cu-net.py:182)."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=87)
+    x, target = O.synthetic_batch(24, 68, 256, seed=88)
+    xd, td = x.cuda(), target.cuda()
+    res = {}
+    try:
+        for opt in (1, 12, 13, 14, 4):
+            set_planner_option('dgrad_nt', opt)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(24, 256, 256, True)
+            loss = plan.stage_target(td)
+            plan.forward(xd, True, want_outputs=False)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            d = plan.handle.describe()
+            first_pool = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][1]['out']][0]      # the stem's pooled output
+            res[opt] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True))
+            del plan, net
+    finally:
+        set_planner_option('dgrad_nt', 4)
+    l0, g0, t0 = res[1]
+    assert torch.isfinite(g0).all() and float(g0.norm()) > 0
+    for opt in (12, 13, 14, 4):
+        l1, g1, t1 = res[opt]
+        assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)      # the forward does not depend on the option (fp64 atomics order only)
+        assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))
+        assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max()), (opt, float((t1 - t0).abs().max()), float(t0.abs().max()))
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16_grads'])
 def test_heads_on_the_side_stream_equal_heads_in_node_order(mode):
     """Planner option heads_on_side (default 1): in a training pass the heat-map heads run on the internal side stream -- forward
