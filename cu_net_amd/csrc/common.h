@@ -133,6 +133,8 @@ struct WgradArgs {
     int IH, IW;
     int xbf16;             // 1 = the segments' x are bf16; 2 = x and dy are bf16 (dw stays fp32)
     int qin_bits;          // > 0: the conv's input is QuanInput(relu(bn(x))): the weight gradient contracts dY with the QUANTISED activation
+    int bf16_dma;          // xbf16 == 2, 1x1: 1 = the LDS-DMA ring kernel where its preconditions hold (the plan's snapshot of planner option
+                           // wgrad_bf16_dma), 0 = always the register-staged kernel
 };
 
 // third-generation 1x1 weight gradient (wgrad3_kernels.hip): one workgroup owns the whole [128][CW] output for a range
@@ -143,6 +145,7 @@ struct Wg3Args {
     int rows_per_split;    // multiple of 32
     int c0, CW;            // channel slice of this launch (CW <= 320, multiple of 32)
     int any_ups;
+    int wshift, hwshift;   // log2(W), log2(H * W) when both are powers of two, else -1 (wgrad4_bf16_kernel's up-sample map)
 };
 // LDS geometry of the stem weight gradient (wgrad3_stem_kernel): an input image row is stored as 3 channel rows of CP floats
 // (3 zero columns left and right), a ring row every RP floats; CP = 17 and RP = 7 (mod 32) put im2col column k = c*49 + ky*7 + kx

@@ -162,6 +162,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "pair_adapters") o.pair_adapters = value;
     else if (n == "heads_on_side") o.heads_on_side = value;
     else if (n == "dgrad_nt") o.dgrad_nt = value;
+    else if (n == "wgrad_bf16_dma") o.wgrad_bf16_dma = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -599,6 +600,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
             w.dw = h->grads + c.w;
             w.xbf16 = E.xmode;
             w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
+            w.bf16_dma = planner_options().wgrad_bf16_dma;      // (a launch-time choice between bit-identical kernels: read live, not from the plan's snapshot)
             if (c.taps == 9 && wg3_active(P, n, E.xmode) && wgrad3_3x3_supported(w)) {
                 // LDS ring of activated image rows, partial tiles [split][tap][n][c] (reduced + transposed per bucket)
                 const bool on16 = wgrad3_3x3_on_bf16_mfma(w);

@@ -478,6 +478,256 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_bf16_kernel(const Wg3Ar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The bf16 weight gradient on CDNA4's data-movement instructions (round 4).  The kernel above moves every byte through
+// VGPRs twice (global -> registers -> pixel-major LDS image, eight 8-byte ds_writes per 64 bytes) and keeps ONE 64-pixel
+// chunk in flight per workgroup: alone on the GPU it reached 1.1 TB/s, 0.14 of the HBM peak (profiles/r03_bf16_*), parked
+// on its loads.  Here
+//   * the raw NHWC rows of dY [P][128] and of the concat X [P][CW] go from HBM straight into an LDS ring by LDS-DMA
+//     (global_load_lds_dwordx4: 16 bytes per lane, lane l lands at M0 + 16 l, any source address per lane -- so a ring row
+//     is [dY | segment 0 | segment 1 | ...] gathered from the tensors' own rows, the nearest-upsample map included); no
+//     VGPR holds data, and D - 1 of the D ring slots (4 ... 7 x 18 ... 30 KB per workgroup) are in flight while one is used;
+//   * MFMA operands are taken from those channel-minor rows by ds_read_b64_tr_b16, the LDS transpose read: in a 16-lane group lane 4 j + c passes the address of (pixel j, 4-channel piece c) of a 4 x 16 block
+//     and lane i receives channel i of the four pixels (tools/probes/cdna4_lds_probe.hip, gpurun_out of round 4) -- two
+//     reads give the 8 consecutive pixels v_mfma_f32_32x32x16_bf16 wants per lane;
+//   * BatchNorm + ReLU run on the X fragment in registers: after the transpose a lane holds eight pixels of ONE channel,
+//     i.e. one scale / shift pair per (lane, channel tile), applied in fp32 and re-rounded with v_cvt_pk_bf16_f32 exactly
+//     as the staging path above does -- the two kernels are bit-identical (tests/test_gpu_exact.py).
+// Ring row pitch: 256 + 64 CT bytes, + 64 when CT is even, so that pitch = 64 or 192 (mod 256): the four pixel rows a
+// 32-lane half touches in one transpose read start 16 banks apart (conflict-free).  One barrier per 32-pixel slot.
+// Preconditions (else the staging kernel runs): every pixel range a multiple of 32 (M and rows_per_split), power-of-two
+// image geometry when a segment is read through the up-sample map.
+constexpr int WG4_P = 32;                  // pixels per ring slot = two MFMA k-steps
+constexpr int WG4_RING0 = 3072;            // LDS byte offset of the ring (sc / sh tables in front of it)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int wg4_pitch(int ct) { return 256 + 64 * ct + ((ct & 1) ? 0 : 64); }      // bytes per pixel row
+__host__ __device__ constexpr int wg4_slots(int ct) { return (160 * 1024 - WG4_RING0) / (WG4_P * wg4_pitch(ct)); }
+
+// one LDS-DMA request: 64 lanes x 16 bytes from per-lane global addresses to LDS [dst, dst + 1024)
+__device__ __forceinline__ void wg4_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wg4_wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// bf16 pair (two pixels of one channel) -> relu(bn(.)) in fp32 -> bf16 pair
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wg4_bn_relu(unsigned v, float sc, float sh) {
+    const f32x2_t y = {fmaxf(fmaf(bf16_bits_lo(v), sc, sh), 0.f), fmaxf(fmaf(bf16_bits_hi(v), sc, sh), 0.f)};
+    // (the compiler's own v_cvt_pk_bf16_f32 -- round to nearest even, as the asm helper above -- so that it also places the wait
+    // states between this VALU write and the MFMA that reads the register)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2_t));
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct Wg4Frag { u32x2_t h[2]; };          // (plain registers: the two halves a transpose read pair delivers)
+__device__ __forceinline__ bf16x8_t wg4_operand(const Wg4Frag& f) {
+    const u32x4_t w = {f.h[0].x, f.h[0].y, f.h[1].x, f.h[1].y};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+
+// the transpose reads of one k-step: fragment 0 = dY (this wave's output-channel tile), fragments 1 .. CTW = X tiles; all
+// requests, then ONE wait -- issued behind the previous step's MFMAs, whose execution covers the LDS round trip
+template <int CTW, int PITCH>
+__device__ __forceinline__ void wg4_read_step(Wg4Frag (&f)[CTW + 1], unsigned addr_a, unsigned addr_x) {
+#define WG4_RD(F, ADDR, OFF) \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" \
+                 : "=&v"((F).h[0]), "=&v"((F).h[1]) : "v"(ADDR), "n"(OFF), "n"((OFF) + 4 * PITCH) : "memory")
+    WG4_RD(f[0], addr_a, 0);
+    WG4_RD(f[1], addr_x, 0);
+    if constexpr (CTW > 1) WG4_RD(f[CTW > 1 ? 2 : 0], addr_x, 64);
+    if constexpr (CTW > 2) WG4_RD(f[CTW > 2 ? 3 : 0], addr_x, 128);
+    if constexpr (CTW > 3) WG4_RD(f[CTW > 3 ? 4 : 0], addr_x, 192);
+    if constexpr (CTW > 4) WG4_RD(f[CTW > 4 ? 5 : 0], addr_x, 256);
+#undef WG4_RD
+    // the wait names every destination: nothing reads (or moves) them before the data has landed
+    if constexpr (CTW == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].h[0]), "+v"(f[0].h[1]), "+v"(f[1].h[0]), "+v"(f[1].h[1]), "+v"(f[2].h[0]), "+v"(f[2].h[1]),
+                     "+v"(f[3].h[0]), "+v"(f[3].h[1]), "+v"(f[4].h[0]), "+v"(f[4].h[1]), "+v"(f[5].h[0]), "+v"(f[5].h[1]) :: "memory");
+    else if constexpr (CTW == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].h[0]), "+v"(f[0].h[1]), "+v"(f[1].h[0]), "+v"(f[1].h[1]), "+v"(f[2].h[0]), "+v"(f[2].h[1]),
+                     "+v"(f[3].h[0]), "+v"(f[3].h[1]), "+v"(f[4].h[0]), "+v"(f[4].h[1]) :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].h[0]), "+v"(f[0].h[1]), "+v"(f[1].h[0]), "+v"(f[1].h[1]), "+v"(f[2].h[0]), "+v"(f[2].h[1]),
+                     "+v"(f[3].h[0]), "+v"(f[3].h[1]) :: "memory");
+}
+
+template <int CT>      // channel tiles of the slice: CW = 32 CT; CT <= 5: split-K over the two k-steps of a slot
+__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad4_bf16_kernel(const Wg3Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SPLITK = CT <= 5;
+    constexpr int CTW = SPLITK ? CT : (CT + 1) / 2;
+    static_assert(CTW >= 3 && CTW <= 5, "tile ownerships of 3 .. 5 channel tiles");
+    constexpr int CW = 32 * CT;
+    constexpr int PITCH = wg4_pitch(CT);                   // bytes
+    constexpr int PPR = PITCH / 16;                        // 16-byte pieces per ring row (incl. the pad)
+    constexpr int NI = WG4_P * PPR / 64;                   // DMA requests per slot
+    constexpr int IPC = (NI + 7) / 8;                      // ... per wave
+    constexpr int D = wg4_slots(CT);                       // ring slots
+    constexpr int SLOT = WG4_P * PITCH;                    // bytes
+    static_assert(D >= 3 && (D - 1) * IPC < 64, "ring depth / vmcnt range");
+    const WgradArgs& p = q.w;
+    float* sc = reinterpret_cast<float*>(smem);            // [CW]
+    float* sh = sc + WG3_MAXCW;
+    const unsigned ring0 = (unsigned)(size_t)smem + WG4_RING0;      // LDS byte address of slot 0
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int HW = p.H * p.W;
+    const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(p.dy);
+
+    for (int c = tid; c < CW; c += WG3_THREADS) {
+        const int cc = q.c0 + c;
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cc >= p.seg[t].choff) s = t;
+        const Seg& sg = p.seg[s];
+        const int lc = cc - sg.choff;
+        const double sum = sg.stats[lc], sq = sg.stats[sg.C + lc];
+        const double mean = sum / sg.count;
+        double var = sq / sg.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[cc] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[cc] - mean * scale);
+    }
+
+    // ---- loader plan of this lane (slot-invariant): request t of this wave is request I = wave + 8 t of the slot (the last ones
+    // of a slot whose count does not divide by 8 are issued twice: same bytes to the same place); lane l moves piece 64 I + l
+    const unsigned short* gptr[IPC];
+    int gld[IPC], gpix[IPC], gups[IPC];
+    unsigned gdst[IPC];
+#pragma unroll
+    for (int t = 0; t < IPC; ++t) {
+        int I = wave + 8 * t;
+        if (I >= NI) I = NI - 1;
+        gdst[t] = (unsigned)I * 1024u;
+        const int piece = I * 64 + lane;
+        const int row = piece / PPR, pr = piece - row * PPR;
+        gpix[t] = row;
+        if (pr >= 16 && pr < 16 + CW / 8) {                // X: 8 channels of the slice
+            const int cc = q.c0 + 8 * (pr - 16);
+            int s = 0;
+            for (int u = 1; u < p.nseg; ++u)
+                if (cc >= p.seg[u].choff) s = u;
+            const Seg& sg = p.seg[s];
+            gptr[t] = reinterpret_cast<const unsigned short*>(sg.x) + (cc - sg.choff);
+            gld[t] = sg.ld; gups[t] = sg.ups;
+        } else {                                           // dY: 8 output channels (a pad piece repeats piece 0)
+            gptr[t] = dy16 + 8 * (pr < 16 ? pr : 0);
+            gld[t] = p.lddy; gups[t] = 0;
+        }
+    }
+    const int row_begin = blockIdx.x * q.rows_per_split;
+    int row_end = row_begin + q.rows_per_split;
+    if (row_end > p.M) row_end = p.M;
+    const int nchunks = (row_end - row_begin) / WG4_P;     // (whole slots: launcher precondition)
+    auto issue = [&](int chunk) {                          // the IPC requests of this wave for ring slot chunk % D
+        const int m0 = row_begin + chunk * WG4_P;
+        const unsigned slot = ring0 + (unsigned)(chunk % D) * (unsigned)SLOT;
+#pragma unroll
+        for (int t = 0; t < IPC; ++t) {
+            const int m = m0 + gpix[t];
+            int row = m;
+            if (q.any_ups && gups[t]) {                    // nearest-upsample index map (models/cu_net.py:250,265), power-of-two geometry
+                const int nimg = m >> q.hwshift;
+                const int rem = m & (HW - 1);
+                row = nimg * (HW >> 2) + ((rem >> q.wshift) >> 1) * (p.W >> 1) + ((rem & (p.W - 1)) >> 1);
+            }
+            wg4_dma16(gptr[t] + (size_t)row * gld[t], __builtin_amdgcn_readfirstlane(slot + gdst[t]));
+        }
+    };
+
+    // ---- tile ownership as in the staging kernel: output-channel tile wave & 3; split-K: every X tile, k-step (wave >> 2) of a slot;
+    // otherwise half (wave >> 2) owns CTW consecutive X tiles -- the second half the LAST CTW (an odd CT: its first tile repeats the
+    // first half's last one and is not stored)
+    const int nt = wave & 3;
+    const int half = wave >> 2;
+    const int cb = SPLITK ? 0 : (half ? CT - CTW : 0);
+    const bool dup_first = !SPLITK && half && (CT & 1);
+    float bsc[CTW], bsh[CTW];
+    f32x16 acc[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // transpose-read address of this lane inside a slot: pixel 8 (l >> 5) + ((l & 15) >> 2) (+ 4 for the second read, + 16 for the second
+    // k-step), channel piece 16 ((l >> 4) & 1) + 4 (l & 3) of the tile
+    const unsigned lane_off = (unsigned)((8 * hi + ((lane & 15) >> 2)) * PITCH + 32 * ((lane >> 4) & 1) + 8 * (lane & 3));
+    const unsigned off_a = lane_off + (unsigned)(nt * 64);
+    const unsigned off_x = lane_off + (unsigned)(256 + cb * 64);
+
+#pragma unroll 1
+    for (int c = 0; c < D - 1; ++c)
+        if (c < nchunks) issue(c);
+    __syncthreads();                                       // sc / sh visible
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) { bsc[t] = sc[(cb + t) * 32 + li]; bsh[t] = sh[(cb + t) * 32 + li]; }
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        // this wave's requests of slot `chunk` have landed when at most the (D - 2) younger slots' are outstanding (the tail of the
+        // loop issues nothing: wait for everything there)
+        if (chunk + (D - 2) < nchunks) wg4_wait_dma<(D - 2) * IPC>(); else wg4_wait_dma<0>();
+        __syncthreads();                                   // every wave's pieces of this slot are in LDS; slot chunk - 1 is free
+        if (chunk + D - 1 < nchunks) issue(chunk + D - 1);
+        const unsigned slot = ring0 + (unsigned)(chunk % D) * (unsigned)SLOT;
+        constexpr int NK = SPLITK ? 1 : 2;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const unsigned kst = (unsigned)((SPLITK ? half : ks) * 16 * PITCH);
+            Wg4Frag f[CTW + 1];
+            wg4_read_step<CTW, PITCH>(f, slot + off_a + kst, slot + off_x + kst);
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) {
+                f[t + 1].h[0].x = wg4_bn_relu(f[t + 1].h[0].x, bsc[t], bsh[t]);
+                f[t + 1].h[0].y = wg4_bn_relu(f[t + 1].h[0].y, bsc[t], bsh[t]);
+                f[t + 1].h[1].x = wg4_bn_relu(f[t + 1].h[1].x, bsc[t], bsh[t]);
+                f[t + 1].h[1].y = wg4_bn_relu(f[t + 1].h[1].y, bsc[t], bsh[t]);
+            }
+            const bf16x8_t av = wg4_operand(f[0]);
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wg4_operand(f[t + 1]), acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // (the ring is reused below)
+
+    if (SPLITK) {
+        float* red = reinterpret_cast<float*>(smem + WG4_RING0);
+        if (half == 1) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((nt * CTW + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((nt * CTW + t) * 16 + r) * 64 + lane];
+        }
+        if (half == 1) return;
+    }
+    float* out = q.part + (size_t)blockIdx.x * WG3_NOUT * p.Ccat;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        if (t == 0 && dup_first) continue;                  // the tile both halves computed
+        const int c = q.c0 + (cb + t) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)n * p.Ccat + c] = acc[t][r];
+        }
+    }
+}
+
 // dst[i] = sum_s part[s][i]: fixed summation order (bitwise reproducible).  blockIdx.y = table entry.
 // A block covers 64 float4 of the output; its four 64-thread groups take every fourth split and meet in LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgReduceEntry* __restrict__ tab, const float* __restrict__ ws,
@@ -524,6 +774,23 @@ bool wgrad3_supported(const WgradArgs& a) {
     return true;
 }
 
+static hipError_t launch_wg4_bf16(const Wg3Args& q, int ct, dim3 grid, hipStream_t s) {
+    const size_t smem = (size_t)WG4_RING0 + (size_t)wg4_slots(ct) * WG4_P * wg4_pitch(ct);
+#define CUNET_WG4(CT_) hipLaunchKernelGGL((wgrad4_bf16_kernel<CT_>), grid, dim3(WG3_THREADS), smem, s, q)
+    switch (ct) {
+        case 4: CUNET_WG4(4); break;
+        case 5: CUNET_WG4(5); break;
+        case 6: CUNET_WG4(6); break;
+        case 7: CUNET_WG4(7); break;
+        case 8: CUNET_WG4(8); break;
+        case 9: CUNET_WG4(9); break;
+        case 10: CUNET_WG4(10); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CUNET_WG4
+    return hipGetLastError();
+}
+
 static hipError_t launch_wg3_bf16(const Wg3Args& q, int ct, dim3 grid, size_t smem, hipStream_t s) {
 #define CUNET_WG3B(CTW_, SK_) hipLaunchKernelGGL((wgrad3_bf16_kernel<CTW_, SK_>), grid, dim3(WG3_THREADS), smem, s, q)
     switch (ct) {
@@ -564,7 +831,9 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
             (const void*)&wgrad3_kernel<4, true, 1>, (const void*)&wgrad3_kernel<5, true, 1>, (const void*)&wgrad3_kernel<3, false, 1>,
             (const void*)&wgrad3_kernel<4, false, 1>, (const void*)&wgrad3_kernel<5, false, 1>,
             (const void*)&wgrad3_bf16_kernel<4, true>, (const void*)&wgrad3_bf16_kernel<5, true>, (const void*)&wgrad3_bf16_kernel<3, false>,
-            (const void*)&wgrad3_bf16_kernel<4, false>, (const void*)&wgrad3_bf16_kernel<5, false>};
+            (const void*)&wgrad3_bf16_kernel<4, false>, (const void*)&wgrad3_bf16_kernel<5, false>,
+            (const void*)&wgrad4_bf16_kernel<4>, (const void*)&wgrad4_bf16_kernel<5>, (const void*)&wgrad4_bf16_kernel<6>, (const void*)&wgrad4_bf16_kernel<7>,
+            (const void*)&wgrad4_bf16_kernel<8>, (const void*)&wgrad4_bf16_kernel<9>, (const void*)&wgrad4_bf16_kernel<10>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -577,6 +846,15 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
     q.rows_per_split = rows_per_split;
     q.any_ups = 0;
     for (int i = 0; i < a.nseg; ++i) q.any_ups |= a.seg[i].ups;
+    {
+        auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (v > 0 && (1 << l) == v) ? l : -1; };
+        const int lw = lg2(a.W), lhw = lg2(a.H * a.W);
+        q.wshift = (lw >= 0 && lhw >= 0) ? lw : -1;
+        q.hwshift = (lw >= 0 && lhw >= 0) ? lhw : -1;
+    }
+    // bf16 x and dY: the LDS-DMA ring kernel (wgrad4_bf16_kernel) when every pixel range is whole ring slots and the up-sample map is
+    // shifts; the register-staged kernel otherwise (ragged ranges: N * H * W not a multiple of 32 at the bottom of a small batch)
+    const bool dma = a.xbf16 == 2 && a.bf16_dma && a.M % WG4_P == 0 && rows_per_split % WG4_P == 0 && (!q.any_ups || q.wshift >= 0);
     const int ct_all = a.Ccat / 32;
     const int nslices = (ct_all + 9) / 10;
     const int per = (ct_all + nslices - 1) / nslices;
@@ -589,7 +867,7 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
         size_t buf_bytes = a.xbf16 == 2 ? (size_t)2 * (WG3_NOUT + q.CW) * WG3B_LDP * 2 : (size_t)2 * WG3_P * (WG3_NOUT + ldx) * 4;
         if (ct <= 5 && buf_bytes < (size_t)4 * ct * 4096) buf_bytes = (size_t)4 * ct * 4096;      // split-K hand-over area
         const size_t smem = (size_t)2 * WG3_MAXCW * 4 + buf_bytes;
-        const hipError_t e = a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)
+        const hipError_t e = dma ? launch_wg4_bf16(q, ct, dim3(S), s) : a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)
                            : a.xbf16 ? launch_wg3_x<1>(q, ct, dim3(S), smem, s) : launch_wg3_x<0>(q, ct, dim3(S), smem, s);
         if (e != hipSuccess) return e;
     }

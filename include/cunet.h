@@ -264,6 +264,10 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
  *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
+ *   "wgrad_bf16_dma"     1 (default): the 1x1 weight gradient of the bf16 storage mode streams dY and x into an LDS ring by LDS-DMA
+ *                        (global_load_lds) and takes its MFMA operands with the LDS transpose read where every pixel range is whole
+ *                        32-pixel slots; 0: always the register-staged kernel of rounds 2-3 (bit-identical results).  Unlike the other
+ *                        options this one is read at every launch, also by live plans
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
 

@@ -336,6 +336,56 @@ def test_dgrad_channel_tiles_per_wave_agree():
         assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max()), (opt, float((t1 - t0).abs().max()), float(t0.abs().max()))
 
 
+@pytest.mark.parametrize('n', [4, 24])
+def test_bf16_weight_gradient_on_lds_dma_is_bit_identical(n):
+    """wgrad4_bf16_kernel (round 4: dY and x streamed into an LDS ring by global_load_lds_dwordx4, MFMA operands by
+    ds_read_b64_tr_b16, BatchNorm + ReLU on the transposed fragment) against wgrad3_bf16_kernel (operands transposed through VGPRs
+    on the way into LDS) on the SAME plan state, node by node: the two contract the same bf16 operands in the same order, so every
+    1x1 weight gradient must agree bit for bit.  N = 4: few splits, 2 - 8 ring slots per workgroup (shorter than the ring: its
+    prologue / tail paths); N = 24: the bench's geometry (96 splits of 1024 pixels = 32 slots, the ring wraps).  Up-sampled
+    segments (up blocks), split-K (<= 5 channel tiles) and two-half ownerships incl. odd tile counts (7, 9) all occur in CU-Net-2.
+    Planner option wgrad_bf16_dma; autograd wgrad of models/cu_net.py:24,43."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=93)
+    x, _ = O.synthetic_batch(n, 16, 256, seed=94)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    plan = net._get_plan(n, 256, 256, True, bf16=True)
+    plan.forward_bf16(x.cuda(), 2, want_outputs=False)
+    torch.cuda.synchronize()
+    desc = plan.handle.describe()
+    T = desc['tensors']
+    off = {name: (o, nmel) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    nodes = [(k, nd) for k, nd in enumerate(desc['nodes']) if nd['op'] == 'conv' and nd['taps'] == 1 and nd.get('wg3_bf16', 0) > 0]
+    assert len(nodes) >= 40
+    seen_ct, bad = set(), []
+    try:
+        for k, nd in nodes:
+            o, nmel = off[nd['conv'] + '.weight']
+            t = T[nd['out']]
+            gen = torch.Generator().manual_seed(2000 + k)
+            plan.debug_poke(t['name'], torch.randn((t['N'], t['C'], t['H'], t['W']), generator=gen), grad=True)      # this node's d(loss)/d(out)
+            got = {}
+            for dma in (1, 0):
+                set_planner_option('wgrad_bf16_dma', dma)
+                plan.debug_run_node_backward(k)
+                torch.cuda.synchronize()
+                got[dma] = net._grad_arena[o:o + nmel].clone()
+            seen_ct.add(nmel // (128 * 32))
+            if not torch.equal(got[1], got[0]):
+                d = (got[1] - got[0]).abs()
+                bad.append(f'{nd["name"]}: {int((d > 0).sum())}/{nmel} elements differ, max {float(d.max()):.3e} of {float(got[0].abs().max()):.3e}')
+            assert float(got[0].abs().max()) > 0
+    finally:
+        set_planner_option('wgrad_bf16_dma', 1)
+    assert not bad, '\n'.join(bad[:20])
+    assert {4, 5, 6, 8, 9, 10} <= seen_ct, seen_ct
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16_grads'])
 def test_heads_on_the_side_stream_equal_heads_in_node_order(mode):
     """Planner option heads_on_side (default 1): in a training pass the heat-map heads run on the internal side stream -- forward

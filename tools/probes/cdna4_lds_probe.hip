@@ -16,7 +16,7 @@ __global__ void tr_probe(unsigned short* out, int pitch_elems) {
     const int l = threadIdx.x;
     // hypothesis (guide): a 16-lane group reads a [4 k][16 col] row-major block; lane (l & 15) gets column l & 15, rows 0..3.
     // Address given per lane: base of ITS group's block + its own column?  Try: addr = ((l >> 4) * 4 * pitch + (l & 15)) elements.
-    const unsigned addr = (unsigned)(((l >> 4) * 4 * pitch_elems + (l & 15)) * 2);
+    const unsigned addr = (unsigned)(size_t)lds + (unsigned)(((l >> 4) * 4 * pitch_elems + (l & 15)) * 2);
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     out[l * 4 + 0] = (unsigned short)(v.x & 0xffff);
@@ -31,7 +31,7 @@ __global__ void tr_probe_uniform(unsigned short* out, int pitch_elems) {
     for (int i = threadIdx.x; i < 64 * 64; i += 64) lds[i] = (unsigned short)i;
     __syncthreads();
     const int l = threadIdx.x;
-    const unsigned addr = (unsigned)(((l >> 4) * 4 * pitch_elems) * 2);
+    const unsigned addr = (unsigned)(size_t)lds + (unsigned)(((l >> 4) * 4 * pitch_elems) * 2);
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     out[l * 4 + 0] = (unsigned short)(v.x & 0xffff);
@@ -48,7 +48,7 @@ __global__ void tr_probe_rowpiece(unsigned short* out, int pitch_elems) {
     __syncthreads();
     const int l = threadIdx.x;
     const int r = (l >> 4) * 4 + ((l & 15) >> 2), c = 4 * (l & 3);
-    const unsigned addr = (unsigned)((r * pitch_elems + c) * 2);
+    const unsigned addr = (unsigned)(size_t)lds + (unsigned)((r * pitch_elems + c) * 2);
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     out[l * 4 + 0] = (unsigned short)(v.x & 0xffff);
@@ -64,7 +64,7 @@ __global__ void glds_probe(const unsigned* src, unsigned* out, int lds_base_byte
     const int l = threadIdx.x;
     // lane l asks for the 16 bytes at src + 4 * (reverse ? 63 - l : l) dwords
     const unsigned* g = src + 4 * (reverse ? 63 - l : l);
-    const unsigned m0v = (unsigned)lds_base_bytes;      // LDS byte address of the wave's 1 KB destination (the array starts at LDS 0 here)
+    const unsigned m0v = (unsigned)(size_t)lds + (unsigned)lds_base_bytes;      // LDS byte address of the wave's 1 KB destination (the array starts at LDS 0 here)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0\n\ts_waitcnt vmcnt(0)"
                  : "=&s"(keep) : "v"(g), "s"(m0v) : "memory");
