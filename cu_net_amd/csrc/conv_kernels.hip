@@ -199,6 +199,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
         cl = 0;
     };
     auto fetch = [&](float4 (&a)[4]) {                // loads chunk (sidx|tap, cl)
+        if (LD == LD_PLAIN && CUNET_DBG(p, 256)) {
+            // tuning builds, TIMING ONLY (the operand is wrong): the same 4 KB of the chunk requested as 8 rows x 128 contiguous bytes per
+            // instruction instead of 32 rows x 32 bytes -- what a request pattern that is kind to the vector L1 would buy
+            const float* base = p.a + (size_t)(mc - li + (lane >> 3)) * p.lda + (lane & 7) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = ldx4<GB>(base + (size_t)(8 * q) * p.lda, cl * 32);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = ldx4<GB>(rowptr, cl * 32 + q * 8);
         if (LD == LD_PLAIN3 && !tvalid) {
@@ -1208,7 +1216,10 @@ static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t 
     if constexpr (EP == EP_FWD && XB == 0 && LD == LD_SEG) {
         if (a.mse_tgt != nullptr) {        // a head with the loss fused in: the instantiation that carries the MSE epilogue
             if (b) return hipErrorInvalidValue;
-            return launch_inst<LD, EP, NT, FAST, 3>(a, grid, threads, smem, s, nullptr);
+            // (never four channel tiles: 16 target values per tile next to 64 accumulators spilled 10 - 13 registers; the launcher
+            // caps a fused-loss head at three)
+            if constexpr (NT <= 3) return launch_inst<LD, EP, NT, FAST, 3>(a, grid, threads, smem, s, nullptr);
+            else return hipErrorInvalidValue;
         }
     } else if constexpr (XB != 3) {
         if (a.mse_tgt != nullptr) return hipErrorInvalidValue;      // (the fused loss exists for the 1x1 forward only)
@@ -1382,7 +1393,7 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
         float best = 1e30f;
         static const int nt_max = tune_int("CUNET_CONV_NT_MAX", 4);
         static const int nt_max_bwd = tune_int("CUNET_CONV_NT_MAX_BWD", 1);
-        for (int c = (a.xbf16 ? 1 : (epi == EP_BWD ? nt_max_bwd : nt_max)); c >= 1; --c) {
+        for (int c = (a.xbf16 ? 1 : (epi == EP_BWD ? nt_max_bwd : (a.mse_tgt ? (nt_max < 3 ? nt_max : 3) : nt_max))); c >= 1; --c) {
             if (conv_smem_bytes(c, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET) continue;
             const int slices = (ncol32 + c - 1) / c;
             if (c > 1 && (long)ntiles * slices < target) continue;

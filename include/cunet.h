@@ -245,7 +245,7 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "wgrad3_min_chunks"  at least this many 32-pixel chunks per workgroup of that kernel (default 2)
  *   "wgrad3_max_splits"  at most this many workgroups (= partial tiles) per launch (default 256)
  *   "wgrad3_min_chunks_bf16", "wgrad3_max_splits_bf16"   the same two with bf16 gradient tensors, where these kernels are
- *                        HBM-bound and fewer, longer splits win (defaults 4 and 96)
+ *                        HBM-bound and fewer, longer splits win (defaults 4 and 128; 96 before the LDS-DMA kernel of round 4)
  *   "wgrad3_stem"        1 (default): the stem's 7x7 weight gradient on the LDS-staged atomics-free kernel where the shape
  *                        allows (128 output channels, output width a multiple of 64); 0: per-wave atomic kernel
  *   "conv3x3_ring_min_rows"  the 3x3 forward of 64-pixel-wide levels runs on the LDS row ring when the batch has at least this many
