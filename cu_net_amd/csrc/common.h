@@ -84,6 +84,8 @@ struct ConvArgs {
     int sl_rem, sl_gx_big, sl_gx_small;      // its first sl_rem slices carry one tile more than the others and get sl_gx_big row blocks each,
                            // the others sl_gx_small -- row blocks in proportion to the tiles, so that every block does the same work
                            // (sl_gx_small > 0 selects this decoding of the 1-D grid, see conv_body)
+    float* wg_part;        // EP_BWD, fp32, 1x1: non-null = also compute this node's weight gradient (conv_body's fused tile loop) and store the
+                           // block's partial tile into wg_part[row block][K][Nout]; the bucket's reduce kernel sums the row blocks
     int dgrad_nt;          // EP_BWD, fp32: most 32-column tiles of dz a wave owns per row tile (the plan's snapshot of planner option
                            // dgrad_nt; 0 = the default 4, 1 = one tile per wave as in rounds 2-3)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of

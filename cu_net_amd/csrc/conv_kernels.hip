@@ -36,7 +36,8 @@ template <int LD, int EP, int NT, bool FAST, int XBG>
 constexpr int conv_max_waves() {
     // the fp32 data gradient with the LDS-tile epilogue: 3 or 4 channel tiles per wave hold 48 / 64 accumulators next to the A chunks in
     // flight and the epilogue's pieces -- two waves per SIMD (256 VGPRs) instead of three
-    return (EP == EP_BWD && FAST && XBG == 0) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
+    // XBG = 4 (the data gradient with the node's weight gradient fused in, round 4): 64 more accumulators per wave -- two waves per SIMD
+    return (EP == EP_BWD && FAST && XBG == 4) ? 8 : (EP == EP_BWD && FAST && XBG == 0) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
 }
 
 // (the body is a device function of (arguments, block coordinates): conv_kernel runs it on one problem, conv_pair_kernel on the
@@ -62,9 +63,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     double* redbuf = reinterpret_cast<double*>(is + p.Ccat);   // [NB][2]
     // fp32 data gradient, nothing ragged: the epilogue's x loads and dz stores go through a wave-private LDS tile, one 32-column
     // tile of the slice after the other (see below).  The other instantiations keep the element-wise epilogue.
-    constexpr bool TEPI = (EP == EP_BWD && FAST && XBG == 0);
+    constexpr bool TEPI = (EP == EP_BWD && FAST && (XBG == 0 || XBG == 4));
+    // XBG = 4: the 1x1 data gradient that also computes the node's WEIGHT gradient from the dY and x tiles it has in hand (see the fused
+    // tile loop below): one pass over dY and x per node instead of two kernels on two streams
+    constexpr bool FUSEW = (TEPI && XBG == 4 && NT == 1 && LD == LD_PLAIN);
+    static_assert(XBG != 4 || FUSEW, "the fused weight gradient exists for the fast fp32 1x1 data gradient, one channel tile per wave");
     constexpr int TEPI_PITCH = 36;                             // floats per tile row (16-byte aligned rows)
-    float* tileT = reinterpret_cast<float*>(redbuf + NB * 2);  // TEPI: [waves][32][36]
+    float* tileT = reinterpret_cast<float*>(redbuf + NB * 2);  // TEPI: [waves][32][36] (FUSEW: a second tile per wave behind them)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,6 +262,139 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             }
         }
     };
+    if constexpr (FUSEW) {
+        // ---- data gradient + weight gradient of a 1x1 node in one pass (round 4) --------------------------------------------------
+        //     dz[m][c] = sum_n dY[m][n] W[n][c]  (masked)          dW[n][c] += sum_m dY[m][n] z[m][c],   z = relu(bn(x))
+        // The wave that owns row tile m0 .. m0+31 for the block's 32 columns has both operands of the second contraction in hand:
+        // the dY chunk (32 rows x 32 output channels) it is feeding to the data gradient, and the x tile of the epilogue.  Per chunk:
+        // the dY pieces also go into a wave-private LDS tile, come back TRANSPOSED (lane = output channel; 16 row values, in the row
+        // order rho(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi of the accumulator layout -- the order a contraction runs in is free), and
+        // contract with z, which the lane already holds in exactly that layout from the epilogue's column read: 16 more MFMAs into one
+        // of four persistent [32 channels x 32 columns] accumulators.  64 + 64 MFMAs per tile on two independent chains; dY and x are
+        // read once per node instead of twice, and the wgrad3 launch of the node (low-priority stream, same CUs) disappears.  At the
+        // end the block's waves add their accumulators through LDS in a fixed order and the block stores its partial tile
+        // part[bx][128][32 columns]; the bucket's reduce kernel sums the row blocks (deterministic, like wgrad3).
+        float* T2base = tileT + (size_t)nwaves * 32 * TEPI_PITCH;
+        float* T = tileT + (size_t)wave * 32 * TEPI_PITCH;
+        float* T2 = T2base + (size_t)wave * 32 * TEPI_PITCH;
+        f32x16 accW[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[t][r] = 0.f;
+        const int col = n0 + li;                               // (FAST: every column of the slice exists)
+        const float csc = sc[col], csh = sh[col], cmu = mu[col], cis = is[col];
+        GrpEnt pg0 = grp[(n0 + 4 * pc4) >> 2];
+        if (tile < ntiles) request_x(pg0, tile, xp);
+        for (; tile < ntiles; tile += tstride) {
+            // x tile -> T -> this lane's column (16 rows rho(r, hi)): z for the weight gradient, x kept for the BatchNorm reductions
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * TEPI_PITCH + 4 * pc4) = xp[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float xv[16], zv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = T[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zv[r] = fmaxf(fmaf(xv[r], csc, csh), 0.f);
+                if (p.qin_bits) zv[r] = quan_input_act(zv[r], p.qin_bits);      // the conv's input is QuanInput(relu(bn(x)))
+            }
+            const bool more = tile + tstride < ntiles;
+            if (more) request_x(pg0, tile + tstride, xp);       // the next tile's x, in flight across this tile's 128 MFMAs
+            f32x16 accD;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accD[r] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {                  // K = 128 output channels = four 32-channel chunks (launcher precondition)
+                float4 acur[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acur[q] = anext[q];
+                if (ch + 1 < 4) { ++cl; fetch(anext); }
+                else if (more) begin_tile(tile + tstride);      // the next tile's first chunk
+                // dY chunk -> T2[row li][channel 8 q + 4 hi ..]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(T2 + li * TEPI_PITCH + 8 * q + 4 * hi) = acur[q];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float4* bb = Bs + (size_t)ch * 8 * NB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = bb[(2 * q + hi) * NB + li];
+                    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].x, bv.x, accD, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].y, bv.y, accD, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].z, bv.z, accD, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q].w, bv.w, accD, 0, 0, 0);
+                }
+                float at[16];                                  // dY^T: output channel 32 ch + li of rows rho(r, hi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) at[r] = T2[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH + li];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[r], zv[r], accW[ch], 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next chunk overwrites T2)
+                __builtin_amdgcn_wave_barrier();
+            }
+            // BatchNorm / ReLU backward, first half, as the TEPI epilogue below
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fmaf(xv[r], csc, csh);
+                const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? accD[r] : 0.f;
+                s1 += dz;
+                s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
+                T[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH + li] = dz;
+            }
+            atomicAdd(&redbuf[li * 2 + 0], (double)s1);
+            atomicAdd(&redbuf[li * 2 + 1], (double)s2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = pr0 + 8 * j;
+                *reinterpret_cast<float4*>(p.y + (size_t)(tile * 32 + rr) * p.ldy + n0 + 4 * pc4) = *reinterpret_cast<const float4*>(T + rr * TEPI_PITCH + 4 * pc4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- the block's partial weight-gradient tile: waves added two at a time, in wave order, through LDS (B, the tables' neighbours
+        // and the tiles are dead: [2][4][1024] floats from the start of the dynamic LDS ... behind the tables, which the statistics
+        // epilogue below still needs -- so: in the tile area, 2 x 16 KB <= 2 tiles x 8 waves x 4.5 KB only from 4 waves up: the launcher
+        // gives a fused block at least four waves)
+        __syncthreads();
+        float* wred = tileT;                                   // [2][4 * 1024]
+        float tot[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot[k] = 0.f;
+        const int nthr = blockDim.x;
+        for (int round = 0; round < nwaves; round += 2) {
+            if (wave == round || wave == round + 1) {
+                float* dst = wred + (wave - round) * 4096;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[t * 1024 + r * 64 + lane] = accW[t][r];
+            }
+            __syncthreads();
+            const bool two = round + 1 < nwaves;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = tid + k * nthr;
+                if (e < 4096) tot[k] += two ? (wred[e] + wred[4096 + e]) : wred[e];
+            }
+            __syncthreads();
+        }
+        float* part = p.wg_part + (size_t)bx * p.K * p.Nout;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * nthr;
+            if (e < 4096) {
+                const int t = e >> 10, r = (e >> 6) & 15, l = e & 63;
+                const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                part[(size_t)n * p.Nout + n0 + (l & 31)] = tot[k];
+            }
+        }
+    }
+    if constexpr (!FUSEW)
     for (; tile < ntiles; tile += tstride) {
         if (!FAST) set_tile(tile);
         if (FAST && !EARLY_NEXT) begin_tile(tile);
@@ -1191,7 +1329,7 @@ constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 // pairs exist for the shapes the adapters take: the nothing-ragged 1x1 forward and its fp32 data gradient
 template <int LD, int EP, int NT, bool FAST, int XB>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
-    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && XB == 0))) {
+    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && (XB == 0 || XB == 4)))) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<LD, EP, NT, FAST, XB>),
@@ -1240,6 +1378,14 @@ static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t 
 
 template <int LD, int EP>
 static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* b = nullptr) {
+    if constexpr (LD == LD_PLAIN && EP == EP_BWD) {
+        if (a.wg_part != nullptr) {            // data gradient + weight gradient in one pass (conv_body's fused tile loop)
+            if (NT != 1 || !fast || a.xbf16 || (b && b->wg_part == nullptr)) return hipErrorInvalidValue;
+            return launch_inst<LD, EP, 1, true, 4>(a, grid, threads, smem, s, b);
+        }
+    } else {
+        if (a.wg_part != nullptr) return hipErrorInvalidValue;
+    }
     if (EP == EP_BWD && a.xbf16) {            // bf16 activations (and gradients): the one-tile variants only
         if (NT != 1) return hipErrorInvalidValue;
         constexpr int B = (EP == EP_BWD) ? 1 : 0;
@@ -1277,15 +1423,17 @@ struct TepiGeom {
 };
 static TepiGeom tepi_geometry(const ConvArgs& a, int c, int ntiles, int ncol32, long target, int num_cus) {
     TepiGeom g;
+    const bool fused = a.wg_part != nullptr;                          // the weight gradient fused in: one channel tile per wave (XBG = 4)
+    if (fused) c = 1;
     const int slices = (ncol32 + c - 1) / c;
     g.NT = (ncol32 + slices - 1) / slices;
     if (g.NT > 1 && (long)ntiles * slices < target) return g;        // too few wave-tiles to fill the chip
     g.gy = (ncol32 + g.NT - 1) / g.NT;
-    g.maxw = g.NT <= 2 ? CUNET_TEPI_WAVES : 8;                        // (conv_max_waves of those instantiations)
+    g.maxw = fused ? 8 : (g.NT <= 2 ? CUNET_TEPI_WAVES : 8);          // (conv_max_waves of those instantiations)
     const size_t base = conv_smem_bytes(g.NT, a.taps, a.Kpad, a.Ccat);
     for (g.bpc = 3; g.bpc >= 1; --g.bpc) {
         const int wmax = g.maxw / g.bpc < 4 ? 4 : g.maxw / g.bpc;
-        g.smem = base + (size_t)wmax * CONV_TEPI_TILE;                // + one epilogue tile per wave
+        g.smem = base + (size_t)wmax * CONV_TEPI_TILE * (fused ? 2 : 1);      // + one epilogue tile per wave (fused: + one transpose tile)
         if (g.smem <= (g.bpc == 3 ? 52 * 1024 : (g.bpc == 2 ? 80 * 1024 : CONV_LDS_BUDGET))) break;
     }
     if (g.bpc < 1) return g;
@@ -1319,6 +1467,18 @@ static TepiGeom tepi_geometry(const ConvArgs& a, int c, int ntiles, int ncol32, 
     }
     g.ok = true;
     return g;
+}
+
+// Row blocks (= partial weight-gradient tiles) a fused data + weight gradient launch of `a` will use on `num_cus` CUs (`pair`: launched with
+// its partner on half of the chip each); 0 when the shape has no fused kernel.  The runtime sizes the bucket's reduce by it.
+int conv_fused_wgrad_splits(const ConvArgs& a_in, bool pair, int num_cus_all) {
+    ConvArgs a = a_in;
+    if (a.wg_part == nullptr) a.wg_part = reinterpret_cast<float*>(sizeof(float));      // (geometry only: any non-null value)
+    const int num_cus = pair ? num_cus_all / 2 : num_cus_all;
+    bool fast = (a.K % 32 == 0) && (a.M % 32 == 0) && (a.K == a.Kpad);
+    if (!(fast && a.xbf16 == 0 && a.taps == 1 && a.K == 128 && a.Nout % 32 == 0 && a.ldy == a.Nout)) return 0;
+    const TepiGeom g = tepi_geometry(a, 1, (a.M + 31) / 32, (a.Nout + 31) / 32, 2L * 4 * num_cus, num_cus);
+    return g.ok ? g.gx : 0;
 }
 
 // Host launcher.  Picks the channel tile NT (all output channels per block when the node is big
@@ -1366,6 +1526,8 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     }
     // the fp32 data gradient with the LDS-tile epilogue (TEPI instantiations of the kernel)
     const bool tepi = epi == EP_BWD && fast && a.xbf16 == 0;
+    if (a.wg_part != nullptr && !(tepi && load == LD_PLAIN && a.taps == 1 && a.K == 128 && a.Nout % 32 == 0 && a.ldy == a.Nout))
+        return hipErrorInvalidValue;       // (the fused weight gradient: fast fp32 1x1 data gradient of a 128-output-channel node only)
     int NT = 1;
     TepiGeom tg;
     if (tepi) {

@@ -10,6 +10,7 @@ hipError_t launch_conv(const ConvArgs& a, int load, int epi, int num_cus, hipStr
 // two convolutions of one shape in ONE launch (the ahead / skip adapters of a down block, forward and data gradient);
 // hipErrorNotSupported with nothing launched when the shapes differ or the shape has no pair kernel
 hipError_t launch_conv_pair(const ConvArgs& a, const ConvArgs& b, int load, int epi, int num_cus, hipStream_t s);
+int conv_fused_wgrad_splits(const ConvArgs& a, bool pair, int num_cus);      // > 0: partial tiles a fused data + weight gradient launch writes
 hipError_t launch_wgrad(WgradArgs a, int load, int num_cus, hipStream_t s);
 bool wgrad3_supported(const WgradArgs& a);
 hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);

@@ -489,6 +489,10 @@ void Plan::layout_workspace() {
                 rows = (rows + 63) / 64 * 64;                // whole chunks of both kernels (32 fp32 / 64 bf16 pixels)
                 S = (M + rows - 1) / rows;
                 n.wg3_S = (int)S; n.wg3_rows = (int)rows; n.wg3_entry = n_wgred++;
+                // the fused data + weight gradient (fp32, conv_body's XBG = 4 loop) writes one partial tile per row block of its launch: at most
+                // two 4-wave blocks per CU over >= 4 column slices, never more than there are 32-row tiles
+                n.fuse_ok = po.fuse_wgrad ? 1 : 0;
+                n.wg3_cap = n.fuse_ok ? (int)std::max<int64_t>(S, std::min<int64_t>((M + 31) / 32, 256)) : (int)S;
                 {
                     int64_t S16 = (M + (int64_t)P * min_chunks16 - 1) / ((int64_t)P * min_chunks16);
                     S16 = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S16, smax16), S));
@@ -554,18 +558,26 @@ void Plan::layout_workspace() {
     (void)dzmax;
     const TensorInfo& h0 = tensors[head_tensors[0]];
     target_off = take(h0.rows() * h0.ld);
-    {   // partial tiles of the wgrad3 nodes: ONE region, reused bucket after bucket (the stream that runs a bucket's
-        // weight gradients also runs its reduce, so the next bucket's partials cannot overtake it)
+    {   // partial tiles of the wgrad3 nodes: TWO regions, used alternately by the buckets in the order backward visits them (round 4).
+        // The side stream that runs a bucket's weight gradients also runs its reduce, so side-stream partials never overtake a reduce;
+        // but the fused data + weight gradient of the fp32 1x1 nodes writes its partials from the CALLER's stream: with one region the
+        // next bucket's data gradients would overwrite tiles the previous bucket's reduce is still reading.  With two, the caller's
+        // stream only has to wait for the reduce of the bucket before the previous one (runtime.hip, red_ev).
         int64_t region = 0;
         for (int b = 0; b <= cfg.layer_num; ++b) {
             int64_t sum = 0;
             for (auto& n : nodes)
-                if (n.wg3_S > 0 && n.bucket == b) { n.wg3_part = sum; sum += round_up64((int64_t)n.wg3_S * wg3_numel(n), 64); }
+                if (n.wg3_S > 0 && n.bucket == b) {
+                    if (n.wg3_cap < n.wg3_S) n.wg3_cap = n.wg3_S;
+                    n.wg3_part = sum;
+                    sum += round_up64((int64_t)n.wg3_cap * wg3_numel(n), 64);
+                }
             region = std::max(region, sum);
         }
-        const int64_t base = take(region);
+        wg3_region = region;
+        const int64_t base = take(2 * region);
         for (auto& n : nodes)
-            if (n.wg3_S > 0) n.wg3_part += base;
+            if (n.wg3_S > 0) n.wg3_part += base + (bucket_position(n.bucket) & 1) * region;
     }
     n_floats_train = f;
     ws_bytes_infer = off_floats + n_floats_infer * 4;
@@ -600,7 +612,7 @@ void Plan::describe() {
         if (n.conv >= 0) o << ",\"conv\":\"" << convs[n.conv].name << "\",\"taps\":" << n.taps;
         o << ",\"head\":" << n.head << ",\"wg3\":" << n.wg3_S << ",\"wg3_rows\":" << n.wg3_rows << ",\"wg3_bf16\":" << n.wg3_S16
           << ",\"wg3_rows_bf16\":" << n.wg3_rows16 << ",\"wg3_wpi\":" << n.wg3_wpi << ",\"wg3_part\":" << n.wg3_part
-          << ",\"wg3_numel\":" << (n.wg3_S > 0 ? wg3_numel(n) : 0) << ",\"bucket\":" << n.bucket << ",\"pair\":" << n.pair << ",\"segs\":[";
+          << ",\"wg3_numel\":" << (n.wg3_S > 0 ? wg3_numel(n) : 0) << ",\"fuse_wgrad\":" << n.fuse_ok << ",\"wg3_cap\":" << n.wg3_cap << ",\"bucket\":" << n.bucket << ",\"pair\":" << n.pair << ",\"segs\":[";
         for (size_t s = 0; s < n.segs.size(); ++s)
             o << (s ? "," : "") << "{\"t\":" << n.segs[s].tensor << ",\"ups\":" << n.segs[s].ups
               << "}";

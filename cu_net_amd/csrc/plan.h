@@ -77,12 +77,15 @@ struct Node {
     // LDS-staged 1x1 weight gradient (wgrad3): pixel splits, rows per split, float offset of the [S][Cout][Ccat]
     // partial tiles inside the per-bucket partial region, index into the reduce table; wg3_S == 0: not eligible
     int wg3_S = 0, wg3_rows = 0, wg3_entry = -1;
+    int wg3_cap = 0;                      // partial tiles the node's slice of the partial region holds (>= wg3_S; the fused data + weight gradient of a
+                                          // 1x1 node writes one per ROW BLOCK of its launch, a count the runtime fixes at bind)
+    int fuse_ok = 0;                      // 1: fp32 1x1 node whose weight gradient may be computed by its data-gradient launch (planner option fuse_wgrad)
     int wg3_S16 = 0, wg3_rows16 = 0;
     int wg3_wpi = 0;                      // stem: workgroups per image (wg3_S = N * wg3_wpi, wg3_rows = output rows per workgroup)      // the same with bf16 gradient tensors: those kernels are HBM-bound, fewer and longer splits (less partial traffic) win
     int64_t wg3_part = -1;
 };
 
-struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 128, wgrad3_stem = 1, conv3x3_ring_min_rows = 512, wgrad_fork_group = 4, wgrad_fork_group_bf16 = 8, fwd_fork_min_w = 0, pair_adapters = 1, heads_on_side = 1, dgrad_nt = 4, wgrad_bf16_dma = 1; };
+struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 256, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 128, wgrad3_stem = 1, conv3x3_ring_min_rows = 512, wgrad_fork_group = 4, wgrad_fork_group_bf16 = 8, fwd_fork_min_w = 0, pair_adapters = 1, heads_on_side = 1, dgrad_nt = 4, wgrad_bf16_dma = 1, fuse_wgrad = 1; };
 PlannerOptions& planner_options();
 
 struct Plan {
@@ -90,6 +93,8 @@ struct Plan {
     PlannerOptions opts;      // snapshot of the process-wide options taken when the plan was created (cunet_set_planner_option later
                               // does not change kernel selection of a live plan)
     // elements of one wgrad3 partial tile == of the node's weight tensor
+    int64_t wg3_region = 0;               // floats of ONE partial region; there are two, used alternately by the buckets in backward's order
+    int bucket_position(int b) const { return b == cfg.layer_num ? cfg.layer_num : cfg.layer_num - 1 - b; }      // backward visits U-Nets L-1 .. 0, then the stem
     int64_t wg3_numel(const Node& n) const { return n.type == N_STEM_CONV ? (int64_t)convs[n.conv].Cout * convs[n.conv].Cin : (int64_t)convs[n.conv].Cout * n.Ccat * n.taps; }
     std::vector<int> anchors;
     std::vector<StateEntry> state;

@@ -49,6 +49,11 @@ struct cunet_plan {
     std::vector<int> pending;            // forward: tensor -> node whose side-stream result it is, or -1
     hipEvent_t join_ev = nullptr;
     int use_side = 1;
+    // fp32 1x1 nodes whose weight gradient is computed by their data-gradient launch (conv_body's fused loop; planner option fuse_wgrad):
+    // per node the number of partial tiles that launch writes (0 = the node keeps its own weight-gradient launch), fixed at bind
+    std::vector<int> fused_S;
+    hipEvent_t red_ev[2] = {nullptr, nullptr};      // "the reduce of the bucket at backward position p has run", by parity of p (two partial regions)
+    hipEvent_t bucket_ev = nullptr;                 // "every data gradient of the bucket is enqueued" (its fused partial tiles are complete behind it)
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     int prof_mode = 0;               // 0 off, 1 every class, 2 only prof_cls
     int prof_cls = -1;
@@ -140,6 +145,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(CUNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
+static int plan_fused_wgrads(cunet_plan* h);      // (defined behind the executor helpers)
+
 extern "C" {
 
 const char* cunet_last_error(void) { return g_err.c_str(); }
@@ -163,6 +170,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "heads_on_side") o.heads_on_side = value;
     else if (n == "dgrad_nt") o.dgrad_nt = value;
     else if (n == "wgrad_bf16_dma") o.wgrad_bf16_dma = value;
+    else if (n == "fuse_wgrad") o.fuse_wgrad = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -185,6 +193,8 @@ void cunet_plan_destroy(cunet_plan_t* plan) {
     for (auto e : plan->fork_ev) (void)hipEventDestroy(e);
     for (auto e : plan->done_ev) (void)hipEventDestroy(e);
     if (plan->join_ev) (void)hipEventDestroy(plan->join_ev);
+    for (auto e : plan->red_ev) if (e) (void)hipEventDestroy(e);
+    if (plan->bucket_ev) (void)hipEventDestroy(plan->bucket_ev);
     for (auto e : plan->prof_pool) (void)hipEventDestroy(e);
     for (auto& r : plan->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (plan->side) (void)hipStreamDestroy(plan->side);
@@ -285,19 +295,28 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         }
     }
     if ((int)h->runstat.size() != P.n_runstat) return fail(CUNET_ERR_STATE, "internal: running-stat table size");
+    // fused data + weight gradient (fp32 gradient tensors only): which nodes, and how many partial tiles their launch writes
+    h->fused_S.assign(P.nodes.size(), 0);
+    if (training) {
+        const int rcf = plan_fused_wgrads(h);
+        if (rcf != CUNET_OK) return rcf;
+    }
     // two copies of the reduce table: [0, n) for fp32 gradient tensors, [n, 2n) for bf16 gradient tensors, where the nodes
     // that stay on the atomic kernels in that mode (3x3 convs) have S = 0 and are skipped by the reduce
     const int nwg = P.n_wgred > 0 ? P.n_wgred : 1;
     h->wgred.assign((size_t)2 * nwg, WgReduceEntry{});
-    for (auto& n : P.nodes)
+    for (size_t k = 0; k < P.nodes.size(); ++k) {
+        const Node& n = P.nodes[k];
         if (n.wg3_S > 0) {
             for (int mode = 0; mode < 2; ++mode) {
                 WgReduceEntry& e = h->wgred[(size_t)mode * nwg + n.wg3_entry];
                 e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.numel = (int)P.wg3_numel(n);
                 e.taps = n.type == N_STEM_CONV ? 1 : n.taps; e.pad_ = 0;
                 e.S = wg3_active(P, n, mode ? 2 : 0) ? (mode ? n.wg3_S16 : n.wg3_S) : 0;
+                if (mode == 0 && h->fused_S[k] > 0) e.S = h->fused_S[k];      // one partial tile per row block of the fused launch
             }
         }
+    }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(h->ws + P.off_wgred_tab, h->wgred.data(), h->wgred.size() * sizeof(WgReduceEntry), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->ws + P.off_repack_tab, h->repack.data(), h->repack.size() * sizeof(RepackEntry), hipMemcpyHostToDevice, s));
@@ -321,6 +340,8 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         h->done_ev.resize(P.nodes.size());
         for (auto& e : h->done_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+        for (auto& e : h->red_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->bucket_ev, hipEventDisableTiming));
     }
     h->fwd_training_done = 0; h->loss_done = 0;
     return CUNET_OK;
@@ -521,7 +542,46 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.y = n.dz >= 0 ? E.wsf + n.dz : nullptr; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = E.zero + n.red;
     a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
     a.dgrad_nt = P.opts.dgrad_nt;
+    // fp32 gradient tensors: this launch also computes the node's weight gradient (partial tiles; the bucket's reduce sums them)
+    a.wg_part = (E.xmode == 0 && !h->fused_S.empty() && h->fused_S[node_index] > 0) ? E.wsf + n.wg3_part : nullptr;
     return a;
+}
+
+// Is node k's weight gradient computed by its data-gradient launch in the current pass?
+static bool wgrad_is_fused(const cunet_plan* h, int k, int xmode) { return xmode == 0 && !h->fused_S.empty() && h->fused_S[k] > 0; }
+
+// bind(): which fp32 1x1 nodes fuse their weight gradient into the data gradient, and the partial tiles each such launch writes (the row
+// blocks of its grid -- a function of the shape, the CU count and whether the node is launched as half of an adapter pair; it has to
+// fit the slice of the partial region the planner reserved, Node::wg3_cap).
+static int plan_fused_wgrads(cunet_plan* h) {
+    Plan& P = h->plan;
+    if (!P.opts.fuse_wgrad) return CUNET_OK;
+    const int saved = h->fwd_training_done;
+    h->fwd_training_done = 0;                                  // (dgrad_args of the fp32 mode)
+    Exec E(h);
+    std::vector<int> tmp(P.nodes.size(), 0);
+    h->fused_S.assign(P.nodes.size(), 0);
+    for (size_t k = 0; k < P.nodes.size(); ++k) {
+        const Node& n = P.nodes[k];
+        if (n.type != N_CONV || !n.fuse_ok || n.taps != 1 || n.head >= 0 || n.wg3_S <= 0 || !wg3_active(P, n, 0)) continue;
+        const bool first_of_pair = n.pair && k + 1 < P.nodes.size() && P.nodes[k + 1].bucket == n.bucket;
+        const bool second_of_pair = k >= 1 && P.nodes[k - 1].pair && P.nodes[k - 1].bucket == n.bucket;
+        if (second_of_pair) continue;                          // (decided with its partner)
+        ConvArgs a = dgrad_args(h, E, n, (int)k);
+        if (first_of_pair) {
+            const Node& n2 = P.nodes[k + 1];
+            const ConvArgs a2 = dgrad_args(h, E, n2, (int)k + 1);
+            const bool both = n2.fuse_ok && n2.wg3_S > 0 && n2.taps == 1 && wg3_active(P, n2, 0) && conv_pairable(a, a2);
+            const int S = both ? conv_fused_wgrad_splits(a, true, h->num_cus) : 0;
+            if (S > 0 && S <= n.wg3_cap && S <= n2.wg3_cap) tmp[k] = tmp[k + 1] = S;
+            continue;                                          // (a pair is fused together or not at all: one launch)
+        }
+        const int S = conv_fused_wgrad_splits(a, false, h->num_cus);
+        if (S > 0 && S <= n.wg3_cap) tmp[k] = S;
+    }
+    h->fused_S = tmp;
+    h->fwd_training_done = saved;
+    return CUNET_OK;
 }
 
 // the same for dgrad_bf16_kernel (bf16 gradient tensors): the bf16 backward operand
@@ -552,6 +612,10 @@ static int bwd_dgrad_pair(cunet_plan* h, int k0, int k1, hipStream_t s, int& rc_
     else e = launch_conv_pair(a0, a1, LD_PLAIN, EP_BWD, h->num_cus, s);
     if (e == hipErrorNotSupported || e == hipErrorInvalidValue) {
         prof_cancel(h, slot_);
+        if (a0.wg_part || a1.wg_part) {        // (the reduce table was sized for the pair's geometry at bind: no silent fall-back)
+            rc_out = fail(CUNET_ERR_STATE, "internal: the fused data + weight gradient of an adapter pair has no pair launch");
+            return -1;
+        }
         return 0;
     }
     PAIRCHK(e);
@@ -591,7 +655,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
                 PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
                      launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
         }
-        if (parts & BWD_WGRAD) {   // weight gradient
+        if ((parts & BWD_WGRAD) && !wgrad_is_fused(h, node_index, E.xmode)) {   // weight gradient (a fused node's came with its data gradient)
             WgradArgs w{};
             w.dy = E.grad(n.out); w.lddy = head_grad_ld(P, n, E.xmode == 2); w.Cout = c.Cout;
             w.nseg = E.fill_segs(n, w.seg); w.Ccat = n.Ccat;
@@ -1091,18 +1155,36 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
     int bucket_hi = (int)P.nodes.size();                       // nodes [k+1, bucket_hi) belong to cur_bucket
     std::vector<int> pending;                                  // nodes whose weight gradient has not been forked yet
+    // Fused data + weight gradients write their partial tiles from the CALLER's stream; the bucket's reduce runs on the side stream.
+    // (1) the reduce has to see every data gradient of its bucket: when no weight-gradient hand-over follows the bucket's last data
+    // gradient, one event does; (2) the partial region alternates between two halves by bucket position, and the caller's stream
+    // waits for the reduce of position p - 2 before position p's first fused launch.
+    const bool side_on = h->use_side && h->side;
+    bool any_fused = false;
+    for (size_t k = 0; k < P.nodes.size() && !any_fused; ++k) any_fused = wgrad_is_fused(h, (int)k, E.xmode);
+    int position = 0;
+    auto close_bucket = [&](int k_lo, int k_hi) -> int {     // everything that writes bucket `cur_bucket` (nodes [k_lo, k_hi)) has been enqueued
+        const bool had_pending = !pending.empty();
+        const int rcf = fork_wgrads(h, pending, s);
+        if (rcf != CUNET_OK) return rcf;
+        if (side_on && any_fused && !had_pending) {
+            HIPCHK(hipEventRecord(h->bucket_ev, s));
+            HIPCHK(hipStreamWaitEvent(h->side, h->bucket_ev, 0));
+        }
+        const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket], side_on ? h->side : s);
+        if (rcr != CUNET_OK) return rcr;
+        if (side_on && any_fused) HIPCHK(hipEventRecord(h->red_ev[position & 1], h->side));
+        ++position;
+        if (side_on && any_fused && position >= 2) HIPCHK(hipStreamWaitEvent(s, h->red_ev[position & 1], 0));      // (recorded at position - 2)
+        return bn_param_grads(h, k_lo, k_hi, cur_bucket, s);
+    };
     // (bf16 gradient tensors: shorter kernels, the hand-over bubble weighs more -- 8 per group measured best there, 4 in fp32)
     const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, E.xmode == 2 ? P.opts.wgrad_fork_group_bf16 : P.opts.wgrad_fork_group) : 1;
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
-            const int rcf = fork_wgrads(h, pending, s);
-            if (rcf != CUNET_OK) return rcf;
-            const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket],
-                                          (h->use_side && h->side) ? h->side : s);
-            if (rcr != CUNET_OK) return rcr;
-            const int rcg = bn_param_grads(h, k + 1, bucket_hi, cur_bucket, s);
-            if (rcg != CUNET_OK) return rcg;
+            const int rcb = close_bucket(k + 1, bucket_hi);
+            if (rcb != CUNET_OK) return rcb;
             if (on_bucket && on_bucket(cur_bucket, user) != 0) {   // the consumer joins the side stream itself (cunet_side_stream_join)
                 (void)cunet_side_stream_join(h, stream);
                 h->fwd_training_done = 0;
@@ -1124,7 +1206,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
                 const int rcg = gather_tensor_grad(h, nq.out, -1, s);
                 if (rcg != CUNET_OK) return rcg;
             }
-            if (node_has_wgrad(nq)) {          // (its d(loss)/d(out) is enqueued: the weight gradient may start once that has run)
+            if (node_has_wgrad(nq) && !wgrad_is_fused(h, q, E.xmode)) {          // (its d(loss)/d(out) is enqueued: the weight gradient may start once that has run)
                 pending.push_back(q);
                 if ((pending.size() >= group && q == (paired ? k - 1 : k)) || q == 0) {
                     const int rcf = fork_wgrads(h, pending, s);
@@ -1144,16 +1226,12 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         }
         if (paired) --k;
     }
-    {
+    if (cur_bucket >= 0) {
+        const int rcb = close_bucket(0, bucket_hi);
+        if (rcb != CUNET_OK) return rcb;
+    } else {
         const int rcf = fork_wgrads(h, pending, s);
         if (rcf != CUNET_OK) return rcf;
-        if (cur_bucket >= 0) {
-            const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket],
-                                          (h->use_side && h->side) ? h->side : s);
-            if (rcr != CUNET_OK) return rcr;
-        }
-        const int rcg = bn_param_grads(h, 0, bucket_hi, cur_bucket, s);
-        if (rcg != CUNET_OK) return rcg;
     }
     if (h->use_side && h->side) {
         HIPCHK(hipEventRecord(h->join_ev, h->side));
@@ -1275,9 +1353,10 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (n.red >= 0)
         HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * n.red, 0, (size_t)16 * n.Ccat, s));
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
+    const bool fused = wgrad_is_fused(h, node, Exec(h).xmode);      // (its weight gradient comes with the data gradient launched below)
     {
         std::vector<int> one;
-        if (node_has_wgrad(n)) one.push_back(node);
+        if (node_has_wgrad(n) && !fused) one.push_back(node);
         const int rcf = fork_wgrads(h, one, s);
         if (rcf != CUNET_OK) return rcf;
     }
@@ -1297,7 +1376,7 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
         if (rc != CUNET_OK) return rc;
     }
     if (n.wg3_S > 0) {
-        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, (int)P.wg3_numel(n), (h->use_side && h->side) ? h->side : s);
+        const int rcr = reduce_wgrad3(h, n.wg3_entry, 1, (int)P.wg3_numel(n), (h->use_side && h->side && !fused) ? h->side : s);
         if (rcr != CUNET_OK) return rcr;
     }
     if (n.type == N_CONV) {                // this node's contribution to each of its inputs, and its BN parameter gradients

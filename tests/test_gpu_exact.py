@@ -386,6 +386,57 @@ def test_bf16_weight_gradient_on_lds_dma_is_bit_identical(n):
     assert {4, 5, 6, 8, 9, 10} <= seen_ct, seen_ct
 
 
+@pytest.mark.parametrize('n', [2, 24])
+def test_fused_weight_gradient_equals_the_separate_launches(n):
+    """Planner option fuse_wgrad (default 1): the fp32 data gradient of a 1x1 node also contracts dY^T with relu(bn(x)) -- both tiles are in
+    the wave's hands -- and writes partial weight-gradient tiles that the bucket's reduce sums; 0: the node's own wgrad3 launch on the side
+    stream as in rounds 2-3.  Same state, same batch, whole backward: every parameter gradient agrees to fp32 summation order, the
+    BatchNorm / tensor gradients likewise (the data-gradient arithmetic is the same code).  N = 24 is the bench's geometry (two partial
+    regions alternating by bucket, the caller's stream waiting for the reduce two buckets back); N = 2 has single-tile waves and the
+    ragged levels that keep their own launch (4 x 4: 32 rows).  Also: the fused launches really ran (no 1x1 weight-gradient launches
+    left except the heads').  autograd wgrad + dgrad of models/cu_net.py:24,43; cu-net.py:182."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=95)
+    x, target = O.synthetic_batch(n, 68, 256, seed=96)
+    xd, td = x.cuda(), target.cuda()
+    res = {}
+    try:
+        for fuse in (0, 1):
+            set_planner_option('fuse_wgrad', fuse)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(n, 256, 256, True)
+            desc = plan.handle.describe()
+            n1x1 = sum(1 for nd in desc['nodes'] if nd['op'] == 'conv' and nd['taps'] == 1 and nd.get('head', -1) < 0)
+            assert n1x1 == 45 and sum(nd.get('fuse_wgrad', 0) for nd in desc['nodes']) == (n1x1 if fuse else 0)      # every 1x1 conv of CU-Net-2 but the two heads
+            plan.handle.profile_begin(1)
+            plan.handle.profile_reset()
+            loss = plan.stage_target(td)
+            plan.forward(xd, True, want_outputs=False)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            counts = {k: v[0] for k, v in plan.handle.profile_collect().items()}
+            plan.handle.profile_begin(0)
+            first_pool = [t['name'] for t in desc['tensors'] if t['id'] == desc['nodes'][1]['out']][0]
+            res[fuse] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True), counts)
+            del plan, net
+    finally:
+        set_planner_option('fuse_wgrad', 1)
+    (l0, g0, t0, c0), (l1, g1, t1, c1) = res[0], res[1]
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert torch.isfinite(g1).all()
+    assert float((g1 - g0).norm() / g0.norm()) <= 2e-5, float((g1 - g0).norm() / g0.norm())
+    assert float((g1 - g0).abs().max()) <= 2e-4 * float(g0.abs().max()), (float((g1 - g0).abs().max()), float(g0.abs().max()))
+    assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max())
+    assert c0['conv1x1_bwd_weight'] >= 40
+    assert c1['conv1x1_bwd_weight'] <= c0['conv1x1_bwd_weight'] - (40 if n == 2 else 45), (c0['conv1x1_bwd_weight'], c1['conv1x1_bwd_weight'])
+    assert c1['conv1x1_bwd_data'] == c0['conv1x1_bwd_data']
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16_grads'])
 def test_heads_on_the_side_stream_equal_heads_in_node_order(mode):
     """Planner option heads_on_side (default 1): in a training pass the heat-map heads run on the internal side stream -- forward

@@ -103,13 +103,29 @@ def test_weight_gradient_partial_tile_plan(cfg, n, h, w):
             assert rows % 64 == 0 and rows16 % 64 == 0
             assert S * rows >= m and (S - 1) * rows < m
             assert S16 * rows16 >= m and (S16 - 1) * rows16 < m
-            assert S <= 256 and S16 <= 96
-        per_bucket.setdefault(nd['bucket'], []).append((nd['wg3_part'], nd['wg3_part'] + S * nd['wg3_numel']))
+            assert S <= 256 and S16 <= 128
+            # the fused data + weight gradient (fp32) writes one partial tile per row block of its launch: the node's slice holds
+            # at least min(32-row tiles, 256) of them
+            assert nd['fuse_wgrad'] == (1 if nd.get('head', -1) < 0 else 0)
+            if nd['fuse_wgrad']:
+                assert nd['wg3_cap'] >= min((m + 31) // 32, 256)
+        cap = nd['wg3_cap']
+        assert cap >= S
+        per_bucket.setdefault(nd['bucket'], []).append((nd['wg3_part'], nd['wg3_part'] + cap * nd['wg3_numel']))
     assert seen >= 20 * cfg['layer_num']
+    L = cfg['layer_num']
+    lo_hi = {}
     for b, spans in per_bucket.items():
         spans.sort()
         for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
             assert a1 <= b0, (b, a0, a1, b0, b1)
+        lo_hi[b] = (spans[0][0], spans[-1][1])
+    # two partial regions, alternating in the order backward visits the buckets (U-Nets L-1 .. 0, then the stem): neighbours in that
+    # order never share floats, so the caller's stream (fused launches) only waits for the reduce two buckets back
+    order = [b for b in list(range(L - 1, -1, -1)) + [L] if b in lo_hi]
+    for b0, b1 in zip(order, order[1:]):
+        (a0, a1), (c0, c1) = lo_hi[b0], lo_hi[b1]
+        assert a1 <= c0 or c1 <= a0, (b0, b1, lo_hi[b0], lo_hi[b1])
 
 
 def test_adapter_pairs_are_marked_on_the_down_blocks():
