@@ -86,6 +86,8 @@ struct ConvArgs {
                            // (sl_gx_small > 0 selects this decoding of the 1-D grid, see conv_body)
     float* wg_part;        // EP_BWD, fp32, 1x1: non-null = also compute this node's weight gradient (conv_body's fused tile loop) and store the
                            // block's partial tile into wg_part[row block][K][Nout]; the bucket's reduce kernel sums the row blocks
+    int dgrad_prefetch;    // EP_BWD, fp32 1x1 over K = 128, one channel tile per wave: 2 = two chunks of dY in flight per wave (conv_body's PF2 loop),
+                           // else one (the plan's snapshot of planner option dgrad_prefetch)
     int dgrad_nt;          // EP_BWD, fp32: most 32-column tiles of dz a wave owns per row tile (the plan's snapshot of planner option
                            // dgrad_nt; 0 = the default 4, 1 = one tile per wave as in rounds 2-3)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of

@@ -28,6 +28,16 @@
 
 namespace cunet {
 
+#ifdef CUNET_TUNING
+// Phase clocks of the 1x1 data gradient's tile loop (tuning builds, CUNET_CONV_DBG & 512): shader cycles (s_memtime) summed over every
+// wave and tile -- [0] tiles, [1] requests + MFMA issue of a tile, [2] x pieces into the LDS tile (waits for the x loads),
+// [3] column pass (waits for the MFMA chain), [4] LDS fp64 atomics of the reductions, [5] dz pieces out (LDS read + global stores),
+// [6] block set-up (operand copy, tables) x waves, [7] whole kernel x waves.  tools/dgrad_phase_clocks.py reads them.
+__device__ unsigned long long g_conv_phase[8];
+#define CUNET_STAMP(var) const unsigned long long var = CUNET_DBG(p, 512) ? __builtin_amdgcn_s_memtime() : 0ull
+#else
+#define CUNET_STAMP(var) const unsigned long long var = 0ull; (void)var
+#endif
 constexpr int CONV_MAX_WAVES = 12;       // 3 waves per SIMD (VGPR budget 168)
 #ifndef CUNET_TEPI_WAVES
 #define CUNET_TEPI_WAVES 12              // the fp32 1x1 / 3x3 data gradient with the LDS-tile epilogue (118 VGPRs: 16 would fit; probe builds)
@@ -37,7 +47,7 @@ constexpr int conv_max_waves() {
     // the fp32 data gradient with the LDS-tile epilogue: 3 or 4 channel tiles per wave hold 48 / 64 accumulators next to the A chunks in
     // flight and the epilogue's pieces -- two waves per SIMD (256 VGPRs) instead of three
     // XBG = 4 (the data gradient with the node's weight gradient fused in, round 4): 64 more accumulators per wave -- two waves per SIMD
-    return (EP == EP_BWD && FAST && XBG == 4) ? 8 : (EP == EP_BWD && FAST && XBG == 0) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
+    return (EP == EP_BWD && FAST && XBG == 4) ? 8 : (EP == EP_BWD && FAST && (XBG == 0 || XBG == 5)) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
 }
 
 // (the body is a device function of (arguments, block coordinates): conv_kernel runs it on one problem, conv_pair_kernel on the
@@ -63,7 +73,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     double* redbuf = reinterpret_cast<double*>(is + p.Ccat);   // [NB][2]
     // fp32 data gradient, nothing ragged: the epilogue's x loads and dz stores go through a wave-private LDS tile, one 32-column
     // tile of the slice after the other (see below).  The other instantiations keep the element-wise epilogue.
-    constexpr bool TEPI = (EP == EP_BWD && FAST && (XBG == 0 || XBG == 4));
+    constexpr bool TEPI = (EP == EP_BWD && FAST && (XBG == 0 || XBG == 4 || XBG == 5));
+    // XBG = 5: the 1x1 data gradient over K = 128 with TWO 32-channel chunks of dY in flight per wave (see the PF2 tile loop below)
+    constexpr bool PF2 = (TEPI && XBG == 5 && NT == 1 && LD == LD_PLAIN);
+    static_assert(XBG != 5 || PF2, "the two-chunks-ahead loop exists for the fast fp32 1x1 data gradient, one channel tile per wave");
     // XBG = 4: the 1x1 data gradient that also computes the node's WEIGHT gradient from the dY and x tiles it has in hand (see the fused
     // tile loop below): one pass over dY and x per node instead of two kernels on two streams
     constexpr bool FUSEW = (TEPI && XBG == 4 && NT == 1 && LD == LD_PLAIN);
@@ -77,6 +90,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     const int nwaves = blockDim.x >> 6;
     const int li = lane & 31;
     const int hi = lane >> 5;
+    CUNET_STAMP(tk0);
     // block -> (row block bx of gxd, column slice by).  With xcd_gx > 0 the launch is 1-D and the slices of a row block sit on one XCD.
     int bx = bidx, by = bidy, gxd = gdimx;
     if (TEPI && p.sl_gx_small > 0) {
@@ -231,7 +245,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     constexpr bool EARLY_NEXT = NT <= 2;              // (NT = 3 / 4 hold 48 / 64 accumulators: 16 more live registers across their epilogue spill)
     const int tstride = gxd * nwaves;
     int tile = bx * nwaves + wave;
-    if (FAST && EARLY_NEXT && tile < ntiles) begin_tile(tile);
+    if (FAST && EARLY_NEXT && !PF2 && tile < ntiles) begin_tile(tile);
     // TEPI: this lane's four 16-byte pieces of a 32 x 32 tile of x (see the epilogue): piece column 4 * pc4 of the channel tile,
     // rows pr0 + 8 j.  The group entry (segment pointer, pitch, up-sample flag) of a channel tile is re-read from LDS where it is needed
     // (four registers per tile otherwise).
@@ -394,7 +408,126 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             }
         }
     }
-    if constexpr (!FUSEW)
+    if constexpr (PF2) {
+        // ---- 1x1 data gradient, K = 128 = four chunks, two chunks ahead (round 4) -------------------------------------------------------
+        // The generic loop keeps ONE chunk (4 KB per wave) on the way while the previous one is contracted: 16 MFMAs = 1024 matrix-pipe
+        // cycles (x 3 waves sharing the SIMD) to cover a round trip that takes 2 - 3 us when the rows come from HBM.  Here the four chunks
+        // of a tile have fixed register sets A0 .. A3 and chunk c + 2 is requested when chunk c is consumed -- across the tile boundary
+        // too (the next tile's chunks 0 / 1 behind this tile's chunks 2 / 3, i.e. before its epilogue's stores), without a branch around
+        // any request (the last tile re-requests its own rows), so the compiler's counted vmcnt waits stay exact.
+        float* T = tileT + (size_t)wave * 32 * TEPI_PITCH;
+        const int col = n0 + li;
+        const float csc = sc[col], csh = sh[col], cmu = mu[col], cis = is[col];
+        const GrpEnt pg0 = grp[(n0 + 4 * pc4) >> 2];
+        float4 A0[4], A1[4], A2[4], A3[4];
+        auto rowp = [&](int t) { return p.a + (size_t)(t * 32 + li) * p.lda + 4 * hi; };
+        auto req = [&](const float* rp, int c, float4 (&a)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = ldg4(rp + c * 32 + q * 8);
+        };
+        f32x16 acc1;
+        auto mfma16 = [&](int ch, const float4 (&a)[4]) {
+            const float4* bb = Bs + (size_t)ch * 8 * NB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = bb[(2 * q + hi) * NB + li];
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bv.x, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bv.y, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bv.z, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bv.w, acc1, 0, 0, 0);
+            }
+        };
+        const float* rp = rowp(tile < ntiles ? tile : 0);
+        CUNET_STAMP(tk1);
+        unsigned long long ph[5] = {0, 0, 0, 0, 0};
+        unsigned ntl_done = 0;
+        if (tile < ntiles) { req(rp, 0, A0); req(rp, 1, A1); }
+        __builtin_amdgcn_sched_barrier(0);
+        for (; tile < ntiles; tile += tstride) {
+            CUNET_STAMP(ts0);
+            request_x(pg0, tile, xp);
+            const float* rpn = rowp(tile + tstride < ntiles ? tile + tstride : tile);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+            // (sched_barrier: left alone the scheduler sinks each request next to its first use -- two MFMA groups of cover instead of 32)
+            req(rp, 2, A2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(0, A0);
+            __builtin_amdgcn_sched_barrier(0);
+            req(rp, 3, A3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(1, A1);
+            __builtin_amdgcn_sched_barrier(0);
+            req(rpn, 0, A0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(2, A2);
+            __builtin_amdgcn_sched_barrier(0);
+            req(rpn, 1, A1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(3, A3);
+            __builtin_amdgcn_sched_barrier(0);
+            rp = rpn;
+            CUNET_STAMP(ts1);
+            // the TEPI epilogue of one channel tile (see below)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * TEPI_PITCH + 4 * pc4) = xp[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            CUNET_STAMP(ts2);
+            float s1 = 0.f, s2 = 0.f;
+            float* tcol = T + li;
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fmaf(xv[r], csc, csh);
+                const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc1[r] : 0.f;
+                s1 += dz;
+                s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
+                xv[r] = dz;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * TEPI_PITCH] = xv[r];
+            CUNET_STAMP(ts3);
+            atomicAdd(&redbuf[li * 2 + 0], (double)s1);
+            atomicAdd(&redbuf[li * 2 + 1], (double)s2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            CUNET_STAMP(ts4);
+            if (CUNET_DBG(p, 1024)) {                          // tuning builds: the dz pieces as non-temporal stores
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = pr0 + 8 * j;
+                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4v*>(T + rr * TEPI_PITCH + 4 * pc4),
+                                                reinterpret_cast<f32x4v*>(p.y + (size_t)(tile * 32 + rr) * p.ldy + n0 + 4 * pc4));
+                }
+            } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = pr0 + 8 * j;
+                *reinterpret_cast<float4*>(p.y + (size_t)(tile * 32 + rr) * p.ldy + n0 + 4 * pc4) = *reinterpret_cast<const float4*>(T + rr * TEPI_PITCH + 4 * pc4);
+            }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+            __builtin_amdgcn_wave_barrier();
+            CUNET_STAMP(ts5);
+            ph[0] += ts1 - ts0; ph[1] += ts2 - ts1; ph[2] += ts3 - ts2; ph[3] += ts4 - ts3; ph[4] += ts5 - ts4;
+            ++ntl_done;
+        }
+        (void)ntl_done;
+#ifdef CUNET_TUNING
+        if (CUNET_DBG(p, 512) && lane == 0) {
+            const unsigned long long te = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_conv_phase[0], (unsigned long long)ntl_done);
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
+            atomicAdd(&g_conv_phase[6], tk1 - tk0);
+            atomicAdd(&g_conv_phase[7], te - tk0);
+        }
+#endif
+    }
+    if constexpr (!FUSEW && !PF2)
     for (; tile < ntiles; tile += tstride) {
         if (!FAST) set_tile(tile);
         if (FAST && !EARLY_NEXT) begin_tile(tile);
@@ -1329,7 +1462,7 @@ constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 // pairs exist for the shapes the adapters take: the nothing-ragged 1x1 forward and its fp32 data gradient
 template <int LD, int EP, int NT, bool FAST, int XB>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
-    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && (XB == 0 || XB == 4)))) {
+    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && (XB == 0 || XB == 4 || XB == 5)))) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<LD, EP, NT, FAST, XB>),
@@ -1383,6 +1516,9 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
             if (NT != 1 || !fast || a.xbf16 || (b && b->wg_part == nullptr)) return hipErrorInvalidValue;
             return launch_inst<LD, EP, 1, true, 4>(a, grid, threads, smem, s, b);
         }
+        // one channel tile per wave over K = 128 (every bottleneck / adapter): two chunks of dY in flight (planner option dgrad_prefetch)
+        if (NT == 1 && fast && !a.xbf16 && a.dgrad_prefetch >= 2 && a.taps == 1 && a.K == 128 && a.Kpad == 128 && a.Nout % 32 == 0)
+            return launch_inst<LD, EP, 1, true, 5>(a, grid, threads, smem, s, b);
     } else {
         if (a.wg_part != nullptr) return hipErrorInvalidValue;
     }
@@ -1603,5 +1739,17 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
 #undef CUNET_CASE
     return hipErrorInvalidValue;
 }
+
+#ifdef CUNET_TUNING
+// tuning builds: read (and clear) the phase clocks
+extern "C" int cunet_tuning_conv_phase(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_phase), sizeof(g_conv_phase)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace cunet

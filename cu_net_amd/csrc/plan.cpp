@@ -506,7 +506,7 @@ void Plan::layout_workspace() {
         }
     }
     off_wgred_tab = off;
-    off += round_up64((int64_t)2 * (n_wgred > 0 ? n_wgred : 1) * (int64_t)sizeof(WgReduceEntry), 256);      // one copy per gradient-storage mode
+    off += round_up64((int64_t)3 * (n_wgred > 0 ? n_wgred : 1) * (int64_t)sizeof(WgReduceEntry), 256);      // one copy per storage mode (runtime.hip, cunet_bind)
     // QuanInput sites (3x3 convs and heads): bit-mask storage for the AND-popcount forward of the quantised-input mode
     {
         int64_t words = 0;

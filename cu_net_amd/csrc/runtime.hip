@@ -171,6 +171,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "dgrad_nt") o.dgrad_nt = value;
     else if (n == "wgrad_bf16_dma") o.wgrad_bf16_dma = value;
     else if (n == "fuse_wgrad") o.fuse_wgrad = value;
+    else if (n == "dgrad_prefetch") o.dgrad_prefetch = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -301,18 +302,19 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
         const int rcf = plan_fused_wgrads(h);
         if (rcf != CUNET_OK) return rcf;
     }
-    // two copies of the reduce table: [0, n) for fp32 gradient tensors, [n, 2n) for bf16 gradient tensors, where the nodes
-    // that stay on the atomic kernels in that mode (3x3 convs) have S = 0 and are skipped by the reduce
+    // three copies of the reduce table: [0, n) fp32 activations and gradient tensors, [n, 2n) bf16 gradient tensors -- where the nodes that
+    // stay on the atomic kernels in that mode (3x3 convs) have S = 0 and are skipped by the reduce --, [2n, 3n) bf16 activations with fp32
+    // gradient tensors (the fp32 split counts; only copy 0 knows the fused launches' partial-tile counts)
     const int nwg = P.n_wgred > 0 ? P.n_wgred : 1;
-    h->wgred.assign((size_t)2 * nwg, WgReduceEntry{});
+    h->wgred.assign((size_t)3 * nwg, WgReduceEntry{});
     for (size_t k = 0; k < P.nodes.size(); ++k) {
         const Node& n = P.nodes[k];
         if (n.wg3_S > 0) {
-            for (int mode = 0; mode < 2; ++mode) {
+            for (int mode = 0; mode < 3; ++mode) {
                 WgReduceEntry& e = h->wgred[(size_t)mode * nwg + n.wg3_entry];
                 e.part = n.wg3_part; e.dst = P.convs[n.conv].w; e.numel = (int)P.wg3_numel(n);
                 e.taps = n.type == N_STEM_CONV ? 1 : n.taps; e.pad_ = 0;
-                e.S = wg3_active(P, n, mode ? 2 : 0) ? (mode ? n.wg3_S16 : n.wg3_S) : 0;
+                e.S = wg3_active(P, n, mode == 1 ? 2 : (mode == 2 ? 1 : 0)) ? (mode == 1 ? n.wg3_S16 : n.wg3_S) : 0;
                 if (mode == 0 && h->fused_S[k] > 0) e.S = h->fused_S[k];      // one partial tile per row block of the fused launch
             }
         }
@@ -513,7 +515,7 @@ static int reduce_wgrad3(cunet_plan* h, int first, int count, int max_numel, hip
     if (count <= 0) return CUNET_OK;
     Plan& P = h->plan;
     const int nwg = P.n_wgred > 0 ? P.n_wgred : 1;
-    const WgReduceEntry* tab = reinterpret_cast<const WgReduceEntry*>(h->ws + P.off_wgred_tab) + (E.xmode == 2 ? nwg : 0) + first;
+    const WgReduceEntry* tab = reinterpret_cast<const WgReduceEntry*>(h->ws + P.off_wgred_tab) + (E.xmode == 2 ? nwg : (E.xmode == 1 ? 2 * nwg : 0)) + first;
     PROF_ON(s, PC_MISC, 0.0, 0.0, launch_wgrad_reduce(tab, count, max_numel, E.wsf, h->grads, s));
     return CUNET_OK;
 }
@@ -542,6 +544,7 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.y = n.dz >= 0 ? E.wsf + n.dz : nullptr; a.ldy = n.Ccat; a.Nout = n.Ccat; a.ystats = E.zero + n.red;
     a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
     a.dgrad_nt = P.opts.dgrad_nt;
+    a.dgrad_prefetch = P.opts.dgrad_prefetch;
     // fp32 gradient tensors: this launch also computes the node's weight gradient (partial tiles; the bucket's reduce sums them)
     a.wg_part = (E.xmode == 0 && !h->fused_S.empty() && h->fused_S[node_index] > 0) ? E.wsf + n.wg3_part : nullptr;
     return a;

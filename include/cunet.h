@@ -264,6 +264,12 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
  *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
+ *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 (default) =
+ *                        two 32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 = one (rounds 1-3)
+ *   "fuse_wgrad"         1: the fp32 data gradient of a 1x1 node (128 output channels) also computes the node's weight gradient from the dY
+ *                        and x tiles it holds and writes one partial tile per row block (summed by the bucket's reduce): one pass over dY
+ *                        and x per node, no wgrad launch on the side stream.  0 (default): separate launches -- measured 4.8 % faster in
+ *                        the overlapped CU-Net-2 step on MI355X (the fused kernel is 1.9 % faster when nothing overlaps)
  *   "wgrad_bf16_dma"     1 (default): the 1x1 weight gradient of the bf16 storage mode streams dY and x into an LDS ring by LDS-DMA
  *                        (global_load_lds) and takes its MFMA operands with the LDS transpose read where every pixel range is whole
  *                        32-pixel slots; 0: always the register-staged kernel of rounds 2-3 (bit-identical results).  Unlike the other

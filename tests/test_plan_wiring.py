@@ -70,9 +70,13 @@ def test_weight_gradient_partial_tile_plan(cfg, n, h, w):
     the bf16 split policy never needs more partials than the fp32 one (they share the region), 1x1 ranges are whole chunks of both
     kernels, the bf16 3x3 ring walks rows in pairs, the stem's workgroups cover every output row of an image and fit the LDS, and the
     partial regions of a gradient bucket do not overlap (the region itself is reused bucket after bucket)."""
-    from cu_net_amd._lib import PlanHandle
-    ph = PlanHandle(cfg['neck_size'], cfg['growth_rate'], cfg['init_chan_num'], cfg['class_num'], cfg['layer_num'], cfg['order'],
-                    cfg['loss_num'], n, h, w)
+    from cu_net_amd._lib import PlanHandle, set_planner_option
+    set_planner_option('fuse_wgrad', 1)              # (the option that asks for the larger partial slices; default 0)
+    try:
+        ph = PlanHandle(cfg['neck_size'], cfg['growth_rate'], cfg['init_chan_num'], cfg['class_num'], cfg['layer_num'], cfg['order'],
+                        cfg['loss_num'], n, h, w)
+    finally:
+        set_planner_option('fuse_wgrad', 0)
     d = ph.describe()
     T = d['tensors']
     per_bucket = {}
