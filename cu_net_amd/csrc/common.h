@@ -86,6 +86,8 @@ struct ConvArgs {
                            // (sl_gx_small > 0 selects this decoding of the 1-D grid, see conv_body)
     float* wg_part;        // EP_BWD, fp32, 1x1: non-null = also compute this node's weight gradient (conv_body's fused tile loop) and store the
                            // block's partial tile into wg_part[row block][K][Nout]; the bucket's reduce kernel sums the row blocks
+    int dgrad_rows;        // EP_BWD, fp32 1x1 over K = 128: > 0 = launches with at least this many 32-row tiles run dgrad1x1_rows_kernel (all columns
+                           // of a row tile in one workgroup, dY staged once by LDS-DMA); 0 = always the column-sliced kernel (planner option dgrad_rows)
     int dgrad_prefetch;    // EP_BWD, fp32 1x1 over K = 128, one channel tile per wave: 2 = two chunks of dY in flight per wave (conv_body's PF2 loop),
                            // else one (the plan's snapshot of planner option dgrad_prefetch)
     int dgrad_nt;          // EP_BWD, fp32: most 32-column tiles of dz a wave owns per row tile (the plan's snapshot of planner option

@@ -952,6 +952,192 @@ __global__ __launch_bounds__((conv_max_waves<LD, EP, NT, FAST, XBG>() * 64)) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1x1 data gradient with dY staged ONCE per row tile (round 4): dz[M][Ccat] = dY[M][128] . W[128][Ccat], masked, + BatchNorm reductions.
+// The weight-stationary kernel above cuts the Ccat output channels into 32-column slices on different workgroups: every slice re-reads
+// the whole dY (5 - 10 times per node, from L2), and its phase clocks show a wave waiting ~40 k cycles per tile for 4 k cycles of MFMAs
+// -- on requests landing and on stores being ACCEPTED, i.e. on the CU's vector-memory path (deeper prefetch, other request shapes and
+// more accumulator chains per wave all measured +-1 %).  What goes through that path is what counts, so here
+//   * a workgroup owns ALL Ccat channels of its row tiles: wave w computes columns 32 w .. 32 w + 31 (Ccat / 32 = 4 .. 10 waves);
+//   * its slice of the weights (128 x 32) lives in 64 REGISTERS per lane for the whole launch -- no LDS operand, no per-chunk B reads;
+//   * the 32 x 128 dY tile goes from HBM into an LDS ring ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4, no VGPRs), in MFMA
+//     fragment order: request q of a tile = the 64 16-byte pieces (row l & 31, piece 2 q + (l >> 5)) step q of the contraction wants, so
+//     every wave takes its A fragment with ONE conflict-free ds_read_b128 at slot + 1024 q + 16 l.  Three slots: the requests of tile
+//     t + 2 are issued when tile t starts, one barrier per tile;
+//   * epilogue per wave as in the kernel above (x pieces -> wave-private LDS tile -> column pass -> dz pieces out, fp64 sums in LDS).
+// dY, x and dz cross the CU's memory path once each: 1/3 ... 1/2 of the bytes the sliced kernel moves.
+constexpr int DR_SLOT = 32 * 128 * 4;              // bytes of one dY tile
+constexpr int DR_SLOTS = 3;
+constexpr int DR_MAX_WAVES = 10;
+
+__device__ __forceinline__ void dr_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(DR_MAX_WAVES * 64) void dgrad1x1_rows_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;                // = Ccat / 32
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    // LDS: [ring 3 x 16 KB][T tiles: waves x 32 x 36 floats][group table][sc sh mu is][fp64 sums 2 x Ccat]
+    char* ring = smem;
+    float* tileT = reinterpret_cast<float*>(smem + DR_SLOTS * DR_SLOT);
+    GrpEnt* grp = reinterpret_cast<GrpEnt*>(tileT + (size_t)nwaves * 32 * 36);
+    float* sc = reinterpret_cast<float*>(grp + (p.Ccat >> 2));
+    float* sh = sc + p.Ccat;
+    float* mu = sh + p.Ccat;
+    float* is = mu + p.Ccat;
+    double* redbuf = reinterpret_cast<double*>(is + p.Ccat);      // [Ccat][2]
+    const unsigned ring0 = (unsigned)(size_t)ring;
+
+    setup_concat<true, 0>(p, grp, sc, sh, mu, is);
+    for (int i = tid; i < 2 * p.Ccat; i += blockDim.x) redbuf[i] = 0.0;
+
+    // this wave's 128 x 32 slice of the backward operand [k / 4][Npad][4]: b[q] = (k = 8 q + 4 hi + 0..3, column 32 wave + li)
+    float4 b[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = ldg4(p.wB + ((size_t)(2 * q + hi) * p.Npad + wave * 32 + li) * 4);
+
+    const int ntiles = p.M >> 5;
+    const int gstride = gridDim.x;
+    int tile = blockIdx.x;
+    // LDS-DMA requests of a tile: q = wave, wave + nwaves, ... < 16
+    auto issue = [&](int t, int slot) {
+        const float* src = p.a + (size_t)(t * 32 + li) * p.lda + 4 * hi;
+        if (CUNET_DBG(p, 2048)) return;                // tuning builds: no dY requests (stale LDS contents: timing only)
+        for (int q = wave; q < 16; q += nwaves)
+            dr_dma16(src + 8 * q, __builtin_amdgcn_readfirstlane(ring0 + (unsigned)(slot * DR_SLOT + q * 1024)));
+    };
+    if (tile < ntiles) issue(tile, 0);
+    if (tile + gstride < ntiles) issue(tile + gstride, 1);
+    __syncthreads();                                   // tables visible
+
+    const int col = wave * 32 + li;
+    const float csc = sc[col], csh = sh[col], cmu = mu[col], cis = is[col];
+    const int pc4 = lane & 7, pr0 = lane >> 3;        // this lane's 16-byte pieces of a 32 x 32 tile: column piece, first row (+ 8 j)
+    const GrpEnt pg = grp[(wave * 32 + 4 * pc4) >> 2];
+    const int HW = p.H * p.W;
+    float4 xp[4], xn[4];
+    auto request_x = [&](int t, float4 (&o)[4]) {
+        if (CUNET_DBG(p, 8)) { o[0] = o[1] = o[2] = o[3] = make_float4(1.f, 1.f, 1.f, 1.f); return; }      // tuning builds: no x loads
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = t * 32 + pr0 + 8 * j;
+            int row = mm;
+            if (p.any_ups && pg.ups) {                 // (a branch around arithmetic only)
+                int ni, yy, xx;
+                if (p.wshift >= 0) { ni = mm >> p.hwshift; const int rm = mm & (HW - 1); yy = rm >> p.wshift; xx = rm & (p.W - 1); }
+                else { ni = mm / HW; const int rm = mm - ni * HW; yy = rm / p.W; xx = rm - yy * p.W; }
+                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            }
+            o[j] = ldg4(pg.ptr + (size_t)row * pg.ld);
+        }
+    };
+    if (tile < ntiles) request_x(tile, xp);
+    float* T = tileT + (size_t)wave * 32 * 36;
+    int slot = 0;
+    for (; tile < ntiles; tile += gstride) {
+        // everything this wave has requested (its pieces of this tile's dY, issued a whole tile ago; this tile's x) has landed ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // ... and so have the other waves' pieces; the slot of tile - 1 is free
+        const int nslot = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3
+        if (tile + 2 * gstride < ntiles) issue(tile + 2 * gstride, nslot);
+        const bool more = tile + gstride < ntiles;
+        request_x(more ? tile + gstride : tile, xn);    // next tile's x: in flight across this tile (no branch around a request)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float4* A = reinterpret_cast<const float4*>(ring + slot * DR_SLOT) + lane;
+        float4 a_cur = A[0];
+        if (!CUNET_DBG(p, 4))                          // tuning builds: no contraction
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 a_nxt = A[64 * (q + 1 < 16 ? q + 1 : q)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[q].w, acc, 0, 0, 0);
+            a_cur = a_nxt;
+        }
+        // BatchNorm / ReLU backward, first half (as conv_body's LDS-tile epilogue)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * 36 + 4 * pc4) = xp[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float s1 = 0.f, s2 = 0.f;
+        float* tcol = T + li;
+        float xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float z = fmaf(xv[r], csc, csh);
+            const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[r] : 0.f;      // ReLU mask (+ QuanInput's straight-through mask)
+            s1 += dz;
+            s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
+            xv[r] = dz;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36] = xv[r];
+        atomicAdd(&redbuf[col * 2 + 0], (double)s1);
+        atomicAdd(&redbuf[col * 2 + 1], (double)s2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!CUNET_DBG(p, 2))                          // tuning builds: no dz stores
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = pr0 + 8 * j;
+            *reinterpret_cast<float4*>(p.y + (size_t)(tile * 32 + rr) * p.ldy + wave * 32 + 4 * pc4) = *reinterpret_cast<const float4*>(T + rr * 36 + 4 * pc4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = xn[j];
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.ystats != nullptr && tid < p.Ccat) {
+        atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
+        atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
+    }
+}
+
+static bool dgrad1x1_rows_supported(const ConvArgs& a) {
+    if (a.taps != 1 || a.K != 128 || a.Kpad != 128 || a.xbf16 || a.M % 32 || a.Nout % 32 || a.Nout != a.Ccat || a.ldy != a.Nout || a.lda % 4 ||
+        a.Nout / 32 < 4 || a.Nout / 32 > DR_MAX_WAVES || a.wg_part != nullptr || a.mse_tgt != nullptr)
+        return false;
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % 32 || a.seg[i].ld % 4) return false;
+    return true;
+}
+
+static hipError_t launch_dgrad1x1_rows(const ConvArgs& a_in, int num_cus, hipStream_t s) {
+    ConvArgs a = a_in;
+    set_geometry_shifts(a);
+    static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: work-skipping timing experiments
+    a.dbg = dbg;
+    const int nw = a.Nout / 32;
+    const size_t smem = (size_t)DR_SLOTS * DR_SLOT + (size_t)nw * 32 * 36 * 4 + (size_t)(a.Ccat / 4) * sizeof(GrpEnt) + (size_t)a.Ccat * 16 + (size_t)a.Ccat * 16;
+    const int ntiles = a.M / 32;
+    const int bpc = smem <= 80 * 1024 && nw <= 6 ? 2 : 1;         // (12 waves per CU at most: three per SIMD at the kernel's register budget)
+    int grid = bpc * num_cus;
+    if (grid > ntiles) grid = ntiles;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad1x1_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dgrad1x1_rows_kernel, dim3(grid), dim3(nw * 64), smem, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 forward, tap-split (models/cu_net.py:45-48,62: norm2 -> relu2 -> conv2, 128 -> 32 channels).
 // The weight-stationary kernel above walks all 9 taps x K/32 chunks in ONE wave: 36 dependent
 // load -> MFMA steps, ~40 us whatever the resolution (14 of the 18 3x3 launches of a CU-Net-2 step sit on
@@ -1627,6 +1813,8 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
 // a_in and b_in in one launch (see conv_pair_kernel); hipErrorNotSupported (and nothing launched): the caller launches them one by one
 hipError_t launch_conv_pair(const ConvArgs& a_in, const ConvArgs& b_in, int load, int epi, int num_cus, hipStream_t s) {
     if (!conv_pairable(a_in, b_in) || a_in.taps != 1) return hipErrorNotSupported;
+    // (the row-tile data gradient gives every node the whole chip: no pair launch)
+    if (load == LD_PLAIN && epi == EP_BWD && a_in.dgrad_rows && dgrad1x1_rows_supported(a_in)) return hipErrorNotSupported;
     return launch_conv_impl(a_in, &b_in, load, epi, num_cus, s);
 }
 
@@ -1635,6 +1823,10 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 32);      // 3x3 forward on the LDS row ring at this width and above (64 and 32: +0.4 % over 64 only)
     if (!b_in && load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= (a_in.ring_min_rows > 0 ? a_in.ring_min_rows : 512))
         return launch_conv3x3_ring(a_in, num_cus, s);
+    // fp32 1x1 data gradient of a 128-output-channel node with 128 ... 320 input channels: every column of a row tile in one workgroup, dY
+    // staged once (dgrad1x1_rows_kernel); planner option dgrad_rows = the least number of 32-row tiles per launch that takes it
+    if (!b_in && load == LD_PLAIN && epi == EP_BWD && a_in.dgrad_rows > 0 && dgrad1x1_rows_supported(a_in) && a_in.M / 32 >= a_in.dgrad_rows)
+        return launch_dgrad1x1_rows(a_in, num_cus, s);
     static const int use_sk = tune_int("CUNET_CONV_SPLITK", 1);
     // (a pair: one round of one-tile blocks for both problems together)
     if (use_sk && load == LD_SEG && epi == EP_FWD && conv1x1_splitk_supported(a_in, num_cus)) return launch_conv1x1_splitk(a_in, s, b_in);

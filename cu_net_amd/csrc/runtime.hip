@@ -172,6 +172,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "wgrad_bf16_dma") o.wgrad_bf16_dma = value;
     else if (n == "fuse_wgrad") o.fuse_wgrad = value;
     else if (n == "dgrad_prefetch") o.dgrad_prefetch = value;
+    else if (n == "dgrad_rows") o.dgrad_rows = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -545,6 +546,7 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
     a.dgrad_nt = P.opts.dgrad_nt;
     a.dgrad_prefetch = P.opts.dgrad_prefetch;
+    a.dgrad_rows = P.opts.dgrad_rows;
     // fp32 gradient tensors: this launch also computes the node's weight gradient (partial tiles; the bucket's reduce sums them)
     a.wg_part = (E.xmode == 0 && !h->fused_S.empty() && h->fused_S[node_index] > 0) ? E.wsf + n.wg3_part : nullptr;
     return a;

@@ -264,8 +264,13 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
  *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
- *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 (default) =
- *                        two 32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 = one (rounds 1-3)
+ *   "dgrad_rows"         fp32 1x1 data gradient of a 128-output-channel node: launches with at least this many 32-row tiles run the row-tile
+ *                        kernel -- every input channel of a row tile in one workgroup, weights in registers, dY staged once per workgroup by
+ *                        LDS-DMA instead of re-read by every 32-channel slice; 0 (default) = never: measured equal alone (1.60 vs 1.57 ms per
+ *                        CU-Net-2 step) and 2.3 % slower in the step, where its nodes cannot share a launch as adapter pairs do
+ *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
+ *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
+ *                        measured equal (3504 vs 3491 img/s)
  *   "fuse_wgrad"         1: the fp32 data gradient of a 1x1 node (128 output channels) also computes the node's weight gradient from the dY
  *                        and x tiles it holds and writes one partial tile per row block (summed by the bucket's reduce): one pass over dY
  *                        and x per node, no wgrad launch on the side stream.  0 (default): separate launches -- measured 4.8 % faster in

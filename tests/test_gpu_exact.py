@@ -311,8 +311,9 @@ def test_dgrad_channel_tiles_per_wave_agree():
     xd, td = x.cuda(), target.cuda()
     res = {}
     try:
-        for opt in (1, 12, 13, 14, 4):
-            set_planner_option('dgrad_nt', opt)
+        for opt in (1, 12, 13, 14, 4, 'pf2'):
+            set_planner_option('dgrad_nt', 1 if opt == 'pf2' else opt)
+            set_planner_option('dgrad_prefetch', 2 if opt == 'pf2' else 1)      # ('pf2': two chunks of dY in flight per wave, conv_body's PF2 loop)
             net = cu_net_amd.create_cu_net(**cfg)
             net.load_state_dict(st)
             net = net.cuda().train()
@@ -327,9 +328,10 @@ def test_dgrad_channel_tiles_per_wave_agree():
             del plan, net
     finally:
         set_planner_option('dgrad_nt', 4)
+        set_planner_option('dgrad_prefetch', 1)
     l0, g0, t0 = res[1]
     assert torch.isfinite(g0).all() and float(g0.norm()) > 0
-    for opt in (12, 13, 14, 4):
+    for opt in (12, 13, 14, 4, 'pf2'):
         l1, g1, t1 = res[opt]
         assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)      # the forward does not depend on the option (fp64 atomics order only)
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))
@@ -435,6 +437,47 @@ def test_fused_weight_gradient_equals_the_separate_launches(n):
     assert c0['conv1x1_bwd_weight'] >= 40
     assert c1['conv1x1_bwd_weight'] <= c0['conv1x1_bwd_weight'] - (40 if n == 2 else 45), (c0['conv1x1_bwd_weight'], c1['conv1x1_bwd_weight'])
     assert c1['conv1x1_bwd_data'] == c0['conv1x1_bwd_data']
+
+
+def test_row_tile_data_gradient_agrees_with_the_sliced_kernel():
+    """dgrad1x1_rows_kernel (planner option dgrad_rows; round 4: all input channels of a row tile in one workgroup, weights in registers, dY
+    staged once per workgroup by LDS-DMA in MFMA fragment order) against the column-sliced kernel (dgrad_rows = 0) on BASELINE config 2's
+    shapes, whole backward: the same k-ordered MFMA chain per element, so dz is bit-identical and everything downstream agrees to the
+    order of the fp64 BatchNorm reductions.  dgrad_rows = 1 sends EVERY eligible launch to the new kernel (grids smaller than the chip,
+    one tile per workgroup), 512 only the 64 x 64 and 32 x 32 levels (the ring wraps, several tiles per workgroup).  The shipped default
+    is 0: the kernel measured equal alone and slower in the step."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=97)
+    x, target = O.synthetic_batch(24, 68, 256, seed=98)
+    xd, td = x.cuda(), target.cuda()
+    res = {}
+    try:
+        for opt in (0, 1, 512):
+            set_planner_option('dgrad_rows', opt)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(24, 256, 256, True)
+            loss = plan.stage_target(td)
+            plan.forward(xd, True, want_outputs=False)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            d = plan.handle.describe()
+            first_pool = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][1]['out']][0]
+            res[opt] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True))
+            del plan, net
+    finally:
+        set_planner_option('dgrad_rows', 0)
+    l0, g0, t0 = res[0]
+    assert torch.isfinite(g0).all() and float(g0.norm()) > 0
+    for opt in (1, 512):
+        l1, g1, t1 = res[opt]
+        assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)
+        assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))
+        assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max()), (opt, float((t1 - t0).abs().max()), float(t0.abs().max()))
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16_grads'])
