@@ -147,7 +147,7 @@ def load_mfma_busy(cls, workload_key):
 
 def load_traffic(cls, workload_key):
     """HBM bytes per launch of a kernel class from the newest committed PMC passes of THIS workload
-    (rocprofv3 --pmc cannot run inside this process): profiles/rNN_traffic.json, produced by tools/profile_round.sh +
+    (rocprofv3 --pmc cannot run inside this process): profiles/rNN_traffic.json, produced by tools/profile_r04.sh +
     tools/pmc_traffic.py.  Returns (bytes or None, source string)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):

@@ -249,6 +249,9 @@ hipError_t launch_pool_bf16(const void* x, void* y, double* ystats, int N, int H
 // Seg::x / ConvArgs::y carry bf16 pointers here (typed float* in the shared argument struct); ld in elements.
 // Requirements (checked by the launcher): every segment and K a multiple of 32 channels, M a multiple of 32 rows.
 constexpr int B16_MAX_WAVES = 16;        // <= 128 VGPRs per lane (the widest variant uses 118)
+// (four channel tiles: 64 accumulators -- at 128 registers the kernel spilled 5 (8 with nine taps), reloaded inside the tile loop; twelve
+// waves = 168 registers.  At batch 24 the launcher gives those blocks twelve waves anyway: 3072 tiles on 256 one-block CUs.)
+constexpr int b16_max_waves(int nt) { return nt == 4 ? 12 : B16_MAX_WAVES; }
 
 template <int TAPS, int NT, int OUTF32>
 __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
@@ -489,12 +492,12 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& p, const int bidx
 }
 
 template <int TAPS, int NT, int OUTF32>
-__global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(b16_max_waves(NT) * 64) void conv_bf16_kernel(const ConvArgs p) {
     conv_bf16_body<TAPS, NT, OUTF32>(p, blockIdx.x, blockIdx.y, gridDim.x);
 }
 // two problems of one shape in one launch (the ahead / skip adapters: see conv_pair_kernel)
 template <int TAPS, int NT, int OUTF32>
-__global__ __launch_bounds__(B16_MAX_WAVES * 64) void conv_bf16_pair_kernel(const ConvPair q) {
+__global__ __launch_bounds__(b16_max_waves(NT) * 64) void conv_bf16_pair_kernel(const ConvPair q) {
     conv_bf16_body<TAPS, NT, OUTF32>(q.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
 }
 
@@ -1369,7 +1372,7 @@ static hipError_t launch_conv_bf16_impl(const ConvArgs& a, const ConvArgs* pb, i
     const int blocks_per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : 3);
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
-    if (waves > B16_MAX_WAVES / blocks_per_cu) waves = B16_MAX_WAVES / blocks_per_cu;
+    if (waves > b16_max_waves(NT) / blocks_per_cu) waves = b16_max_waves(NT) / blocks_per_cu;
     if (waves < 1) waves = 1;
     int gx = (ntiles + waves - 1) / waves;
     if (gx > max_blocks_x) gx = max_blocks_x;

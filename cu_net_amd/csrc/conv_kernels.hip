@@ -422,11 +422,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
         float4 A0[4], A1[4], A2[4], A3[4];
         auto rowp = [&](int t) { return p.a + (size_t)(t * 32 + li) * p.lda + 4 * hi; };
         auto req = [&](const float* rp, int c, float4 (&a)[4]) {
+            if (CUNET_DBG(p, 2048)) return;                // tuning builds: no dY requests (timing only)
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = ldg4(rp + c * 32 + q * 8);
         };
         f32x16 acc1;
         auto mfma16 = [&](int ch, const float4 (&a)[4]) {
+            if (CUNET_DBG(p, 4)) return;                   // tuning builds: no contraction
             const float4* bb = Bs + (size_t)ch * 8 * NB;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -445,7 +447,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
         __builtin_amdgcn_sched_barrier(0);
         for (; tile < ntiles; tile += tstride) {
             CUNET_STAMP(ts0);
-            request_x(pg0, tile, xp);
+            if (!CUNET_DBG(p, 8)) request_x(pg0, tile, xp);      // (tuning builds: 8 = no x loads)
             const float* rpn = rowp(tile + tstride < ntiles ? tile + tstride : tile);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
@@ -495,7 +497,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             CUNET_STAMP(ts4);
-            if (CUNET_DBG(p, 1024)) {                          // tuning builds: the dz pieces as non-temporal stores
+            if (CUNET_DBG(p, 2)) {                             // tuning builds: no dz stores
+            } else if (CUNET_DBG(p, 1024)) {                   // tuning builds: the dz pieces as non-temporal stores
                 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
