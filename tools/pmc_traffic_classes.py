@@ -4,7 +4,7 @@ import re
 CLASSES = [      # first match wins: the bf16-MFMA kernels carry bench.py's *_bf16 class names
     (r'wgrad3_stem_kernel', 'stem_bwd_weight'),
     (r'wgrad3_3x3_bf16_kernel', 'conv3x3_bwd_weight_bf16'),
-    (r'wgrad3_bf16_kernel', 'conv1x1_bwd_weight_bf16'),
+    (r'wgrad3_bf16_kernel|wgrad4_bf16_kernel', 'conv1x1_bwd_weight_bf16'),
     (r'wgrad3_3x3_kernel', 'conv3x3_bwd_weight'),
     (r'wgrad3_kernel', 'conv1x1_bwd_weight'),
     (r'wgrad_reduce_kernel', 'wgrad_partial_reduce'),
@@ -20,7 +20,7 @@ CLASSES = [      # first match wins: the bf16-MFMA kernels carry bench.py's *_bf
     (r'conv(_pair)?_kernel<0, 0,|conv1x1_splitk(_pair)?_kernel', 'conv1x1_fwd'),
     (r'conv_kernel<1, 0,', 'conv3x3_fwd'),
     (r'conv_kernel<4, 0,', 'stem_conv_fwd'),
-    (r'conv(_pair)?_kernel<2, 1,', 'conv1x1_bwd_data'),
+    (r'conv(_pair)?_kernel<2, 1,|dgrad1x1_rows_kernel', 'conv1x1_bwd_data'),
     (r'conv_kernel<3, 1,', 'conv3x3_bwd_data'),
     (r'grad_gather_kernel', 'bn_bwd_apply'),
     (r'pool_fwd_kernel<0>|pool_bf16_kernel', 'pool_fwd'),
