@@ -118,11 +118,17 @@ def cpu_baseline(layers, class_num, steps):
         n_main = max(1, min(phys, usable))
         v_main = run(n_main)
         v8 = run(min(8, usable)) if n_main != min(8, usable) else v_main
+        n32 = min(32, usable)
+        v32 = run(n32) if n32 not in (n_main, min(8, usable)) else (v_main if n32 == n_main else v8)
     finally:
         torch.set_num_threads(saved)
+    # (at bs = 4 torch's CPU kernels do not scale to a whole two-socket host: the all-cores figure SURVEY 8d asks for is the headline, the
+    # fastest thread count tried is named next to it)
+    best = max((v_main, n_main), (v32, n32), (v8, min(8, usable)))
     return {'value': v_main, 'unit': 'images/sec', 'cores': n_main, 'kind': 'port',
             'cpu_model': model, 'physical_cores': phys, 'logical_cpus_usable': usable,
-            'at_8_threads': {'value': v8, 'cores': min(8, usable)},
+            'at_8_threads': {'value': v8, 'cores': min(8, usable)}, 'at_32_threads': {'value': v32, 'cores': n32},
+            'best_of_the_three': {'value': best[0], 'cores': best[1]},
             'sample': f'CU-Net-{layers} order 1 K={class_num}, bs=4, 256x256 fp32, {steps} full train steps '
                       f'(fwd+MSE+bwd+RMSprop) after 1 warm-up at each thread count, torch CPU {torch.__version__}'}
 
