@@ -92,6 +92,8 @@ struct ConvArgs {
                            // else one (the plan's snapshot of planner option dgrad_prefetch)
     int dgrad_nt;          // EP_BWD, fp32: most 32-column tiles of dz a wave owns per row tile (the plan's snapshot of planner option
                            // dgrad_nt; 0 = the default 4, 1 = one tile per wave as in rounds 2-3)
+    int split;             // fp32 operands, nothing ragged: 1 = contract on the bf16 matrix pipe with every operand value cut into three bf16
+                           // pieces, six products (conv_body's XBG = 6 / 7; the plan's snapshot of planner option f32_split)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
                            // planner option conv3x3_ring_min_rows; 0 = the default 512)
     int dbg;               // timing experiments only (CUNET_CONV_DBG; conv_bf16_kernel: CUNET_B16_DBG = 32 / 64 as below, 2048 no output

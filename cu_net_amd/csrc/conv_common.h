@@ -34,6 +34,46 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- an fp32 contraction on the bf16 matrix pipe (planner option f32_split) --------------------------------------------------------
+// Eight fp32 values -> three operand registers of v_mfma_f32_32x32x16_bf16: x = h + m + l, each piece rounded to nearest even from
+// what the pieces before it left (8 + 8 + 8 significand bits: h + m + l == x exactly unless l underflows).  Elements 2 j, 2 j + 1 of
+// the input are the low / high half of dword j, the operand order of the instruction.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_op __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_op __attribute__((ext_vector_type(2)));
+typedef float f32x2_op __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_bf16x3_pair(const f32x2_op a, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_op));                          // v_cvt_pk_bf16_f32
+    const f32x2_op hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    const f32x2_op r1 = a - hf;                                                                      // exact
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_op));
+    const f32x2_op mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    const f32x2_op r2 = r1 - mf;                                                                     // exact
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_op));
+}
+__device__ __forceinline__ void split_bf16x3(const float (&f)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned hu, mu, lu;
+        split_bf16x3_pair(f32x2_op{f[2 * j], f[2 * j + 1]}, hu, mu, lu);
+        h[j] = hu; m[j] = mu; l[j] = lu;
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16x8(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_op, a), __builtin_bit_cast(bf16x8_op, b), c, 0, 0, 0);
+}
+// the six products of two split operands, the small terms first
+__device__ __forceinline__ f32x16 mfma_split6(const u32x4& ah, const u32x4& am, const u32x4& al, const u32x4& bh, const u32x4& bm,
+                                              const u32x4& bl, f32x16 c) {
+    c = mfma_bf16x8(ah, bl, c);
+    c = mfma_bf16x8(al, bh, c);
+    c = mfma_bf16x8(am, bm, c);
+    c = mfma_bf16x8(ah, bm, c);
+    c = mfma_bf16x8(am, bh, c);
+    return mfma_bf16x8(ah, bh, c);
+}
+
 // Fill sc/sh (and mu/is) for every channel of the concat, and the group table.
 template <bool NEED_MEAN, int XB>
 __device__ __forceinline__ void setup_concat(const ConvArgs& p, GrpEnt* grp, float* sc, float* sh,

@@ -47,7 +47,7 @@ constexpr int conv_max_waves() {
     // the fp32 data gradient with the LDS-tile epilogue: 3 or 4 channel tiles per wave hold 48 / 64 accumulators next to the A chunks in
     // flight and the epilogue's pieces -- two waves per SIMD (256 VGPRs) instead of three
     // XBG = 4 (the data gradient with the node's weight gradient fused in, round 4): 64 more accumulators per wave -- two waves per SIMD
-    return (EP == EP_BWD && FAST && XBG == 4) ? 8 : (EP == EP_BWD && FAST && (XBG == 0 || XBG == 5)) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
+    return (EP == EP_BWD && FAST && XBG == 4) ? 8 : (EP == EP_BWD && FAST && (XBG == 0 || XBG == 5 || XBG == 6)) ? (NT <= 2 ? CUNET_TEPI_WAVES : 8) : CONV_MAX_WAVES;
 }
 
 // (the body is a device function of (arguments, block coordinates): conv_kernel runs it on one problem, conv_pair_kernel on the
@@ -58,14 +58,22 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     // XBG = 3 (EP_FWD only): the heat-map heads' fused MSE epilogue.  Its 16 target values per channel tile were live next to the
     // accumulators in EVERY forward instantiation and cost the 128-column one 20 spilled registers, reloaded from scratch one by
     // one in its store epilogue (rocm ISA, round 3); only the heads' kernels carry it now.
-    constexpr bool MSE = (EP == EP_FWD && XBG == 3);
+    constexpr bool MSE = (EP == EP_FWD && (XBG == 3 || XBG == 7));
+    // XBG = 6 (XBG = 7: with the fused MSE epilogue), round 4: the fp32 contraction on the bf16 matrix pipe.  Every fp32 operand value is
+    // cut into three bf16 pieces a = h + m + l (8 + 8 + 8 significand bits: exact), and a b ~ hh' + hm' + mh' + mm' + hl' + lh' -- six
+    // v_mfma_f32_32x32x16_bf16 (6 x 32 cycles) where the fp32 pipe needs eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles) for the same
+    // 16 k.  The dropped terms (ml', lm', ll') are below 2^-24 of |a b|; measured against fp64 the result is as close as the fp32
+    // MFMA's (tools/probes/split_bf16_probe.hip, profiles/r04_split_bf16_probe.txt).  B is cut once per block while it is copied into
+    // LDS (three planes: 1.5 x the bytes), A in registers behind the BatchNorm + ReLU; loaders and epilogues are unchanged.
+    constexpr bool EMU = (XBG == 6 || XBG == 7);
     constexpr int GB = (XBG == 2 && (LD == LD_PLAIN || LD == LD_PLAIN3)) ? 1 : 0;      // storage of the gradient tensors
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;                      // output channels per block
     const int kq4 = p.Kpad >> 2;
     const int brows = p.taps * kq4;                  // float4 rows of B
-    float4* Bs = reinterpret_cast<float4*>(smem);    // [taps * Kpad/4][NB]
-    GrpEnt* grp = reinterpret_cast<GrpEnt*>(Bs + (size_t)brows * NB);
+    float4* Bs = reinterpret_cast<float4*>(smem);    // [taps * Kpad/4][NB]   (EMU: [chunk][step 0..1][plane h, m, l][NT][64 lanes] x 16 bytes)
+    const u32x4* Bp = reinterpret_cast<const u32x4*>(smem);
+    GrpEnt* grp = reinterpret_cast<GrpEnt*>(Bs + (size_t)brows * NB * (EMU ? 3 : 2) / 2);
     float* sc = reinterpret_cast<float*>(grp + (p.Ccat >> 2));
     float* sh = sc + p.Ccat;
     float* mu = sh + p.Ccat;
@@ -73,7 +81,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     double* redbuf = reinterpret_cast<double*>(is + p.Ccat);   // [NB][2]
     // fp32 data gradient, nothing ragged: the epilogue's x loads and dz stores go through a wave-private LDS tile, one 32-column
     // tile of the slice after the other (see below).  The other instantiations keep the element-wise epilogue.
-    constexpr bool TEPI = (EP == EP_BWD && FAST && (XBG == 0 || XBG == 4 || XBG == 5));
+    constexpr bool TEPI = (EP == EP_BWD && FAST && (XBG == 0 || XBG == 4 || XBG == 5 || XBG == 6));
     // XBG = 5: the 1x1 data gradient over K = 128 with TWO 32-channel chunks of dY in flight per wave (see the PF2 tile loop below)
     constexpr bool PF2 = (TEPI && XBG == 5 && NT == 1 && LD == LD_PLAIN);
     static_assert(XBG != 5 || PF2, "the two-chunks-ahead loop exists for the fast fp32 1x1 data gradient, one channel tile per wave");
@@ -129,7 +137,40 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
     }
 
     // ---- one-time block setup: B operand -> LDS, BN scale/shift tables ------------------------
-    if (!CUNET_DBG(p, 32)) {
+    if constexpr (EMU) {
+        // operand slot (chunk ch, step t, channel tile nt, lane) = the 8 k-values lane (column nt * 32 + (lane & 31), half lane >> 5) feeds
+        // step t of chunk ch with: float4 rows 8 ch + 4 t + half and + 2 of the packed operand (the channels 8 q + 4 half .. + 3 of
+        // q = 2 t, 2 t + 1 the A side holds), cut into the three planes
+        u32x4* Bw = reinterpret_cast<u32x4*>(smem);
+        const int total = (brows >> 3) * 2 * NT * 64;
+        for (int base = tid; base < total; base += blockDim.x * 4) {
+            float4 v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * blockDim.x;
+                const int ic = idx < total ? idx : 0;
+                const int l = ic & 63, nt = (ic >> 6) % NT, ct = (ic >> 6) / NT;      // ct = ch * 2 + t
+                const int row = (ct >> 1) * 8 + (ct & 1) * 4 + (l >> 5);
+                const int n = n0 + nt * 32 + (l & 31);
+                const int nn = n < p.Npad ? n : 0;
+                v[u][0] = ldg4(p.wB + ((size_t)row * p.Npad + nn) * 4);
+                v[u][1] = ldg4(p.wB + ((size_t)(row + 2) * p.Npad + nn) * 4);
+                if (n >= p.Npad) { v[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); v[u][1] = v[u][0]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * blockDim.x;
+                if (idx < total) {
+                    const int l = idx & 63, nt = (idx >> 6) % NT, ct = (idx >> 6) / NT;
+                    const float f[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+                    u32x4 h, m, lo;
+                    split_bf16x3(f, h, m, lo);
+                    u32x4* d = Bw + ((size_t)ct * 3 * NT + nt) * 64 + l;
+                    d[0] = h; d[NT * 64] = m; d[2 * NT * 64] = lo;
+                }
+            }
+        }
+    } else if (!CUNET_DBG(p, 32)) {
         // 8 independent 16-byte loads in flight per thread (a load-then-store loop would expose one full
         // L2/HBM round trip per iteration: the copy of a 147 KB 3x3 operand dominated the small launches)
         const int total = brows * NB;
@@ -619,6 +660,22 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
 
         auto mfma_live = [&](int ch, const float4 (&acur)[4], auto ltag) {      // the first L channel tiles of the slice
             constexpr int L = decltype(ltag)::value;
+            if constexpr (EMU) {
+                const u32x4* bb = Bp + (size_t)ch * 2 * 3 * NT * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float f[8] = {acur[2 * t].x, acur[2 * t].y, acur[2 * t].z, acur[2 * t].w,
+                                        acur[2 * t + 1].x, acur[2 * t + 1].y, acur[2 * t + 1].z, acur[2 * t + 1].w};
+                    u32x4 ah, am, al;
+                    split_bf16x3(f, ah, am, al);
+#pragma unroll
+                    for (int nt = 0; nt < L; ++nt) {
+                        const u32x4 bh = bb[((t * 3 + 0) * NT + nt) * 64], bm = bb[((t * 3 + 1) * NT + nt) * 64], bl = bb[((t * 3 + 2) * NT + nt) * 64];
+                        acc[nt] = mfma_split6(ah, am, al, bh, bm, bl, acc[nt]);
+                    }
+                }
+                return;
+            }
             const float4* bb = Bs + (size_t)ch * 8 * NB;     // chunk ch = (tap, c): rows (t*kq4 + c*8) ..+7
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1457,6 +1514,183 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_kernel(const ConvArgs
     }
 }
 
+// The same walk with the contraction on the bf16 matrix pipe (planner option f32_split, see conv_body's XBG = 6): an element is cut
+// into its three bf16 pieces ONCE, on the way into the ring (the nine taps and 32 output channels that read it share the cut), a
+// ring pixel is three 256-byte planes (+ 16 bytes: conflict-free 16-byte fragment reads), a step of the contraction is 16 channels:
+// lane (pixel, half) reads channels 16 s + 8 half .. + 7 of each plane, six MFMAs.  The planes make a pixel 784 bytes instead of
+// 528, so a workgroup walks a 32-pixel-wide strip of the image (34 ring pixels per row; at W = 64 two strips per row block).
+constexpr int R3S_PIX = 784;            // bytes per ring pixel
+constexpr int R3S_SLOT = 34 * R3S_PIX;  // bytes per ring row
+
+__global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const ConvArgs p, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 128;
+    const int W = p.W, H = p.H;
+    float* sc = reinterpret_cast<float*>(smem);                   // [K]
+    float* sh = sc + K;                                           // [K]
+    double* redbuf = reinterpret_cast<double*>(sh + K);           // [32][2]
+    float* part = reinterpret_cast<float*>(redbuf + 64);          // [8][1024] partial tiles
+    char* ring = reinterpret_cast<char*>(part + 8 * 1024);        // 3 rows
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int tap = tid >> 6;                                     // 0 .. 7
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const Seg sg = p.seg[0];
+    const int nstrip = W >> 5;
+    const int strip = blockIdx.x % nstrip;
+    const int x0 = strip * 32;
+
+    for (int c = tid; c < K; c += R3_THREADS) {
+        double mean, istd;
+        if (p.training) {
+            mean = sg.stats[c] / sg.count;
+            double var = sg.stats[sg.C + c] / sg.count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            istd = 1.0 / sqrt(var + (double)BN_EPS);
+        } else {
+            mean = (double)p.rmean[c];
+            istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+        }
+        const double scale = (double)p.gamma[c] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[c] - mean * scale);
+    }
+    if (tid < 64) redbuf[tid] = 0.0;
+    for (int i = tid; i < 3 * R3S_SLOT / 16; i += R3_THREADS)     // pixels outside the image stay zero for the whole launch
+        reinterpret_cast<float4*>(ring)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this wave's weights, cut: step s of tap `tap` = k 16 s + 8 hi .. + 7, column li (packed [tap][K/4][Npad][4]: float4 rows 4 s + 2 hi, + 1);
+    // the ninth tap is shared: wave w contracts its k-slice [16 w, 16 w + 16)
+    u32x4 bh[9], bm[9], bl[9];
+#pragma unroll
+    for (int s9 = 0; s9 < 9; ++s9) {
+        const int row = (s9 < 8 ? tap * (K / 4) + 4 * s9 : 8 * (K / 4) + 4 * tap) + 2 * hi;
+        const float4 w0 = ldg4(p.wB + ((size_t)row * p.Npad + li) * 4);
+        const float4 w1 = ldg4(p.wB + ((size_t)(row + 1) * p.Npad + li) * 4);
+        const float f[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        split_bf16x3(f, bh[s9], bm[s9], bl[s9]);
+    }
+    __syncthreads();
+
+    const int NH = p.M / W;                                       // image rows in the batch
+    const int g_begin = (blockIdx.x / nstrip) * rows_per_wg;
+    int g_end = g_begin + rows_per_wg;
+    if (g_end > NH) g_end = NH;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+
+    // staging plan: a ring row is 34 pixels x 32 float4; thread t takes float4 t, t + 512, t + 1024: its channel group never changes
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+    constexpr int NX4 = 34 * 32;
+    const int c4 = (tid & 31) << 2;
+    const float4 s4 = *reinterpret_cast<const float4*>(sc + c4);
+    const float4 h4 = *reinterpret_cast<const float4*>(sh + c4);
+    f32x4n xv[3];
+    bool xok = false;
+    auto issue_x = [&](int g) {
+        xok = g >= 0 && g < NH;
+        const size_t base = (size_t)(xok ? g : 0) * W;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int idx = tid + R3_THREADS * j;
+            if (idx >= NX4) idx = NX4 - 1;
+            int x = x0 - 1 + (idx >> 5);
+            x = x < 0 ? 0 : (x >= W ? W - 1 : x);                 // (clamped: the load stays unconditional, commit_x skips the pixel)
+            xv[j] = *reinterpret_cast<const f32x4n*>(sg.x + (base + x) * sg.ld + c4);
+        }
+    };
+    auto commit_x = [&](int g) {
+        if (!xok) return;
+        char* slot = ring + (size_t)(((g % 3) + 3) % 3) * R3S_SLOT;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = tid + R3_THREADS * j;
+            if (idx >= NX4) break;
+            const int x = x0 - 1 + (idx >> 5);
+            if (x < 0 || x >= W) continue;
+            f32x4n v;
+            v[0] = fmaxf(fmaf(xv[j][0], s4.x, h4.x), 0.f);
+            v[1] = fmaxf(fmaf(xv[j][1], s4.y, h4.y), 0.f);
+            v[2] = fmaxf(fmaf(xv[j][2], s4.z, h4.z), 0.f);
+            v[3] = fmaxf(fmaf(xv[j][3], s4.w, h4.w), 0.f);
+            if (p.qin_bits) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quan_input_act(v[e], p.qin_bits);
+            }
+            u32x2n ph, pm, pl;
+            unsigned a0, a1, a2;
+            split_bf16x3_pair(f32x2_op{v[0], v[1]}, a0, a1, a2);
+            ph[0] = a0; pm[0] = a1; pl[0] = a2;
+            split_bf16x3_pair(f32x2_op{v[2], v[3]}, a0, a1, a2);
+            ph[1] = a0; pm[1] = a1; pl[1] = a2;
+            char* d = slot + (idx >> 5) * R3S_PIX + c4 * 2;
+            *reinterpret_cast<u32x2n*>(d) = ph;
+            *reinterpret_cast<u32x2n*>(d + 256) = pm;
+            *reinterpret_cast<u32x2n*>(d + 512) = pl;
+        }
+    };
+
+    for (int g = g_begin - 1; g <= g_begin + 1; ++g) { issue_x(g); commit_x(g); }
+    __syncthreads();
+
+    double dsum = 0.0, dsq = 0.0;
+    for (int g = g_begin; g < g_end; ++g) {
+        const int y = g % H;
+        issue_x(g + 2);                                           // in flight across this row's MFMAs
+        const bool rvalid = (y + dy >= 0) && (y + dy < H);
+        const bool xvalid = y + 1 < H;                            // tap 8 = (dy, dx) = (+1, +1)
+        const int sl = (g + dy + 3) % 3, slx = (g + 1) % 3;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (rvalid) {
+            const char* ap = ring + (size_t)sl * R3S_SLOT + (li + dx + 1) * R3S_PIX + 16 * hi;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ap + 32 * s8);
+                const u32x4 am = *reinterpret_cast<const u32x4*>(ap + 32 * s8 + 256);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(ap + 32 * s8 + 512);
+                acc = mfma_split6(ah, am, al, bh[s8], bm[s8], bl[s8], acc);
+            }
+        }
+        if (xvalid) {
+            const char* ap = ring + (size_t)slx * R3S_SLOT + (li + 2) * R3S_PIX + 32 * tap + 16 * hi;
+            const u32x4 ah = *reinterpret_cast<const u32x4*>(ap);
+            const u32x4 am = *reinterpret_cast<const u32x4*>(ap + 256);
+            const u32x4 al = *reinterpret_cast<const u32x4*>(ap + 512);
+            acc = mfma_split6(ah, am, al, bh[8], bm[8], bl[8], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[tap * 1024 + r * 64 + lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + R3_THREADS * u;
+            float vsum = part[e];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) vsum += part[w * 1024 + e];
+            const int r = e >> 6, l = e & 63;                     // C layout: col = l & 31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            p.y[((size_t)g * W + x0 + row) * p.ldy + (l & 31)] = vsum;
+            dsum += (double)vsum;
+            dsq += (double)vsum * (double)vsum;
+        }
+        __syncthreads();                                          // everyone is done with row g-1's ring row and with `part`
+        commit_x(g + 2);
+        __syncthreads();
+    }
+    if (p.ystats != nullptr) {                                    // a thread's column is tid & 31 in both passes (512 = 16 * 32)
+        atomicAdd(&redbuf[(tid & 31) * 2 + 0], dsum);
+        atomicAdd(&redbuf[(tid & 31) * 2 + 1], dsq);
+        __syncthreads();
+        if (tid < 32 && tid < p.Nout) {
+            atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
+            atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
+        }
+    }
+}
+
 static bool conv3x3_ring_supported(const ConvArgs& a) {
     return a.nseg == 1 && a.K == 128 && a.Kpad == 128 && a.Nout == 32 && a.Npad == 32 && !a.seg[0].ups && a.seg[0].ld % 4 == 0 &&
            a.seg[0].C == 128 && (a.W == 64 || a.W == 32) && a.M % a.W == 0 && a.ldy >= 32;
@@ -1464,6 +1698,21 @@ static bool conv3x3_ring_supported(const ConvArgs& a) {
 
 static hipError_t launch_conv3x3_ring(const ConvArgs& a, int num_cus, hipStream_t s) {
     const int NH = a.M / a.W;
+    if (a.split) {                      // 32-pixel strips: (W / 32) strips x row blocks
+        const int nstrip = a.W / 32;
+        int rows = (NH * nstrip + num_cus - 1) / num_cus;
+        if (rows < 2) rows = 2;
+        const int grid = ((NH + rows - 1) / rows) * nstrip;
+        const size_t smem = (size_t)2 * 128 * 4 + 64 * 8 + (size_t)8 * 1024 * 4 + (size_t)3 * R3S_SLOT;
+        static bool attr_split = false;
+        if (!attr_split) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_split = true;
+        }
+        hipLaunchKernelGGL(conv3x3_ring_split_kernel, dim3(grid), dim3(R3_THREADS), smem, s, a, rows);
+        return hipGetLastError();
+    }
     int rows = (NH + num_cus - 1) / num_cus;
     if (rows < 2) rows = 2;
     const int grid = (NH + rows - 1) / rows;
@@ -1637,8 +1886,9 @@ static hipError_t launch_conv1x1_splitk(const ConvArgs& a_in, hipStream_t s, con
     return hipGetLastError();
 }
 
-static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat) {
+static size_t conv_smem_bytes(int NT, int taps, int Kpad, int Ccat, bool split = false) {
     size_t b = (size_t)taps * (Kpad / 4) * NT * 32 * 16;   // resident B operand
+    if (split) b += b / 2;                                 // (three bf16 planes)
     b += (size_t)(Ccat / 4) * sizeof(GrpEnt);              // group table
     b += (size_t)Ccat * 4 * 4;                             // sc, sh, mu, is
     b += (size_t)NT * 32 * 2 * 8;                          // reduction scratch
@@ -1651,7 +1901,7 @@ constexpr size_t CONV_LDS_BUDGET = 160 * 1024;
 // pairs exist for the shapes the adapters take: the nothing-ragged 1x1 forward and its fp32 data gradient
 template <int LD, int EP, int NT, bool FAST, int XB>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 grid, int threads, size_t smem, hipStream_t s) {
-    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && (XB == 0 || XB == 4 || XB == 5)))) {
+    if constexpr (FAST && ((LD == LD_SEG && EP == EP_FWD) || (LD == LD_PLAIN && EP == EP_BWD && (XB == 0 || XB == 4 || XB == 5 || XB == 6)))) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<LD, EP, NT, FAST, XB>),
@@ -1673,18 +1923,18 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, dim3 gr
 
 template <int LD, int EP, int NT, bool FAST, int XB = 0>      // XB: 0 / 1 / 2 as ConvArgs::xbf16
 static hipError_t launch_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* b = nullptr) {
-    if constexpr (EP == EP_FWD && XB == 0 && LD == LD_SEG) {
+    if constexpr (EP == EP_FWD && (XB == 0 || XB == 6) && LD == LD_SEG) {
         if (a.mse_tgt != nullptr) {        // a head with the loss fused in: the instantiation that carries the MSE epilogue
             if (b) return hipErrorInvalidValue;
             // (never four channel tiles: 16 target values per tile next to 64 accumulators spilled 10 - 13 registers; the launcher
             // caps a fused-loss head at three)
-            if constexpr (NT <= 3) return launch_inst<LD, EP, NT, FAST, 3>(a, grid, threads, smem, s, nullptr);
+            if constexpr (NT <= 3) return launch_inst<LD, EP, NT, FAST, (XB == 6 ? 7 : 3)>(a, grid, threads, smem, s, nullptr);
             else return hipErrorInvalidValue;
         }
-    } else if constexpr (XB != 3) {
+    } else if constexpr (XB != 3 && XB != 7) {
         if (a.mse_tgt != nullptr) return hipErrorInvalidValue;      // (the fused loss exists for the 1x1 forward only)
     }
-    if constexpr (XB != 3) {
+    if constexpr (XB != 3 && XB != 7) {
         if (b) return launch_pair_inst<LD, EP, NT, FAST, XB>(a, *b, grid, threads, smem, s);
     }
     static bool attr_done = false;
@@ -1721,6 +1971,16 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
         if (fast) return launch_inst<LD, EP, 1, (LD != LD_STEM), B>(a, grid, threads, smem, s, b);
         return launch_inst<LD, EP, 1, false, B>(a, grid, threads, smem, s, b);      // heads: K = class_num
     }
+    if constexpr (LD != LD_STEM) {
+        if (fast && a.split) {             // the fp32 contraction on the bf16 matrix pipe (planner option f32_split)
+            switch (NT) {
+                case 1: return launch_inst<LD, EP, 1, true, 6>(a, grid, threads, smem, s, b);
+                case 2: return launch_inst<LD, EP, 2, true, 6>(a, grid, threads, smem, s, b);
+                case 3: return launch_inst<LD, EP, 3, true, 6>(a, grid, threads, smem, s, b);
+                default: return launch_inst<LD, EP, 4, true, 6>(a, grid, threads, smem, s, b);
+            }
+        }
+    }
     if (fast && LD != LD_STEM) {
         switch (NT) {
             case 1: return launch_inst<LD, EP, 1, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
@@ -1728,6 +1988,9 @@ static hipError_t launch_nt(const ConvArgs& a, int NT, bool fast, dim3 grid, int
             case 3: return launch_inst<LD, EP, 3, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
             default: return launch_inst<LD, EP, 4, (LD != LD_STEM)>(a, grid, threads, smem, s, b);
         }
+    }
+    if constexpr (LD == LD_PLAIN && EP == EP_BWD) {
+        if (a.split && NT == 1) return launch_inst<LD, EP, 1, false, 6>(a, grid, threads, smem, s, b);      // heads: K = class_num
     }
     switch (NT) {
         case 1: return launch_inst<LD, EP, 1, false>(a, grid, threads, smem, s, b);
@@ -1755,7 +2018,7 @@ static TepiGeom tepi_geometry(const ConvArgs& a, int c, int ntiles, int ncol32, 
     if (g.NT > 1 && (long)ntiles * slices < target) return g;        // too few wave-tiles to fill the chip
     g.gy = (ncol32 + g.NT - 1) / g.NT;
     g.maxw = fused ? 8 : (g.NT <= 2 ? CUNET_TEPI_WAVES : 8);          // (conv_max_waves of those instantiations)
-    const size_t base = conv_smem_bytes(g.NT, a.taps, a.Kpad, a.Ccat);
+    const size_t base = conv_smem_bytes(g.NT, a.taps, a.Kpad, a.Ccat, a.split != 0);
     for (g.bpc = 3; g.bpc >= 1; --g.bpc) {
         const int wmax = g.maxw / g.bpc < 4 ? 4 : g.maxw / g.bpc;
         g.smem = base + (size_t)wmax * CONV_TEPI_TILE * (fused ? 2 : 1);      // + one epilogue tile per wave (fused: + one transpose tile)
@@ -1857,10 +2120,15 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     }
     // the fp32 data gradient with the LDS-tile epilogue (TEPI instantiations of the kernel)
     const bool tepi = epi == EP_BWD && fast && a.xbf16 == 0;
+    // the split contraction: fp32 operands; of the ragged shapes only the heads' data gradient (the stem's im2col loader is bound by its
+    // own address arithmetic: 200 -> 211 us with the split's VALU work on top); not next to the fused weight gradient / the two-chunk loop
+    a.split = (a.split && a.xbf16 == 0 && a.wg_part == nullptr && load != LD_STEM && (fast || (load == LD_PLAIN && epi == EP_BWD))) ? 1 : 0;
+    if (a.split) a.dgrad_prefetch = 1;
     if (a.wg_part != nullptr && !(tepi && load == LD_PLAIN && a.taps == 1 && a.K == 128 && a.Nout % 32 == 0 && a.ldy == a.Nout))
         return hipErrorInvalidValue;       // (the fused weight gradient: fast fp32 1x1 data gradient of a 128-output-channel node only)
     int NT = 1;
     TepiGeom tg;
+    const bool split_in = a.split != 0;
     if (tepi) {
         // Channel tiles per wave (planner option dgrad_nt = the most allowed): more tiles per wave read dY fewer times and give every A
         // fragment more independent accumulator chains, but they are dealt in coarser units -- the candidate with the shortest modelled
@@ -1869,32 +2137,45 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
         const bool greedy = opt > 10;
         int cap = greedy ? opt - 10 : opt;
         cap = load == LD_PLAIN ? (cap > 4 ? 4 : (cap < 1 ? 1 : cap)) : 1;
-        for (int c = cap; c >= 1; --c) {
-            const TepiGeom g = tepi_geometry(a, c, ntiles, ncol32, target, num_cus);
-            if (!g.ok) continue;
-            if (!tg.ok || g.est < tg.est) tg = g;
-            if (greedy) break;
+        // (split contraction: the matrix pipe is no longer what a second tile per wave relieves, and the two- and four-tile instantiations
+        // spill 10 - 27 registers: one tile per wave measured best, 3701 vs 3612 (model) / 3530 / 3573 img/s (forced 2 / 4))
+        if (a.split && !greedy) cap = 1;
+        for (int pass = 0; pass < 2 && !tg.ok; ++pass) {
+            if (pass == 1) {
+                if (!a.split) break;
+                a.split = 0;                          // (an operand whose three planes exceed the LDS: the fp32 pipe)
+            }
+            for (int c = cap; c >= 1; --c) {
+                const TepiGeom g = tepi_geometry(a, c, ntiles, ncol32, target, num_cus);
+                if (!g.ok) continue;
+                if (!tg.ok || g.est < tg.est) tg = g;
+                if (greedy) break;
+            }
         }
         if (!tg.ok) return hipErrorInvalidValue;
         NT = tg.NT;
     } else if (nt_ovh < 0.f) {                                  // powers of two only (first version of this launcher)
         NT = ncol32 >= 4 ? 4 : (ncol32 >= 2 ? 2 : 1);
         while (NT > 1 && ((long)ntiles * ((ncol32 + NT - 1) / NT) < target ||
-                          conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET))
+                          conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat, split_in) > CONV_LDS_BUDGET))
             NT >>= 1;
     } else {
         float best = 1e30f;
         static const int nt_max = tune_int("CUNET_CONV_NT_MAX", 4);
         static const int nt_max_bwd = tune_int("CUNET_CONV_NT_MAX_BWD", 1);
         for (int c = (a.xbf16 ? 1 : (epi == EP_BWD ? nt_max_bwd : (a.mse_tgt ? (nt_max < 3 ? nt_max : 3) : nt_max))); c >= 1; --c) {
-            if (conv_smem_bytes(c, a.taps, a.Kpad, a.Ccat) > CONV_LDS_BUDGET) continue;
+            if (conv_smem_bytes(c, a.taps, a.Kpad, a.Ccat, split_in) > CONV_LDS_BUDGET) continue;
             const int slices = (ncol32 + c - 1) / c;
             if (c > 1 && (long)ntiles * slices < target) continue;
             const float cost = slices * ((float)c + nt_ovh);
             if (cost < best) { best = cost; NT = c; }
         }
     }
-    size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat);
+    size_t smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat, a.split != 0);
+    if (smem > CONV_LDS_BUDGET && a.split) {                     // (a 3x3 operand that fits as fp32 only: the fp32 pipe)
+        a.split = 0;
+        smem = conv_smem_bytes(NT, a.taps, a.Kpad, a.Ccat, false);
+    }
     if (smem > CONV_LDS_BUDGET) return hipErrorInvalidValue;   // weights of one 32-channel slice exceed the LDS
     const int gy = (ncol32 + NT - 1) / NT;
     a.col_slices = gy;

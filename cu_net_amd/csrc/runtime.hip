@@ -173,6 +173,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "fuse_wgrad") o.fuse_wgrad = value;
     else if (n == "dgrad_prefetch") o.dgrad_prefetch = value;
     else if (n == "dgrad_rows") o.dgrad_rows = value;
+    else if (n == "f32_split") o.f32_split = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -547,6 +548,7 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.dgrad_nt = P.opts.dgrad_nt;
     a.dgrad_prefetch = P.opts.dgrad_prefetch;
     a.dgrad_rows = P.opts.dgrad_rows;
+    a.split = P.opts.f32_split;
     // fp32 gradient tensors: this launch also computes the node's weight gradient (partial tiles; the bucket's reduce sums them)
     a.wg_part = (E.xmode == 0 && !h->fused_S.empty() && h->fused_S[node_index] > 0) ? E.wsf + n.wg3_part : nullptr;
     return a;
@@ -763,6 +765,7 @@ static ConvArgs conv_fwd_args(cunet_plan* h, Exec& E, const Node& n, int node_in
     a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
     a.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
     a.ring_min_rows = P.opts.conv3x3_ring_min_rows > 0 ? P.opts.conv3x3_ring_min_rows : 1;
+    a.split = P.opts.f32_split;
     return a;
 }
 

@@ -271,6 +271,13 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
  *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
  *                        measured equal (3504 vs 3491 img/s)
+ *   "f32_split"          1: the fp32 convolutions contract on the bf16 matrix pipe.  Every fp32 operand value is cut into three bf16 pieces
+ *                        x = h + m + l (8 + 8 + 8 significand bits: exact) and a product is hh' + hm' + mh' + mm' + hl' + lh', six
+ *                        v_mfma_f32_32x32x16_bf16 (192 cycles per 16 k) instead of eight v_mfma_f32_32x32x2_f32 (512 cycles), accumulated in
+ *                        fp32 as before; inputs, outputs, statistics and every tensor in HBM stay fp32.  The dropped terms are below 2^-24
+ *                        of |x y|: measured against fp64 the result is as close as the fp32 MFMA's (profiles/r04_split_bf16_probe.txt;
+ *                        tests/test_gpu_exact.py::test_backward_error_vs_fp64_tracks_torch_fp32[*-1]).  Kernels: 1x1 forward, heads, 1x1 and
+ *                        3x3 data gradients (conv_body XBG = 6 / 7), 3x3 forward on the row ring.  0 (default): the fp32 matrix pipe
  *   "fuse_wgrad"         1: the fp32 data gradient of a 1x1 node (128 output channels) also computes the node's weight gradient from the dY
  *                        and x tiles it holds and writes one partial tile per row block (summed by the bucket's reduce): one pass over dY
  *                        and x per node, no wgrad launch on the side stream.  0 (default): separate launches -- measured 4.8 % faster in

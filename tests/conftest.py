@@ -26,3 +26,15 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    """CUNET_TEST_PLANNER_OPTS="name=value,..." applies cunet_set_planner_option before any plan exists: the whole GPU suite can be run
+    on a non-default kernel selection (e.g. f32_split=1: the convolutions contract on the bf16 matrix pipe)."""
+    opts = os.environ.get('CUNET_TEST_PLANNER_OPTS', '')
+    if not opts:
+        return
+    from cu_net_amd._lib import set_planner_option
+    for kv in opts.split(','):
+        name, val = kv.split('=')
+        set_planner_option(name.strip(), int(val))

@@ -116,8 +116,21 @@ def test_pool_forward_and_upsample_gather_bit_exact(full):
         assert torch.equal(y, cat[:, sels[nd['name']]]), nd['name']
 
 
+@pytest.mark.parametrize('split', [0, 1])
 @pytest.mark.parametrize('tag', ['G9_L2_o1_c32', 'G1_L2_o1', 'G2_L3_o2'])
-def test_backward_error_vs_fp64_tracks_torch_fp32(tag):
+def test_backward_error_vs_fp64_tracks_torch_fp32(tag, split):
+    """Every gradient tensor and parameter gradient of a train step against the fp64 run of the same graph, with torch's fp32 CPU
+    error on the same tensor as the yardstick.  split = 1: the convolutions contract on the bf16 matrix pipe with every fp32 operand
+    value cut into three bf16 pieces (planner option f32_split, conv_body's XBG = 6) -- the same bound: that path is an fp32 path."""
+    from cu_net_amd._lib import set_planner_option
+    set_planner_option('f32_split', split)
+    try:
+        _backward_error_vs_fp64(tag, '_split' if split else '')
+    finally:
+        set_planner_option('f32_split', 0)
+
+
+def _backward_error_vs_fp64(tag, suffix):
     g = Golden(tag)
     x, target = g.t('x'), g.t('target')
     net = cu_net_amd.create_cu_net(**g.cfg)
@@ -177,7 +190,7 @@ def test_backward_error_vs_fp64_tracks_torch_fp32(tag):
         bad.append(f'median ratio {med_ratio:.2f}')
     try:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-        with open(os.path.join(ROOT, 'gpurun_out', f'backward_vs_f64_{tag}.txt'), 'w') as f:
+        with open(os.path.join(ROOT, 'gpurun_out', f'backward_vs_f64_{tag}{suffix}.txt'), 'w') as f:
             f.write('\n'.join(lines) + '\n')
     except OSError:
         pass
@@ -336,6 +349,55 @@ def test_dgrad_channel_tiles_per_wave_agree():
         assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)      # the forward does not depend on the option (fp64 atomics order only)
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))
         assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max()), (opt, float((t1 - t0).abs().max()), float(t0.abs().max()))
+
+
+def test_split_contraction_agrees_with_the_fp32_matrix_pipe():
+    """Planner option f32_split: the fp32 convolutions (1x1 forward, heads with the fused loss, 1x1 / 3x3 data gradients, adapter pairs)
+    contract on the bf16 matrix pipe -- x = h + m + l in bf16 pieces, six products per pair of operands.  Not bit-identical to the fp32
+    MFMA (other roundings of the same sums) but the same arithmetic to fp32 accuracy: BASELINE config 2's shapes, one whole train step,
+    loss / every parameter gradient / the stem-side gradient tensor against the fp32-pipe run at the tolerance two fp32 summation
+    orders differ by (models/cu_net.py:11-17, 45-48 and their autograd; cu-net.py:175-182)."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=91)
+    x, target = O.synthetic_batch(24, 68, 256, seed=92)
+    xd, td = x.cuda(), target.cuda()
+    res = {}
+    try:
+        for split in (0, 1):
+            set_planner_option('f32_split', split)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(24, 256, 256, True)
+            loss = plan.stage_target(td)
+            outs = plan.forward(xd, True, want_outputs=True)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            d = plan.handle.describe()
+            first_pool = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][1]['out']][0]
+            res[split] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True), [o.clone() for o in outs])
+            del plan, net
+    finally:
+        set_planner_option('f32_split', 0)
+    l0, g0, t0, o0 = res[0]
+    l1, g1, t1, o1 = res[1]
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    e_loss = abs(l1 - l0) / abs(l0)
+    e_max = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(o1, o0))
+    e_nrm = max(float((a - b).norm() / b.norm()) for a, b in zip(o1, o0))
+    e_par = float((g1 - g0).norm() / g0.norm())
+    e_stem = float((t1 - t0).abs().max() / t0.abs().max())
+    print(f'split vs fp32 pipe: loss {e_loss:.2e}, heat maps max {e_max:.2e} / norm {e_nrm:.2e}, parameter gradients {e_par:.2e}, stem-side gradient {e_stem:.2e}')
+    # Two fp32 evaluations of the same step: the heat maps agree to 2e-5 of their range (BASELINE.json's bar: 1e-4).  The gradients of a
+    # whole backward do NOT agree to fp32 accuracy between ANY two fp32 paths: a ReLU / max-pool decision that flips on a 1e-7 difference
+    # moves a gradient tensor by 1e-2 (test_backward_error_vs_fp64_tracks_torch_fp32 sees torch's CPU fp32 and this library jump from 3e-5
+    # to 1.4e-2 at the same tensor) -- here 5e-3 on the parameter gradients.  What bounds the split path's accuracy is that test (error
+    # against fp64 as small as the fp32 pipe's, tensor by tensor) and the node-by-node check at this batch
+    # (test_whole_backward_composition_bench_batch[1]); this one catches an instantiation that only runs at N = 24 going wrong grossly.
+    assert e_loss <= 2e-6 and e_max <= 1e-4 and e_nrm <= 5e-5 and e_par <= 3e-2 and e_stem <= 0.3, (e_loss, e_max, e_nrm, e_par, e_stem)
 
 
 @pytest.mark.parametrize('n', [4, 24])

@@ -415,8 +415,11 @@ def test_whole_backward_composition_full_width_cu_net4():
     _check_composition(cfg, st, x, target)
 
 
-def test_whole_backward_composition_bench_batch():
-    """BASELINE config 2 exactly as bench.py runs it -- CU-Net-2, K = 68, N = 24, 256 x 256, default planner options: every
+@pytest.mark.parametrize('split', [0, 1])
+def test_whole_backward_composition_bench_batch(split):
+    """(split = 1: planner option f32_split -- the 1x1 / 3x3 forward, the heads and the data gradients contract on the bf16 matrix pipe,
+    every operand value cut into three bf16 pieces; same checks, same tolerances.)
+    BASELINE config 2 exactly as bench.py runs it -- CU-Net-2, K = 68, N = 24, 256 x 256, default planner options: every
     weight-gradient workgroup walks 12 or more chunks (the double-buffer reuse of wgrad3_kernel needs >= 3), the 3x3 forward
     is on the LDS row ring, the data gradients run their multi-tile loops, 1536 image rows per level.  Composition check of
     the tensor gradients after ONE real backward pass, and the parameter gradients of every conv / BatchNorm against
@@ -426,7 +429,12 @@ def test_whole_backward_composition_bench_batch():
     spec = O.Spec(**cfg)
     st = O.init_state(spec, seed=81)
     x, target = O.synthetic_batch(24, 68, 256, seed=82)
-    _check_composition(cfg, st, x, target, check_params=True)      # (incl. every node's FORWARD at N = 24 against torch on the GPU's own inputs)
+    from cu_net_amd._lib import set_planner_option
+    set_planner_option('f32_split', split)
+    try:
+        _check_composition(cfg, st, x, target, check_params=True)      # (incl. every node's FORWARD at N = 24 against torch on the GPU's own inputs)
+    finally:
+        set_planner_option('f32_split', 0)
 
 
 @pytest.mark.parametrize('mode', [True, 2])
