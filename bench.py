@@ -348,6 +348,12 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     return res
 
 
+SPLIT_NOTE = ('fp32 operands and fp32 accumulation on the bf16 matrix pipe: every operand value cut into three bf16 pieces (8 + 8 + 8 significand '
+              'bits, exact), six v_mfma_f32_32x32x16_bf16 products per pair (planner option f32_split=1, the default); error against fp64 '
+              'equal to the fp32 MFMA path (profiles/r04_split_bf16_probe.txt, tests/test_gpu_exact.py::test_backward_error_vs_fp64_tracks_torch_fp32); '
+              'all tensors in HBM fp32; `also` carries the same workload on the fp32 matrix pipe')
+
+
 def workload_name(L, K, bs, mode, bits_w, forward_only, world, popcount=False):
     return (f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
             + (f'QuanOp bits_w={bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if bits_w > 0 else '')
@@ -436,9 +442,12 @@ def main():
         ranks_seen = int(one.item())
 
     import cu_net_amd
+    split = 1                                   # planner option f32_split (default on): see SPLIT_NOTE
     for po in args.planner_opt:
         name, _, val = po.partition('=')
         cu_net_amd._lib.check(cu_net_amd._lib.lib().cunet_set_planner_option(name.encode(), int(val)), 'cunet_set_planner_option')
+        if name == 'f32_split':
+            split = int(val)
     if rank == 0:
         log('library: %s  (%s)' % (cu_net_amd._lib.LIB_PATH, cu_net_amd._lib.lib().cunet_version().decode()))
     L, K, bs = args.layers, args.class_num, args.bs
@@ -479,6 +488,14 @@ def main():
             'roofline': r['roofline'],
             'final_loss': r['final_loss'],
         }
+        if mode == 'fp32':
+            out['contraction'] = SPLIT_NOTE if split else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32), planner option f32_split=0'
+            if split and out['roofline'] and out['roofline'].get('bound') == 'mfma':
+                # the class's algorithmic fp32 flops against the fp32 pipe's peak (the denominator of every earlier round) and against
+                # what the split contraction can reach at most: the bf16 pipe's peak / 6 products
+                out['roofline']['peak_note'] = ('fp32 dense MFMA peak; the class contracts on the bf16 pipe with 6 products per fp32 product: '
+                                                'its own ceiling is %.1f TFLOP/s of fp32-equivalent work (frac_of_split_peak)' % (PEAK_BF16_MFMA_TFLOPS / 6))
+                out['roofline']['frac_of_split_peak'] = round(out['roofline']['achieved'] / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
         for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
             if k in r:
                 out[k] = r[k]
@@ -493,10 +510,20 @@ def main():
                      (2, 68, 'fp32', 0, False, True), (2, 68, 'bf16', 0, False, True)]
         else:
             extra = [(8, 16, 'bf16_grads', 0, False, False), (8, 16, 'fp32', 0, False, False)]
-        for (l2, k2, m2, bw, pc, fwd) in extra:
-            name2 = workload_name(l2, k2, bs, m2, bw, fwd, world, pc)
+        if world == 1 and split:
+            # the bench workload on the fp32 matrix pipe (every earlier round's kernel selection), so that both numbers are on record
+            extra.append((2, 68, 'fp32', 0, False, False, 0))
+        for spec in extra:
+            (l2, k2, m2, bw, pc, fwd), sp2 = spec[:6], (spec[6] if len(spec) > 6 else split)
+            name2 = workload_name(l2, k2, bs, m2, bw, fwd, world, pc) + ('' if sp2 == split else ' -- planner option f32_split=0: fp32 matrix pipe')
             try:
-                e = measure(dev, pg, rank, world, l2, k2, bs, args.also_steps, max(3, args.warmup), m2, bw, fwd, pc, args.profile_out)
+                if sp2 != split:
+                    cu_net_amd._lib.set_planner_option('f32_split', sp2)
+                try:
+                    e = measure(dev, pg, rank, world, l2, k2, bs, args.also_steps, max(3, args.warmup), m2, bw, fwd, pc, args.profile_out)
+                finally:
+                    if sp2 != split:
+                        cu_net_amd._lib.set_planner_option('f32_split', split)
                 ent = {'workload': name2, 'value': round(e['value'], 2), 'unit': 'images/sec', 'n_gpus': world,
                        'steps': args.also_steps, 'ms_per_step': round(e['ms_per_step'], 3), 'ms_per_step_median': round(e['ms_per_step_median'], 3),
                        'dtype': 'bf16' if m2 != 'fp32' else 'f32', 'roofline': e['roofline'], 'final_loss': e['final_loss']}

@@ -141,6 +141,7 @@ struct WgradArgs {
     int IH, IW;
     int xbf16;             // 1 = the segments' x are bf16; 2 = x and dy are bf16 (dw stays fp32)
     int qin_bits;          // > 0: the conv's input is QuanInput(relu(bn(x))): the weight gradient contracts dY with the QUANTISED activation
+    int split;             // fp32 storage: 1 = contract on the bf16 matrix pipe, operands cut into three bf16 pieces (planner option f32_split)
     int bf16_dma;          // xbf16 == 2, 1x1: 1 = the LDS-DMA ring kernel where its preconditions hold (the plan's snapshot of planner option
                            // wgrad_bf16_dma), 0 = always the register-staged kernel
 };

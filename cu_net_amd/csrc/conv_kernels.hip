@@ -673,6 +673,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bidx, con
                         const u32x4 bh = bb[((t * 3 + 0) * NT + nt) * 64], bm = bb[((t * 3 + 1) * NT + nt) * 64], bl = bb[((t * 3 + 2) * NT + nt) * 64];
                         acc[nt] = mfma_split6(ah, am, al, bh, bm, bl, acc[nt]);
                     }
+                    // (three or four accumulator tiles: the second step's pieces are not cut while the first step's are live)
+                    if constexpr (L >= 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 return;
             }

@@ -671,6 +671,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
             w.dw = h->grads + c.w;
             w.xbf16 = E.xmode;
             w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
+            w.split = E.xmode == 0 ? P.opts.f32_split : 0;
             w.bf16_dma = planner_options().wgrad_bf16_dma;      // (a launch-time choice between bit-identical kernels: read live, not from the plan's snapshot)
             if (c.taps == 9 && wg3_active(P, n, E.xmode) && wgrad3_3x3_supported(w)) {
                 // LDS ring of activated image rows, partial tiles [split][tap][n][c] (reduced + transposed per bucket)

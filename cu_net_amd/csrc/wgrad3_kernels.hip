@@ -18,6 +18,7 @@
 // Roofline: 2*128*CW flops per (128 + CW)*4 bytes = 45.7 flop/B at CW = 320 > the fp32 ridge (~25): MFMA-bound.
 #include <type_traits>
 #include "common.h"
+#include "conv_common.h"
 #include "kernels.h"
 
 namespace cunet {
@@ -34,7 +35,10 @@ constexpr int WG3_MIN_WAVES = CUNET_WG3_MIN_WAVES;
 constexpr int WG3_NOUT = 128;        // output channels (4 tiles): the bottleneck / adapter convs of the network
 constexpr int WG3_MAXCW = 320;
 
-template <int CTW, bool SPLITK, int XB>
+// EMU (planner option f32_split, fp32 storage only): the same staging, the contraction on the bf16 matrix pipe -- a lane takes its
+// operands as 8 consecutive pixels of one channel (eight strided ds_read_b32, as many as the eight fp32 k-steps they replace), cuts
+// each value into three bf16 pieces and issues six v_mfma_f32_32x32x16_bf16 per tile pair (conv_common.h, conv_body's XBG = 6).
+template <int CTW, bool SPLITK, int XB, bool EMU = false>
 __global__ __launch_bounds__(WG3_THREADS, WG3_MIN_WAVES) void wgrad3_kernel(const Wg3Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgradArgs& p = q.w;
@@ -180,6 +184,34 @@ __global__ __launch_bounds__(WG3_THREADS, WG3_MIN_WAVES) void wgrad3_kernel(cons
         // k-step i of this wave contracts pixel pair KS*i + (SPLITK ? half : 0); operands are fetched PF steps ahead of
         // the MFMAs that use them (left to itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per tile, which
         // exposes the whole LDS latency on every MFMA: measured 47 % of the matrix pipe)
+        if constexpr (EMU) {
+            // split-K: half h of the waves takes pixels 16 h .. 16 h + 15 of the chunk, otherwise both k-steps
+            constexpr int NS = SPLITK ? 1 : 2;
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) {
+                const int p0 = 16 * (SPLITK ? half : ks) + 8 * hi;
+                const float* A = cur + p0 * WG3_NOUT + nt * 32 + li;
+                const float* X = cur + WG3_P * WG3_NOUT + p0 * LDX + li;
+                float af[8], xf[CTW][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) af[j] = A[j * WG3_NOUT];
+#pragma unroll
+                for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[t][j] = X[j * LDX + ctile[t] * 32];
+                u32x4 ah, am, al;
+                split_bf16x3(af, ah, am, al);
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) {
+                    u32x4 xh, xm, xl;
+                    split_bf16x3(xf[t], xh, xm, xl);
+                    acc[t] = mfma_split6(ah, am, al, xh, xm, xl, acc[t]);
+                }
+            }
+            if (more) commit(buf0 + ((chunk + 1) & 1) * bufsz);
+            __syncthreads();
+            continue;
+        }
         constexpr int NK = SPLITK ? WG3_P / 4 : WG3_P / 2;
         constexpr int KS = SPLITK ? 2 : 1;
         constexpr int PF = 2;
@@ -805,9 +837,9 @@ static hipError_t launch_wg3_bf16(const Wg3Args& q, int ct, dim3 grid, size_t sm
     return hipGetLastError();
 }
 
-template <int XB>
+template <int XB, bool EMU = false>
 static hipError_t launch_wg3_x(const Wg3Args& q, int ct, dim3 grid, size_t smem, hipStream_t s) {
-#define CUNET_WG3(CTW_, SK_) hipLaunchKernelGGL((wgrad3_kernel<CTW_, SK_, XB>), grid, dim3(WG3_THREADS), smem, s, q)
+#define CUNET_WG3(CTW_, SK_) hipLaunchKernelGGL((wgrad3_kernel<CTW_, SK_, XB, EMU>), grid, dim3(WG3_THREADS), smem, s, q)
     switch (ct) {
         case 4: CUNET_WG3(4, true); break;
         case 5: CUNET_WG3(5, true); break;
@@ -830,6 +862,8 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
             (const void*)&wgrad3_kernel<4, false, 0>, (const void*)&wgrad3_kernel<5, false, 0>,
             (const void*)&wgrad3_kernel<4, true, 1>, (const void*)&wgrad3_kernel<5, true, 1>, (const void*)&wgrad3_kernel<3, false, 1>,
             (const void*)&wgrad3_kernel<4, false, 1>, (const void*)&wgrad3_kernel<5, false, 1>,
+            (const void*)&wgrad3_kernel<4, true, 0, true>, (const void*)&wgrad3_kernel<5, true, 0, true>, (const void*)&wgrad3_kernel<3, false, 0, true>,
+            (const void*)&wgrad3_kernel<4, false, 0, true>, (const void*)&wgrad3_kernel<5, false, 0, true>,
             (const void*)&wgrad3_bf16_kernel<4, true>, (const void*)&wgrad3_bf16_kernel<5, true>, (const void*)&wgrad3_bf16_kernel<3, false>,
             (const void*)&wgrad3_bf16_kernel<4, false>, (const void*)&wgrad3_bf16_kernel<5, false>,
             (const void*)&wgrad4_bf16_kernel<4>, (const void*)&wgrad4_bf16_kernel<5>, (const void*)&wgrad4_bf16_kernel<6>, (const void*)&wgrad4_bf16_kernel<7>,
@@ -868,7 +902,8 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
         if (ct <= 5 && buf_bytes < (size_t)4 * ct * 4096) buf_bytes = (size_t)4 * ct * 4096;      // split-K hand-over area
         const size_t smem = (size_t)2 * WG3_MAXCW * 4 + buf_bytes;
         const hipError_t e = dma ? launch_wg4_bf16(q, ct, dim3(S), s) : a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)
-                           : a.xbf16 ? launch_wg3_x<1>(q, ct, dim3(S), smem, s) : launch_wg3_x<0>(q, ct, dim3(S), smem, s);
+                           : a.xbf16 ? launch_wg3_x<1>(q, ct, dim3(S), smem, s)
+                           : a.split ? launch_wg3_x<0, true>(q, ct, dim3(S), smem, s) : launch_wg3_x<0>(q, ct, dim3(S), smem, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -895,7 +930,9 @@ hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, c
 // bucket's reduce kernel sums the splits and transposes into torch's [n][c][tap].
 constexpr int WG3C_C = 128, WG3C_N = 32;
 
-template <int XBG>      // 0: fp32 x and dY; 1: bf16 x; 2: bf16 x and bf16 dY (both widened to fp32 on the way into LDS; fp32 MFMA)
+// EMU (planner option f32_split, XBG = 0, W a multiple of 16): the contraction on the bf16 matrix pipe as in wgrad3_kernel -- a lane
+// takes 8 consecutive pixels of its channel, cuts them into three bf16 pieces, six MFMAs per (dY tile, tap).
+template <int XBG, bool EMU = false>      // 0: fp32 x and dY; 1: bf16 x; 2: bf16 x and bf16 dY (both widened to fp32 on the way into LDS; fp32 MFMA)
 __global__ __launch_bounds__(WG3_THREADS, WG3_MIN_WAVES) void wgrad3_3x3_kernel(const Wg3Args q) {
     constexpr int XB = XBG != 0, GB = XBG == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1023,6 +1060,33 @@ __global__ __launch_bounds__(WG3_THREADS, WG3_MIN_WAVES) void wgrad3_3x3_kernel(
         int boff[CTW];
 #pragma unroll
         for (int t = 0; t < CTW; ++t) boff[t] = rowoff[tdy[t] + 1] + (hi + tdx[t] + 1) * WG3C_C + ctile * 32 + li;
+        if constexpr (EMU) {
+            const int ns = W >> 4;                         // k-steps of 16 pixels
+            for (int ks = 0; ks < ns; ++ks) {
+                // this lane's pixels 16 ks + 8 hi .. + 7 (aoff / boff carry hi pixels already: 7 hi more)
+                const int pa = aoff + (16 * ks + 7 * hi) * WG3C_N;
+                float af[8], bf[CTW][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) af[j] = lds[pa + j * WG3C_N];
+#pragma unroll
+                for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bf[t][j] = lds[boff[t] + (16 * ks + 7 * hi + j) * WG3C_C];
+                u32x4 ah, am, al;
+                split_bf16x3(af, ah, am, al);
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) {
+                    u32x4 xh, xm, xl;
+                    split_bf16x3(bf[t], xh, xm, xl);
+                    acc[t] = mfma_split6(ah, am, al, xh, xm, xl, acc[t]);
+                }
+            }
+            __syncthreads();
+            commit_x(g + 2);
+            commit_a(g + 1);
+            __syncthreads();
+            continue;
+        }
         const int nk = W >> 1;
         float a_cur = lds[aoff], b_cur[CTW];
 #pragma unroll
@@ -1510,6 +1574,7 @@ hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_pe
         hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)&wgrad3_3x3_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -1536,6 +1601,7 @@ hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_pe
     const size_t smem = ((size_t)2 * WG3C_C + (size_t)4 * (a.W + 2) * WG3C_C + (size_t)2 * a.W * WG3C_N) * 4;
     if (a.xbf16 == 2) hipLaunchKernelGGL(wgrad3_3x3_kernel<2>, dim3(S), dim3(WG3_THREADS), smem, s, q);
     else if (a.xbf16) hipLaunchKernelGGL(wgrad3_3x3_kernel<1>, dim3(S), dim3(WG3_THREADS), smem, s, q);
+    else if (a.split && a.W % 16 == 0) hipLaunchKernelGGL((wgrad3_3x3_kernel<0, true>), dim3(S), dim3(WG3_THREADS), smem, s, q);
     else hipLaunchKernelGGL(wgrad3_3x3_kernel<0>, dim3(S), dim3(WG3_THREADS), smem, s, q);
     return hipGetLastError();
 }

@@ -27,6 +27,9 @@ def main():
     import cu_net_amd
     from cu_net_amd.parallel import shard_batch
     from cu_net_amd.trainer import FusedTrainer
+    for kv in filter(None, os.environ.get('CUNET_TEST_PLANNER_OPTS', '').split(',')):      # (the suite's kernel selection, see conftest.py)
+        from cu_net_amd._lib import set_planner_option
+        set_planner_option(kv.split('=')[0].strip(), int(kv.split('=')[1]))
     from oracle import cunet_ref as O
     from tests.test_gpu_dp import CASES, make_inputs
     case = os.environ.get('CUNET_DP_CASE', 'toy')

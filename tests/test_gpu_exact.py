@@ -127,7 +127,7 @@ def test_backward_error_vs_fp64_tracks_torch_fp32(tag, split):
     try:
         _backward_error_vs_fp64(tag, '_split' if split else '')
     finally:
-        set_planner_option('f32_split', 0)
+        set_planner_option('f32_split', 1)      # (the default)
 
 
 def _backward_error_vs_fp64(tag, suffix):
@@ -381,7 +381,7 @@ def test_split_contraction_agrees_with_the_fp32_matrix_pipe():
             res[split] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True), [o.clone() for o in outs])
             del plan, net
     finally:
-        set_planner_option('f32_split', 0)
+        set_planner_option('f32_split', 1)      # (the default)
     l0, g0, t0, o0 = res[0]
     l1, g1, t1, o1 = res[1]
     assert torch.isfinite(g1).all() and float(g1.norm()) > 0

@@ -434,7 +434,7 @@ def test_whole_backward_composition_bench_batch(split):
     try:
         _check_composition(cfg, st, x, target, check_params=True)      # (incl. every node's FORWARD at N = 24 against torch on the GPU's own inputs)
     finally:
-        set_planner_option('f32_split', 0)
+        set_planner_option('f32_split', 1)      # (the default)
 
 
 @pytest.mark.parametrize('mode', [True, 2])
