@@ -1169,6 +1169,171 @@ __global__ __launch_bounds__(DR_MAX_WAVES * 64) void dgrad1x1_rows_kernel(const 
     }
 }
 
+// The row-tile data gradient with the contraction on the bf16 matrix pipe (planner options f32_split + dgrad_rows).  In the column-sliced
+// kernel every slice cuts the same dY chunk into its bf16 pieces again (5 - 10 times per node: that kernel is bound by this VALU work once
+// the MFMAs are cheap); here the 32 x 128 dY tile is cut ONCE per workgroup: it arrives in the LDS ring by LDS-DMA as above, all threads
+// together turn it into three planes of MFMA operands (8 k-steps x 3 planes x 64 lanes x 16 bytes = 24 KB, double buffered), and a wave's
+// contraction is 24 ds_read_b128 + 48 MFMAs with its weights -- cut once per launch -- in 96 registers.  The cut of tile t + 1 runs in
+// front of the MFMAs of tile t, so one barrier per tile still covers both the DMA and the planes.  Ccat / 32 waves above 8 do not fit the
+// register budget: the columns are dealt to column groups of at most 8 waves (blockIdx.x % cgroups), each staging dY for itself.
+constexpr int DRS_PLANES = 8 * 3 * 64 * 16;       // bytes of one tile's operand planes
+constexpr int DRS_MAX_WAVES = 8;
+
+__global__ __launch_bounds__(DRS_MAX_WAVES * 64, 2) void dgrad1x1_rows_split_kernel(const ConvArgs p, int cgroups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    // LDS: [ring 3 x 16 KB][planes 2 x 24 KB][T tiles: waves x 32 x 36 floats][group table][sc sh mu is][fp64 sums 2 x Ccat]
+    char* ring = smem;
+    u32x4* planes = reinterpret_cast<u32x4*>(smem + DR_SLOTS * DR_SLOT);
+    float* tileT = reinterpret_cast<float*>(smem + DR_SLOTS * DR_SLOT + 2 * DRS_PLANES);
+    GrpEnt* grp = reinterpret_cast<GrpEnt*>(tileT + (size_t)nwaves * 32 * 36);
+    float* sc = reinterpret_cast<float*>(grp + (p.Ccat >> 2));
+    float* sh = sc + p.Ccat;
+    float* mu = sh + p.Ccat;
+    float* is = mu + p.Ccat;
+    double* redbuf = reinterpret_cast<double*>(is + p.Ccat);      // [Ccat][2]
+    const unsigned ring0 = (unsigned)(size_t)ring;
+
+    setup_concat<true, 0>(p, grp, sc, sh, mu, is);
+    for (int i = tid; i < 2 * p.Ccat; i += blockDim.x) redbuf[i] = 0.0;
+
+    const int group = blockIdx.x % cgroups;
+    const int col0 = (group * nwaves + wave) * 32;                // this wave's 32 columns
+    const bool active = col0 < p.Ccat;                            // (the last group may carry idle waves: they stage and cut with the others)
+    const int colw = active ? col0 : 0;
+    // this wave's 128 x 32 slice of the backward operand [k / 4][Npad][4], cut: step s, lane (column li, half hi) = k 16 s + 4 hi + 0..3 and
+    // 16 s + 8 + 4 hi + 0..3 (float4 rows 4 s + hi and + 2) -- the channels the dY pieces of requests 2 s and 2 s + 1 carry for that lane
+    u32x4 bh[8], bm[8], bl[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+        const float4 w0 = ldg4(p.wB + ((size_t)(4 * s8 + hi) * p.Npad + colw + li) * 4);
+        const float4 w1 = ldg4(p.wB + ((size_t)(4 * s8 + 2 + hi) * p.Npad + colw + li) * 4);
+        const float f[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        split_bf16x3(f, bh[s8], bm[s8], bl[s8]);
+    }
+
+    const int ntiles = p.M >> 5;
+    const int gstride = gridDim.x / cgroups;
+    int tile = blockIdx.x / cgroups;
+    auto issue = [&](int t, int slot) {                           // LDS-DMA requests of a tile: q = wave, wave + nwaves, ... < 16
+        const float* src = p.a + (size_t)(t * 32 + li) * p.lda + 4 * hi;
+        for (int q = wave; q < 16; q += nwaves)
+            dr_dma16(src + 8 * q, __builtin_amdgcn_readfirstlane(ring0 + (unsigned)(slot * DR_SLOT + q * 1024)));
+    };
+    auto cut = [&](int slot, int pb) {                            // ring slot -> operand planes pb: item (step s, lane l) = requests 2 s, 2 s + 1
+        const float4* R = reinterpret_cast<const float4*>(ring + slot * DR_SLOT);
+        u32x4* P = planes + (size_t)pb * (DRS_PLANES / 16);
+        for (int i = tid; i < 512; i += blockDim.x) {
+            const int s8 = i >> 6, l = i & 63;
+            const float4 a0 = R[(2 * s8) * 64 + l], a1 = R[(2 * s8 + 1) * 64 + l];
+            const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            u32x4 h, m, lo;
+            split_bf16x3(f, h, m, lo);
+            P[(s8 * 3 + 0) * 64 + l] = h;
+            P[(s8 * 3 + 1) * 64 + l] = m;
+            P[(s8 * 3 + 2) * 64 + l] = lo;
+        }
+    };
+    for (int k = 0; k < 3; ++k)
+        if (tile + k * gstride < ntiles) issue(tile + k * gstride, k);
+
+    const int pc4 = lane & 7, pr0 = lane >> 3;        // this lane's 16-byte pieces of a 32 x 32 tile: column piece, first row (+ 8 j)
+    const int HW = p.H * p.W;
+    __syncthreads();                                   // tables visible
+    const int col = colw + li;
+    const float csc = sc[col], csh = sh[col], cmu = mu[col], cis = is[col];
+    const GrpEnt pg = grp[(colw + 4 * pc4) >> 2];
+    float4 xp[4], xn[4];
+    auto request_x = [&](int t, float4 (&o)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = t * 32 + pr0 + 8 * j;
+            int row = mm;
+            if (p.any_ups && pg.ups) {                 // (a branch around arithmetic only)
+                int ni, yy, xx;
+                if (p.wshift >= 0) { ni = mm >> p.hwshift; const int rm = mm & (HW - 1); yy = rm >> p.wshift; xx = rm & (p.W - 1); }
+                else { ni = mm / HW; const int rm = mm - ni * HW; yy = rm / p.W; xx = rm - yy * p.W; }
+                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            }
+            o[j] = ldg4(pg.ptr + (size_t)row * pg.ld);
+        }
+    };
+    if (tile < ntiles) request_x(tile, xp);
+    // the first tile's planes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile < ntiles) cut(0, 0);
+    float* T = tileT + (size_t)wave * 32 * 36;
+    int k = 0;                                         // tiles done by this workgroup: ring slot k % 3, planes k & 1
+    for (; tile < ntiles; tile += gstride, ++k) {
+        // this wave's DMA pieces of the next tiles and this tile's x have landed ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // ... everyone's have; planes k & 1 are complete; ring slot k % 3 (cut one tile ago) is free
+        if (tile + 3 * gstride < ntiles) issue(tile + 3 * gstride, k % 3);
+        const bool more = tile + gstride < ntiles;
+        request_x(more ? tile + gstride : tile, xn);   // next tile's x: in flight across this tile (no branch around a request)
+        if (more) cut((k + 1) % 3, (k + 1) & 1);       // the next tile's operands, in front of this tile's MFMAs
+        if (active) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const u32x4* P = planes + (size_t)(k & 1) * (DRS_PLANES / 16) + lane;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8)
+                acc = mfma_split6(P[(s8 * 3 + 0) * 64], P[(s8 * 3 + 1) * 64], P[(s8 * 3 + 2) * 64], bh[s8], bm[s8], bl[s8], acc);
+            // BatchNorm / ReLU backward, first half (as conv_body's LDS-tile epilogue)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * 36 + 4 * pc4) = xp[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float s1 = 0.f, s2 = 0.f;
+            float* tcol = T + li;
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fmaf(xv[r], csc, csh);
+                const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[r] : 0.f;      // ReLU mask (+ QuanInput's straight-through mask)
+                s1 += dz;
+                s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
+                xv[r] = dz;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36] = xv[r];
+            atomicAdd(&redbuf[col * 2 + 0], (double)s1);
+            atomicAdd(&redbuf[col * 2 + 1], (double)s2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = pr0 + 8 * j;
+                *reinterpret_cast<float4*>(p.y + (size_t)(tile * 32 + rr) * p.ldy + col0 + 4 * pc4) = *reinterpret_cast<const float4*>(T + rr * 36 + 4 * pc4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = xn[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.ystats != nullptr) {
+        for (int c = tid; c < nwaves * 32; c += blockDim.x) {      // this column group's sums
+            const int cc = group * nwaves * 32 + c;
+            if (cc < p.Ccat) {
+                atomic_add_f64(p.ystats + cc, redbuf[cc * 2 + 0]);
+                atomic_add_f64(p.ystats + p.Nout + cc, redbuf[cc * 2 + 1]);
+            }
+        }
+    }
+}
+
 static bool dgrad1x1_rows_supported(const ConvArgs& a) {
     if (a.taps != 1 || a.K != 128 || a.Kpad != 128 || a.xbf16 || a.M % 32 || a.Nout % 32 || a.Nout != a.Ccat || a.ldy != a.Nout || a.lda % 4 ||
         a.Nout / 32 < 4 || a.Nout / 32 > DR_MAX_WAVES || a.wg_part != nullptr || a.mse_tgt != nullptr)
@@ -1184,6 +1349,24 @@ static hipError_t launch_dgrad1x1_rows(const ConvArgs& a_in, int num_cus, hipStr
     static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: work-skipping timing experiments
     a.dbg = dbg;
     const int nw = a.Nout / 32;
+    if (a.split) {                      // the contraction on the bf16 matrix pipe: column groups of at most 8 waves, one workgroup per CU
+        const int cgroups = (nw + DRS_MAX_WAVES - 1) / DRS_MAX_WAVES;
+        const int wpg = (nw + cgroups - 1) / cgroups;
+        const size_t smem = (size_t)DR_SLOTS * DR_SLOT + 2 * DRS_PLANES + (size_t)wpg * 32 * 36 * 4 + (size_t)(a.Ccat / 4) * sizeof(GrpEnt) +
+                            (size_t)a.Ccat * 16 + (size_t)a.Ccat * 16;
+        const int ntiles = a.M / 32;
+        int streams = num_cus / cgroups;
+        if (streams > ntiles) streams = ntiles;
+        if (streams < 1) streams = 1;
+        static bool attr_split = false;
+        if (!attr_split) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad1x1_rows_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_split = true;
+        }
+        hipLaunchKernelGGL(dgrad1x1_rows_split_kernel, dim3(streams * cgroups), dim3(wpg * 64), smem, s, a, cgroups);
+        return hipGetLastError();
+    }
     const size_t smem = (size_t)DR_SLOTS * DR_SLOT + (size_t)nw * 32 * 36 * 4 + (size_t)(a.Ccat / 4) * sizeof(GrpEnt) + (size_t)a.Ccat * 16 + (size_t)a.Ccat * 16;
     const int ntiles = a.M / 32;
     const int bpc = smem <= 80 * 1024 && nw <= 6 ? 2 : 1;         // (12 waves per CU at most: three per SIMD at the kernel's register budget)
@@ -2082,7 +2265,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int load, int epi, int num_cus, hip
 hipError_t launch_conv_pair(const ConvArgs& a_in, const ConvArgs& b_in, int load, int epi, int num_cus, hipStream_t s) {
     if (!conv_pairable(a_in, b_in) || a_in.taps != 1) return hipErrorNotSupported;
     // (the row-tile data gradient gives every node the whole chip: no pair launch)
-    if (load == LD_PLAIN && epi == EP_BWD && a_in.dgrad_rows && dgrad1x1_rows_supported(a_in)) return hipErrorNotSupported;
+    if (load == LD_PLAIN && epi == EP_BWD && a_in.dgrad_rows > 0 && dgrad1x1_rows_supported(a_in) && a_in.M / 32 >= a_in.dgrad_rows) return hipErrorNotSupported;
     return launch_conv_impl(a_in, &b_in, load, epi, num_cus, s);
 }
 

@@ -266,8 +266,10 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
  *   "dgrad_rows"         fp32 1x1 data gradient of a 128-output-channel node: launches with at least this many 32-row tiles run the row-tile
  *                        kernel -- every input channel of a row tile in one workgroup, weights in registers, dY staged once per workgroup by
- *                        LDS-DMA instead of re-read by every 32-channel slice; 0 (default) = never: measured equal alone (1.60 vs 1.57 ms per
- *                        CU-Net-2 step) and 2.3 % slower in the step, where its nodes cannot share a launch as adapter pairs do
+ *                        LDS-DMA instead of re-read by every 32-channel slice; 0 = never.  Default (-1, the one negative value accepted): 3072 with f32_split (the tile is cut into
+ *                        its bf16 operand planes once per workgroup instead of once per column slice: +0.7 ... 1.7 % on the CU-Net-2 step when
+ *                        only the 64 x 64 launches of batch 24 take it), 0 on the fp32 matrix pipe (measured equal alone, 1.60 vs 1.57 ms per
+ *                        CU-Net-2 step, and 2.3 % slower in the step, where its nodes cannot share a launch as adapter pairs do)
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
  *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
  *                        measured equal (3504 vs 3491 img/s)

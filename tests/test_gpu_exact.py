@@ -501,8 +501,11 @@ def test_fused_weight_gradient_equals_the_separate_launches(n):
     assert c1['conv1x1_bwd_data'] == c0['conv1x1_bwd_data']
 
 
-def test_row_tile_data_gradient_agrees_with_the_sliced_kernel():
-    """dgrad1x1_rows_kernel (planner option dgrad_rows; round 4: all input channels of a row tile in one workgroup, weights in registers, dY
+@pytest.mark.parametrize('split', [1, 0])
+def test_row_tile_data_gradient_agrees_with_the_sliced_kernel(split):
+    """(split: planner option f32_split -- 1: dgrad1x1_rows_split_kernel, the tile cut into its bf16 operand planes once per workgroup,
+    against conv_body's split mode, which cuts it once per column slice: the same six products in the same order per element.)
+    dgrad1x1_rows_kernel (planner option dgrad_rows; round 4: all input channels of a row tile in one workgroup, weights in registers, dY
     staged once per workgroup by LDS-DMA in MFMA fragment order) against the column-sliced kernel (dgrad_rows = 0) on BASELINE config 2's
     shapes, whole backward: the same k-ordered MFMA chain per element, so dz is bit-identical and everything downstream agrees to the
     order of the fp64 BatchNorm reductions.  dgrad_rows = 1 sends EVERY eligible launch to the new kernel (grids smaller than the chip,
@@ -517,6 +520,7 @@ def test_row_tile_data_gradient_agrees_with_the_sliced_kernel():
     xd, td = x.cuda(), target.cuda()
     res = {}
     try:
+        set_planner_option('f32_split', split)
         for opt in (0, 1, 512):
             set_planner_option('dgrad_rows', opt)
             net = cu_net_amd.create_cu_net(**cfg)
@@ -532,7 +536,8 @@ def test_row_tile_data_gradient_agrees_with_the_sliced_kernel():
             res[opt] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True))
             del plan, net
     finally:
-        set_planner_option('dgrad_rows', 0)
+        set_planner_option('dgrad_rows', -1)     # (the default: by f32_split)
+        set_planner_option('f32_split', 1)      # (the default)
     l0, g0, t0 = res[0]
     assert torch.isfinite(g0).all() and float(g0.norm()) > 0
     for opt in (1, 512):
