@@ -297,6 +297,12 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     res['ms_per_step_median'] = statistics.median(per_step)
     cnt, ms, fl, by = prof[dominant]
     peak_mfma = PEAK_BF16_MFMA_TFLOPS if dominant.endswith('_bf16') else PEAK_F32_MFMA_TFLOPS      # classes that run on bf16 MFMA carry the suffix
+    # fp32 convolution classes on the split contraction (F32_SPLIT): six bf16 products per fp32 product -- the matrix-pipe ceiling of the
+    # class's fp32-equivalent flops is the bf16 peak / 6 (416.7 TFLOP/s), its ridge 52 flop/B: the 1x1 data gradient (24 flop/B at 192
+    # input channels) is bound by HBM there, not by the pipe
+    on_split = F32_SPLIT and not bf16 and not dominant.endswith('_bf16') and dominant.startswith('conv')
+    if on_split:
+        peak_mfma = PEAK_BF16_MFMA_TFLOPS / 6
     roof = None
     if have_classes and ms > 0:
         # the roof that bounds the class: arithmetic intensity of its algorithmic work against the ridge of ITS MFMA peak
@@ -317,6 +323,11 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
             if fl > 0:
                 roof['achieved_TFLOPs'] = round(fl / (ms * 1e-3) / 1e12, 2)
                 roof['arithmetic_intensity_flop_per_byte'] = round(ai, 1)
+        if on_split:
+            roof['matrix_pipe'] = ('bf16 MFMA, 6 products per fp32 product (planner option f32_split): ceiling %.1f TFLOP/s of fp32-equivalent work, '
+                                   'ridge %.0f flop/B' % (peak_mfma, ridge))
+            if fl > 0:
+                roof['frac_of_f32_mfma_peak'] = round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)      # (the denominator of rounds 1-3)
         wkey = f'{L},{K},{bs},{"f32" if not bf16 else mode}'
         tb, src = load_traffic(dominant, wkey)
         if tb is not None:
@@ -348,6 +359,7 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     return res
 
 
+F32_SPLIT = 1      # planner option f32_split as this process has it (main() follows --planner-opt and the fp32-pipe `also` line)
 SPLIT_NOTE = ('fp32 operands and fp32 accumulation on the bf16 matrix pipe: every operand value cut into three bf16 pieces (8 + 8 + 8 significand '
               'bits, exact), six v_mfma_f32_32x32x16_bf16 products per pair (planner option f32_split=1, the default); error against fp64 '
               'equal to the fp32 MFMA path (profiles/r04_split_bf16_probe.txt, tests/test_gpu_exact.py::test_backward_error_vs_fp64_tracks_torch_fp32); '
@@ -448,6 +460,8 @@ def main():
         cu_net_amd._lib.check(cu_net_amd._lib.lib().cunet_set_planner_option(name.encode(), int(val)), 'cunet_set_planner_option')
         if name == 'f32_split':
             split = int(val)
+    global F32_SPLIT
+    F32_SPLIT = split
     if rank == 0:
         log('library: %s  (%s)' % (cu_net_amd._lib.LIB_PATH, cu_net_amd._lib.lib().cunet_version().decode()))
     L, K, bs = args.layers, args.class_num, args.bs
@@ -490,12 +504,6 @@ def main():
         }
         if mode == 'fp32':
             out['contraction'] = SPLIT_NOTE if split else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32), planner option f32_split=0'
-            if split and out['roofline'] and out['roofline'].get('bound') == 'mfma':
-                # the class's algorithmic fp32 flops against the fp32 pipe's peak (the denominator of every earlier round) and against
-                # what the split contraction can reach at most: the bf16 pipe's peak / 6 products
-                out['roofline']['peak_note'] = ('fp32 dense MFMA peak; the class contracts on the bf16 pipe with 6 products per fp32 product: '
-                                                'its own ceiling is %.1f TFLOP/s of fp32-equivalent work (frac_of_split_peak)' % (PEAK_BF16_MFMA_TFLOPS / 6))
-                out['roofline']['frac_of_split_peak'] = round(out['roofline']['achieved'] / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
         for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
             if k in r:
                 out[k] = r[k]
@@ -519,11 +527,13 @@ def main():
             try:
                 if sp2 != split:
                     cu_net_amd._lib.set_planner_option('f32_split', sp2)
+                    F32_SPLIT = sp2
                 try:
                     e = measure(dev, pg, rank, world, l2, k2, bs, args.also_steps, max(3, args.warmup), m2, bw, fwd, pc, args.profile_out)
                 finally:
                     if sp2 != split:
                         cu_net_amd._lib.set_planner_option('f32_split', split)
+                        F32_SPLIT = split
                 ent = {'workload': name2, 'value': round(e['value'], 2), 'unit': 'images/sec', 'n_gpus': world,
                        'steps': args.also_steps, 'ms_per_step': round(e['ms_per_step'], 3), 'ms_per_step_median': round(e['ms_per_step_median'], 3),
                        'dtype': 'bf16' if m2 != 'fp32' else 'f32', 'roofline': e['roofline'], 'final_loss': e['final_loss']}

@@ -413,7 +413,7 @@ void Plan::layout_workspace() {
     {
         const int P = 32;
         const PlannerOptions& po = opts;
-        const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits));
+        const int min_chunks = std::max(1, tune_int("CUNET_WG3_MIN_CHUNKS", po.wgrad3_min_chunks)), smax = std::max(1, tune_int("CUNET_WG3_SMAX", po.wgrad3_max_splits > 0 ? po.wgrad3_max_splits : (po.f32_split ? 192 : 256)));
         const int min_m = tune_int("CUNET_WG3_MIN_M", po.wgrad3_min_rows), enable = tune_int("CUNET_WG3", 1);
         // bf16 gradient tensors (measured on CU-Net-8: 1340 img/s at 256 splits / 2 chunks, 1387 at 96 / 4, 1110 at 32)
         const int min_chunks16 = std::max(1, po.wgrad3_min_chunks_bf16), smax16 = std::max(1, po.wgrad3_max_splits_bf16);

@@ -243,7 +243,8 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        atomics-free kernel, smaller ones the per-wave atomic kernel (default 0: every eligible node --
  *                        measured best on MI355X; tests also run with a large value to keep the other kernel covered)
  *   "wgrad3_min_chunks"  at least this many 32-pixel chunks per workgroup of that kernel (default 2)
- *   "wgrad3_max_splits"  at most this many workgroups (= partial tiles) per launch (default 256)
+ *   "wgrad3_max_splits"  at most this many workgroups (= partial tiles) per launch; default 0 = 192 with f32_split (measured on the CU-Net-2 step:
+ *                        3906-3942 img/s at 256, 3983-4017 at 224, 4016-4024 at 192, 3994-4027 at 160, 3947-3966 at 128), 256 on the fp32 matrix pipe
  *   "wgrad3_min_chunks_bf16", "wgrad3_max_splits_bf16"   the same two with bf16 gradient tensors, where these kernels are
  *                        HBM-bound and fewer, longer splits win (defaults 4 and 128; 96 before the LDS-DMA kernel of round 4)
  *   "wgrad3_stem"        1 (default): the stem's 7x7 weight gradient on the LDS-staged atomics-free kernel where the shape
