@@ -1147,21 +1147,37 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     // The heads' backward depends on nothing but the loss gradient: all of it (data and weight gradient) goes to the side stream
     // up front, last U-Net first (the order the caller's stream will want the results in), one hand-over for all of them; the
     // caller's stream waits for head k's completion where head k's turn would have been.
+    // (round 4: a head's done event is recorded behind its DATA gradient -- what the caller's stream waits for -- and the heads' weight
+    // gradients follow behind all of them; heads_on_side = 2: the last U-Net's head, whose data gradient the caller's stream needs before
+    // anything else, runs that data gradient on the caller's stream itself)
     std::vector<char> head_done(P.nodes.size(), 0);
     if (h->use_side && h->side && P.opts.heads_on_side) {
         int first = -1;
+        std::vector<int> heads;
         for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
             const Node& n = P.nodes[k];
             if (n.type != N_CONV || n.head < 0) continue;
+            const bool own = first < 0 && P.opts.heads_on_side >= 2;
+            if (own) {
+                const int rc = bwd_node(h, n, k, s, s, BWD_MAIN);
+                if (rc != CUNET_OK) return rc;
+            }
             if (first < 0) {
                 first = k;
                 HIPCHK(hipEventRecord(h->fork_ev[k], s));
                 HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[k], 0));
             }
-            const int rc = bwd_node(h, n, k, h->side, h->side, BWD_MAIN | BWD_WGRAD);
+            if (!own) {
+                const int rc = bwd_node(h, n, k, h->side, h->side, BWD_MAIN);
+                if (rc != CUNET_OK) return rc;
+                HIPCHK(hipEventRecord(h->done_ev[k], h->side));
+            }
+            head_done[k] = own ? 2 : 1;
+            heads.push_back(k);
+        }
+        for (int k : heads) {
+            const int rc = bwd_node(h, P.nodes[k], k, h->side, h->side, BWD_WGRAD);
             if (rc != CUNET_OK) return rc;
-            HIPCHK(hipEventRecord(h->done_ev[k], h->side));
-            head_done[k] = 1;
         }
     }
     int cur_bucket = P.nodes.empty() ? -1 : P.nodes.back().bucket;
@@ -1205,8 +1221,8 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             cur_bucket = n.bucket;
             bucket_hi = k + 1;
         }
-        if (head_done[k]) {                // a head: its backward is on the side stream already
-            HIPCHK(hipStreamWaitEvent(s, h->done_ev[k], 0));
+        if (head_done[k]) {                // a head: its backward is on the side stream already (2: its data gradient ran on this stream)
+            if (head_done[k] == 1) HIPCHK(hipStreamWaitEvent(s, h->done_ev[k], 0));
             continue;
         }
         // the skip adapter of a pair (Node::pair on the node in front of it): both adapters' gradients are gathered first, then

@@ -259,9 +259,12 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "pair_adapters"      1 (default): the ahead and the skip adapter of a down block (two 1x1 convolutions over the same concat,
  *                        models/cu_net.py:139-142) share ONE launch, forward and data gradient, where the shape has a pair kernel;
  *                        0: one launch each (forward: the skip adapter on the side stream)
- *   "heads_on_side"      1 (default): in a training pass the heat-map heads (forward with the fused loss, data and weight gradient)
+ *   "heads_on_side"      1: in a training pass the heat-map heads (forward with the fused loss, data and weight gradient)
  *                        run on the internal side stream -- nothing on the caller's stream reads a head's output before the loss
- *                        is finalised, and its backward depends on the loss gradient only; 0: in node order on the caller's stream
+ *                        is finalised, and its backward depends on the loss gradient only; the caller's stream waits for a head's DATA
+ *                        gradient where the head's turn would be, the heads' weight gradients follow behind all of them.  2 (default): as
+ *                        1, but the last U-Net's head -- whose data gradient the caller's stream needs before anything else of backward --
+ *                        runs that data gradient on the caller's stream (+1 % on the CU-Net-2 step).  0: in node order on the caller's stream
  *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
  *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
