@@ -2209,7 +2209,16 @@ static TepiGeom tepi_geometry(const ConvArgs& a, int c, int ntiles, int ncol32, 
         g.smem = base + (size_t)wmax * CONV_TEPI_TILE * (fused ? 2 : 1);      // + one epilogue tile per wave (fused: + one transpose tile)
         if (g.smem <= (g.bpc == 3 ? 52 * 1024 : (g.bpc == 2 ? 80 * 1024 : CONV_LDS_BUDGET))) break;
     }
-    if (g.bpc < 1) return g;
+    if (g.bpc < 1) {
+        // one block per CU with fewer waves (a 3x3 operand on the split contraction with two channel tiles: 110 KB of planes leave room for
+        // eight epilogue tiles, not twelve)
+        for (int w : {8, 6, 4}) {
+            if (w >= g.maxw) continue;
+            g.smem = base + (size_t)w * CONV_TEPI_TILE * (fused ? 2 : 1);
+            if (g.smem <= CONV_LDS_BUDGET) { g.bpc = 1; g.maxw = w; break; }
+        }
+        if (g.bpc < 1) return g;
+    }
     const int max_blocks_x = (g.bpc * num_cus + g.gy - 1) / g.gy;
     g.waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
     if (g.waves > g.maxw / g.bpc) g.waves = g.maxw / g.bpc;
@@ -2325,6 +2334,10 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
         // (split contraction: the matrix pipe is no longer what a second tile per wave relieves, and the two- and four-tile instantiations
         // spill 10 - 27 registers: one tile per wave measured best, 3701 vs 3612 (model) / 3530 / 3573 img/s (forced 2 / 4))
         if (a.split && !greedy) cap = 1;
+        // the 3x3 data gradient (planner option dgrad3_nt, forced): every column slice gathers -- and, on the split contraction, cuts -- the
+        // nine shifted taps of dY again; 2 or 4 tiles per wave halve / remove that
+        bool greedy3 = false;
+        if (load == LD_PLAIN3 && a.dgrad3_nt > 1) { cap = a.dgrad3_nt > 4 ? 4 : a.dgrad3_nt; greedy3 = true; }
         for (int pass = 0; pass < 2 && !tg.ok; ++pass) {
             if (pass == 1) {
                 if (!a.split) break;
@@ -2334,7 +2347,7 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
                 const TepiGeom g = tepi_geometry(a, c, ntiles, ncol32, target, num_cus);
                 if (!g.ok) continue;
                 if (!tg.ok || g.est < tg.est) tg = g;
-                if (greedy) break;
+                if (greedy || greedy3) break;
             }
         }
         if (!tg.ok) return hipErrorInvalidValue;

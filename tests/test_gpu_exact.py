@@ -25,6 +25,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+DGRAD3_NT_DEFAULT = 1      # planner option dgrad3_nt as plan.h ships it
+
+
 @pytest.mark.parametrize('n,gscale', [(1 << 20, 1.0), (100003, 0.125), (7, 1.0)])
 def test_rmsprop_step_matches_torch(n, gscale):
     g = torch.Generator().manual_seed(n)
@@ -347,6 +350,48 @@ def test_dgrad_channel_tiles_per_wave_agree():
     for opt in (12, 13, 14, 4, 'pf2'):
         l1, g1, t1 = res[opt]
         assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)      # the forward does not depend on the option (fp64 atomics order only)
+        assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))
+        assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max()), (opt, float((t1 - t0).abs().max()), float(t0.abs().max()))
+
+
+@pytest.mark.parametrize('split', [1, 0])
+def test_3x3_data_gradient_channel_tiles_per_wave_agree(split):
+    """Planner option dgrad3_nt: the 3x3 data gradient with 2 and 4 channel tiles of dz per wave (the nine shifted taps of dY gathered -- and
+    on the split contraction cut -- once per 64 / 128 output channels instead of once per 32) against one tile per wave: the same chain of
+    products per element, so dz is bit-identical; parameter gradients agree to the order of the fp64 BatchNorm reductions.  BASELINE
+    config 2's shapes, whole backward (models/cu_net.py:45-48 backward)."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=93)
+    x, target = O.synthetic_batch(24, 68, 256, seed=94)
+    xd, td = x.cuda(), target.cuda()
+    res = {}
+    try:
+        set_planner_option('f32_split', split)
+        for opt in (1, 2, 4):
+            set_planner_option('dgrad3_nt', opt)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(24, 256, 256, True)
+            loss = plan.stage_target(td)
+            plan.forward(xd, True, want_outputs=False)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            d = plan.handle.describe()
+            first_pool = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][1]['out']][0]
+            res[opt] = (float(loss), net._grad_arena.clone(), plan.debug_tensor(first_pool, grad=True))
+            del plan, net
+    finally:
+        set_planner_option('dgrad3_nt', DGRAD3_NT_DEFAULT)
+        set_planner_option('f32_split', 1)      # (the default)
+    l0, g0, t0 = res[1]
+    assert torch.isfinite(g0).all() and float(g0.norm()) > 0
+    for opt in (2, 4):
+        l1, g1, t1 = res[opt]
+        assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))
         assert float((t1 - t0).abs().max()) <= 1e-5 * float(t0.abs().max()), (opt, float((t1 - t0).abs().max()), float(t0.abs().max()))
 
