@@ -513,6 +513,7 @@ def test_fused_weight_gradient_equals_the_separate_launches(n):
     xd, td = x.cuda(), target.cuda()
     res = {}
     try:
+        set_planner_option('f32_split', 0)      # (the fused tile loop is an fp32-matrix-pipe kernel: both arms on that pipe, launch for launch)
         for fuse in (0, 1):
             set_planner_option('fuse_wgrad', fuse)
             net = cu_net_amd.create_cu_net(**cfg)
@@ -535,6 +536,7 @@ def test_fused_weight_gradient_equals_the_separate_launches(n):
             del plan, net
     finally:
         set_planner_option('fuse_wgrad', 0)
+        set_planner_option('f32_split', 1)      # (the default)
     (l0, g0, t0, c0), (l1, g1, t1, c1) = res[0], res[1]
     assert abs(l1 - l0) <= 1e-6 * abs(l0)
     assert torch.isfinite(g1).all()
