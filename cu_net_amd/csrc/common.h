@@ -90,6 +90,8 @@ struct ConvArgs {
                            // of a row tile in one workgroup, dY staged once by LDS-DMA); 0 = always the column-sliced kernel (planner option dgrad_rows)
     int dgrad_prefetch;    // EP_BWD, fp32 1x1 over K = 128, one channel tile per wave: 2 = two chunks of dY in flight per wave (conv_body's PF2 loop),
                            // else one (the plan's snapshot of planner option dgrad_prefetch)
+    int dgrad3_ring;       // EP_BWD, fp32 3x3 on the split contraction: > 0 = launches over at least this many image rows run dgrad3x3_ring_split_kernel
+                           // (planner option dgrad3_ring)
     int dgrad3_nt;         // EP_BWD, fp32 3x3: 32-column tiles of dz a wave owns per row tile (planner option dgrad3_nt; 0 / 1 = one)
     int dgrad_nt;          // EP_BWD, fp32: most 32-column tiles of dz a wave owns per row tile (the plan's snapshot of planner option
                            // dgrad_nt; 0 = the default 4, 1 = one tile per wave as in rounds 2-3)

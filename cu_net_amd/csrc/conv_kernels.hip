@@ -1343,6 +1343,212 @@ static bool dgrad1x1_rows_supported(const ConvArgs& a) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 data gradient on a ring of dY rows, split contraction (round 4; planner options f32_split + dgrad3_ring):
+//     dz[m][c] = mask . sum_{tap, n} dY[m (+) tap][n] W_b[tap][n][c]      (32 -> 128 channels, autograd dgrad of models/cu_net.py:47)
+// The column-sliced kernel gathers the nine shifted taps of dY through per-lane global loads in every one of its four column slices
+// (47 us per launch alone for 113 MB at 64 x 64).  Here a 512-thread workgroup walks image rows of a 32-pixel strip as the forward's
+// conv3x3_ring_split_kernel does: a dY row enters the LDS ring ONCE, cut into its three bf16 planes on the way in (pixel = 3 x 64 bytes
+// + 16: conflict-free 16-byte fragment reads), a tap is an LDS offset.  Wave w owns output-channel tile (w & 3) and taps 0..4 (w < 4) or
+// 5..8, its weights cut once per launch in 120 registers; the second tap group hands its partial tile to the first through LDS, which
+// runs the BatchNorm / ReLU-backward epilogue of the other data gradients (x pieces -> wave-private LDS tile -> column pass -> dz pieces,
+// fp64 sums in LDS).  Row g + 2 of dY and the tile's x pieces are requested before the MFMAs of row g.
+constexpr int D3R_PIX = 208;            // bytes per ring pixel
+constexpr int D3R_SLOT = 34 * D3R_PIX;  // bytes per ring row
+
+__global__ __launch_bounds__(512, 2) void dgrad3x3_ring_split_kernel(const ConvArgs p, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = p.W, H = p.H;
+    // LDS: [ring 3 rows][part 4 x 4 KB][T tiles 4 x 32 x 36 floats][group table][sc sh mu is][fp64 sums 2 x 128]
+    char* ring = smem;
+    float* part = reinterpret_cast<float*>(smem + 3 * D3R_SLOT + 64);
+    float* tileT = part + 4 * 1024;
+    GrpEnt* grp = reinterpret_cast<GrpEnt*>(tileT + 4 * 32 * 36);
+    float* sc = reinterpret_cast<float*>(grp + (p.Ccat >> 2));
+    float* sh = sc + p.Ccat;
+    float* mu = sh + p.Ccat;
+    float* is = mu + p.Ccat;
+    double* redbuf = reinterpret_cast<double*>(is + p.Ccat);      // [128][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int nt = wave & 3;
+    const int grp1 = wave >> 2;                                   // tap group: 0 = taps 0..4, 1 = taps 5..8
+    const int nstrip = W >> 5;
+    const int strip = blockIdx.x % nstrip;
+    const int x0 = strip * 32;
+
+    setup_concat<true, 0>(p, grp, sc, sh, mu, is);
+    for (int i = tid; i < 2 * 128; i += 512) redbuf[i] = 0.0;
+    for (int i = tid; i < (3 * D3R_SLOT + 64) / 16; i += 512)     // pixels outside the image stay zero for the whole launch
+        reinterpret_cast<float4*>(ring)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this wave's weights, cut: tap t (5 grp1 + u), step s2 = k 16 s2 + 8 hi .. + 7, column 32 nt + li of the backward operand
+    // [tap][K / 4 = 8][Npad][4] (float4 rows 8 t + 4 s2 + 2 hi, + 1)
+    u32x4 bh[10], bm[10], bl[10];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        int t = grp1 * 5 + u;
+        if (t > 8) t = 8;                                         // (the second group's fifth slot: not contracted)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int row = t * 8 + 4 * s2 + 2 * hi;
+            const float4 w0 = ldg4(p.wB + ((size_t)row * p.Npad + nt * 32 + li) * 4);
+            const float4 w1 = ldg4(p.wB + ((size_t)(row + 1) * p.Npad + nt * 32 + li) * 4);
+            const float f[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            split_bf16x3(f, bh[2 * u + s2], bm[2 * u + s2], bl[2 * u + s2]);
+        }
+    }
+
+    const int NH = p.M / W;                                       // image rows in the batch
+    const int g_begin = (blockIdx.x / nstrip) * rows_per_wg;
+    int g_end = g_begin + rows_per_wg;
+    if (g_end > NH) g_end = NH;
+
+    // staging plan: a ring row is 34 pixels x 8 float4 of dY; thread t < 272 takes float4 t
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+    const int spix = tid >> 3, sc4 = (tid & 7) << 2;              // ring pixel 0 .. 33 (threads 0 .. 271), first channel
+    const int sx = x0 - 1 + spix;
+    const bool sactive = tid < 272 && sx >= 0 && sx < W;
+    // (a row is requested a whole iteration before it is cut into the ring: two register sets)
+    f32x4n dv, dvn;
+    bool dok = false, dokn = false;
+    auto issue_d = [&](int g, f32x4n& v, bool& ok) {
+        ok = g >= 0 && g < NH;
+        const size_t base = (size_t)(ok ? g : 0) * W + (sactive ? sx : 0);
+        v = *reinterpret_cast<const f32x4n*>(p.a + base * p.lda + sc4);
+    };
+    auto commit_d = [&](int g) {
+        if (!dok || !sactive) return;
+        char* slot = ring + (size_t)(((g % 3) + 3) % 3) * D3R_SLOT;
+        u32x2n ph, pm, pl;
+        unsigned a0, a1, a2;
+        split_bf16x3_pair(f32x2_op{dv[0], dv[1]}, a0, a1, a2);
+        ph[0] = a0; pm[0] = a1; pl[0] = a2;
+        split_bf16x3_pair(f32x2_op{dv[2], dv[3]}, a0, a1, a2);
+        ph[1] = a0; pm[1] = a1; pl[1] = a2;
+        char* d = slot + spix * D3R_PIX + sc4 * 2;
+        *reinterpret_cast<u32x2n*>(d) = ph;
+        *reinterpret_cast<u32x2n*>(d + 64) = pm;
+        *reinterpret_cast<u32x2n*>(d + 128) = pl;
+    };
+    __syncthreads();                                              // zeros and tables visible
+    for (int g = g_begin - 1; g <= g_begin + 1; ++g) { issue_d(g, dv, dok); commit_d(g); }
+    issue_d(g_begin + 2, dvn, dokn);
+
+    // epilogue state of the first tap group's waves: column, BatchNorm constants, the x pieces of a 32 x 32 tile
+    const int col = nt * 32 + li;
+    const float csc = sc[col], csh = sh[col], cmu = mu[col], cis = is[col];
+    const int pc4 = lane & 7, pr0 = lane >> 3;
+    const float* xbase = p.seg[0].x + nt * 32 + 4 * pc4;
+    const int xld = p.seg[0].ld;
+    float* T = tileT + (size_t)nt * 32 * 36;
+    float* mypart = part + nt * 1024;
+    float4 xp[4], xn[4];
+    auto request_x = [&](int g, float4 (&o)[4]) {                 // the x pieces of row g's tile (first tap group's waves)
+        const size_t mm = (size_t)g * W + x0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ldg4(xbase + (mm + pr0 + 8 * j) * xld);
+    };
+    if (grp1 == 0 && g_begin < g_end) request_x(g_begin, xp);
+    __syncthreads();
+
+    for (int g = g_begin; g < g_end; ++g) {
+        const int y = g % H;
+        dv = dvn; dok = dokn;                                     // row g + 2, requested one iteration ago
+        issue_d(g + 3, dvn, dokn);                                // in flight across this whole iteration
+        const size_t m0 = (size_t)g * W + x0;                     // first output row of this tile
+        if (grp1 == 0) request_x(g + 1 < g_end ? g + 1 : g, xn);  // the next tile's x pieces likewise
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int t = grp1 * 5 + u;
+            if (t > 8) break;
+            const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+            if (y + dy < 0 || y + dy >= H) continue;              // (block-uniform: the row outside the image contributes zeros)
+            const char* ap = ring + (size_t)((g + dy + 3) % 3) * D3R_SLOT + (li + dx + 1) * D3R_PIX + 16 * hi;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ap + 32 * s2);
+                const u32x4 am = *reinterpret_cast<const u32x4*>(ap + 32 * s2 + 64);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(ap + 32 * s2 + 128);
+                acc = mfma_split6(ah, am, al, bh[2 * u + s2], bm[2 * u + s2], bl[2 * u + s2], acc);
+            }
+        }
+        if (grp1 == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mypart[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();                                          // partial tiles written; every wave is done reading the ring rows of g
+        commit_d(g + 2);                                          // (into the ring row of g - 1)
+        if (grp1 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += mypart[r * 64 + lane];
+            // BatchNorm / ReLU backward, first half (as conv_body's LDS-tile epilogue)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * 36 + 4 * pc4) = xp[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float s1 = 0.f, s2v = 0.f;
+            float* tcol = T + li;
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fmaf(xv[r], csc, csh);
+                const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[r] : 0.f;      // ReLU mask (+ QuanInput's straight-through mask)
+                s1 += dz;
+                s2v = fmaf(dz, (xv[r] - cmu) * cis, s2v);
+                xv[r] = dz;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36] = xv[r];
+            atomicAdd(&redbuf[col * 2 + 0], (double)s1);
+            atomicAdd(&redbuf[col * 2 + 1], (double)s2v);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = pr0 + 8 * j;
+                *reinterpret_cast<float4*>(p.y + (m0 + rr) * p.ldy + nt * 32 + 4 * pc4) = *reinterpret_cast<const float4*>(T + rr * 36 + 4 * pc4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's pieces overwrite T)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xp[j] = xn[j];
+        }
+        __syncthreads();                                          // the new ring row is complete; the partial tiles have been read
+    }
+    if (p.ystats != nullptr && tid < 128) {
+        atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
+        atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
+    }
+}
+
+static bool dgrad3x3_ring_supported(const ConvArgs& a) {
+    return a.split && a.taps == 9 && a.K == 32 && a.Kpad == 32 && a.Nout == 128 && a.Ccat == 128 && a.ldy == 128 && a.xbf16 == 0 && a.nseg == 1 &&
+           !a.seg[0].ups && a.seg[0].C == 128 && a.seg[0].ld % 4 == 0 && a.lda % 4 == 0 && (a.W == 64 || a.W == 32) && a.M % a.W == 0 &&
+           a.wg_part == nullptr && a.mse_tgt == nullptr && a.Npad >= 128;
+}
+
+static hipError_t launch_dgrad3x3_ring(const ConvArgs& a, int num_cus, hipStream_t s) {
+    const int NH = a.M / a.W;
+    const int nstrip = a.W / 32;
+    int rows = (NH * nstrip + num_cus - 1) / num_cus;
+    if (rows < 2) rows = 2;
+    const int grid = ((NH + rows - 1) / rows) * nstrip;
+    const size_t smem = (size_t)3 * D3R_SLOT + 64 + (size_t)4 * 4096 + (size_t)4 * 32 * 36 * 4 + (size_t)(a.Ccat / 4) * sizeof(GrpEnt) +
+                        (size_t)a.Ccat * 16 + (size_t)128 * 16;
+    hipLaunchKernelGGL(dgrad3x3_ring_split_kernel, dim3(grid), dim3(512), smem, s, a, rows);
+    return hipGetLastError();
+}
+
 static hipError_t launch_dgrad1x1_rows(const ConvArgs& a_in, int num_cus, hipStream_t s) {
     ConvArgs a = a_in;
     set_geometry_shifts(a);
@@ -1771,18 +1977,19 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
     const int c4 = (tid & 31) << 2;
     const float4 s4 = *reinterpret_cast<const float4*>(sc + c4);
     const float4 h4 = *reinterpret_cast<const float4*>(sh + c4);
-    f32x4n xv[3];
-    bool xok = false;
-    auto issue_x = [&](int g) {
-        xok = g >= 0 && g < NH;
-        const size_t base = (size_t)(xok ? g : 0) * W;
+    // (a row is requested a whole iteration before it is cut into the ring: two register sets)
+    f32x4n xv[3], xvn[3];
+    bool xok = false, xokn = false;
+    auto issue_x = [&](int g, f32x4n (&v)[3], bool& ok) {
+        ok = g >= 0 && g < NH;
+        const size_t base = (size_t)(ok ? g : 0) * W;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             int idx = tid + R3_THREADS * j;
             if (idx >= NX4) idx = NX4 - 1;
             int x = x0 - 1 + (idx >> 5);
             x = x < 0 ? 0 : (x >= W ? W - 1 : x);                 // (clamped: the load stays unconditional, commit_x skips the pixel)
-            xv[j] = *reinterpret_cast<const f32x4n*>(sg.x + (base + x) * sg.ld + c4);
+            v[j] = *reinterpret_cast<const f32x4n*>(sg.x + (base + x) * sg.ld + c4);
         }
     };
     auto commit_x = [&](int g) {
@@ -1816,13 +2023,17 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
         }
     };
 
-    for (int g = g_begin - 1; g <= g_begin + 1; ++g) { issue_x(g); commit_x(g); }
+    for (int g = g_begin - 1; g <= g_begin + 1; ++g) { issue_x(g, xv, xok); commit_x(g); }
+    issue_x(g_begin + 2, xvn, xokn);
     __syncthreads();
 
     double dsum = 0.0, dsq = 0.0;
     for (int g = g_begin; g < g_end; ++g) {
         const int y = g % H;
-        issue_x(g + 2);                                           // in flight across this row's MFMAs
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xv[j] = xvn[j];               // row g + 2, requested one iteration ago
+        xok = xokn;
+        issue_x(g + 3, xvn, xokn);                                // in flight across this whole iteration
         const bool rvalid = (y + dy >= 0) && (y + dy < H);
         const bool xvalid = y + 1 < H;                            // tap 8 = (dy, dx) = (+1, +1)
         const int sl = (g + dy + 3) % 3, slx = (g + 1) % 3;
@@ -2283,6 +2494,9 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 32);      // 3x3 forward on the LDS row ring at this width and above (64 and 32: +0.4 % over 64 only)
     if (!b_in && load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= (a_in.ring_min_rows > 0 ? a_in.ring_min_rows : 512))
         return launch_conv3x3_ring(a_in, num_cus, s);
+    // fp32 3x3 data gradient at 64 x 64 / 32 x 32 on the split contraction: the dY row ring (planner option dgrad3_ring = least image rows)
+    if (!b_in && load == LD_PLAIN3 && epi == EP_BWD && a_in.dgrad3_ring > 0 && dgrad3x3_ring_supported(a_in) && a_in.M / a_in.W >= a_in.dgrad3_ring)
+        return launch_dgrad3x3_ring(a_in, num_cus, s);
     // fp32 1x1 data gradient of a 128-output-channel node with 128 ... 320 input channels: every column of a row tile in one workgroup, dY
     // staged once (dgrad1x1_rows_kernel); planner option dgrad_rows = the least number of 32-row tiles per launch that takes it
     if (!b_in && load == LD_PLAIN && epi == EP_BWD && a_in.dgrad_rows > 0 && dgrad1x1_rows_supported(a_in) && a_in.M / 32 >= a_in.dgrad_rows)

@@ -176,6 +176,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "dgrad_rows") o.dgrad_rows = value;
     else if (n == "f32_split") o.f32_split = value;
     else if (n == "dgrad3_nt") o.dgrad3_nt = value;
+    else if (n == "dgrad3_ring") o.dgrad3_ring = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -549,6 +550,7 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
     a.dgrad_nt = P.opts.dgrad_nt;
     a.dgrad3_nt = P.opts.dgrad3_nt;
+    a.dgrad3_ring = P.opts.dgrad3_ring;
     a.dgrad_prefetch = P.opts.dgrad_prefetch;
     // (default -1: with the split contraction the 64 x 64 launches -- 3072 row tiles at batch 24 -- take the row-tile kernel, which cuts dY
     // into its bf16 pieces once per workgroup instead of once per column slice: +0.7 ... 1.7 % on the CU-Net-2 step; on the fp32 pipe never)

@@ -268,6 +268,10 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
  *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
+ *   "dgrad3_ring"        fp32 3x3 data gradient on the split contraction: launches over at least this many image rows (N * H; default 768 = the
+ *                        64 x 64 and 32 x 32 levels at batch 24; 0 = never) walk image rows of a 32-pixel strip with dY in an LDS ring, every
+ *                        element cut into its bf16 pieces once (dgrad3x3_ring_split_kernel) instead of gathering nine shifted taps per
+ *                        column slice: class 0.55 -> 0.50 ms per CU-Net-2 step alone, step +1.0 ... 1.7 %
  *   "dgrad3_nt"          fp32 3x3 data gradient: 32-channel tiles of dz a wave owns per row tile (1 = default, 2; 4 does not fit the LDS next to
  *                        the operand's three planes): the nine shifted taps of dY gathered (and cut) once per 64 output channels instead of
  *                        once per 32.  Measured: class 0.540 -> 0.526 ms per CU-Net-2 step alone, step +-0

@@ -53,6 +53,30 @@ def test_every_node_backward_full_width():
     _check_all_nodes(cfg, st, x)
 
 
+@pytest.mark.parametrize('n', [1, 5])
+def test_every_node_backward_with_the_row_ring_kernels_forced(n):
+    """The row-walking kernels of the split contraction on EVERY launch they support instead of the large ones only (planner options
+    dgrad3_ring = 1: dgrad3x3_ring_split_kernel; conv3x3_ring_min_rows = 1: conv3x3_ring_split_kernel; dgrad_rows = 1:
+    dgrad1x1_rows_split_kernel): one and five images (five: 320 image rows at 64 x 64 in ranges of three, so a workgroup's row range starts and ends inside an image and crosses image
+    boundaries (the rows above / below an image edge must contribute zeros, not the neighbouring image's rows) and the launch has
+    fewer row blocks than CUs.  Node by node against autograd on identical inputs (models/cu_net.py:45-48 and its backward)."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=23)
+    x, _ = O.synthetic_batch(n, 68, 256, seed=24)
+    try:
+        set_planner_option('dgrad3_ring', 1)
+        set_planner_option('conv3x3_ring_min_rows', 1)
+        set_planner_option('dgrad_rows', 1)
+        _check_all_nodes(cfg, st, x, check_forward=True)
+    finally:
+        set_planner_option('dgrad3_ring', 768)               # (the defaults)
+        set_planner_option('conv3x3_ring_min_rows', 512)
+        set_planner_option('dgrad_rows', -1)
+
+
 @pytest.mark.parametrize('mode', [False, True, 2])
 def test_every_node_backward_full_width_wgrad3(mode):
     """The LDS-staged, atomics-free 1x1 weight gradient (wgrad3: fp32 MFMA on fp32 / bf16 activations, bf16 MFMA with bf16

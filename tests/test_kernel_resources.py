@@ -33,6 +33,8 @@ EXPECT = {
         'conv_pair_kernelILi2ELi1ELi1ELb1ELi6E': 128,
         'conv_kernelILi3ELi1ELi1ELb1ELi6E': 128,
         'conv3x3_ring_split_kernel': 256,
+        'dgrad3x3_ring_split_kernel': 256,
+        'dgrad1x1_rows_split_kernel': 256,
     },
     'wgrad3_kernels.hip': {
         'wgrad3_kernelILi5ELb0ELi0ELb1E': 256,             # 1x1 weight gradient, 320 channels, split contraction
