@@ -150,7 +150,7 @@ static int plan_fused_wgrads(cunet_plan* h);      // (defined behind the executo
 extern "C" {
 
 const char* cunet_last_error(void) { return g_err.c_str(); }
-const char* cunet_version(void) { return "cunet-hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* cunet_version(void) { return "cunet-hip 0.2 (gfx950; fp32 mode: split-bf16 or fp32 MFMA by planner option f32_split; bf16 storage: bf16 MFMA)"; }
 
 int cunet_set_planner_option(const char* name, int value) {
     if (!name) return fail(CUNET_ERR_INVALID, "bad planner option");
