@@ -1344,6 +1344,210 @@ static bool dgrad1x1_rows_supported(const ConvArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stem forward (conv0 7x7 / 2, pad 3, 3 -> 128 channels, models/cu_net.py:300) on image rows in LDS, split contraction (round 4).
+// conv_kernel<LD_STEM> gathers its A operand element by element through an im2col address computation per load (206 us, the longest
+// launch of the step; bound by that VALU work).  Here a 512-thread workgroup walks OUTPUT rows: the seven input rows an output row
+// reads live in an LDS ring of eight row slots, each element cut into its three bf16 pieces ONCE on the way in (a slot = 3 channels x
+// 3 planes x (IW + 8) bf16, four zero elements in front: element e = ix + 4).  The contraction's k is re-ordered so that a lane's eight
+// k-values of a step are eight CONSECUTIVE input pixels of one (channel, kernel row): for output pixel ox they start at e = 2 ox -- a
+// dword-aligned LDS address with no arithmetic beyond a per-row offset -- and cover kx = -1 .. 6, the first with a zero weight.  Step
+// s = (channel, kernel row) pairs 2 s and 2 s + 1 (one per lane half), 11 steps for the 21 pairs.  Wave w owns output-channel tile w & 3
+// and two of the row's four 32-pixel tiles, its weights cut once per launch in 132 registers.  The two new input rows of the next
+// output row are requested before the MFMAs of the current one.
+constexpr int STF_STEPS = 11;
+
+__global__ __launch_bounds__(512, 2) void stem_fwd_split_kernel(const ConvArgs p, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int IW = p.IW, IH = p.IH, OW = p.W, OH = p.H;
+    const int RP = 2 * IW + 16;                                   // bytes of one (channel, plane) row
+    const int SLOT = 9 * RP;
+    char* ring = smem;                                            // 8 slots
+    double* redbuf = reinterpret_cast<double*>(smem + 8 * SLOT);  // [128][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int nt = wave & 3;
+    const int th = wave >> 2;                                     // tiles 2 th, 2 th + 1 of the row (and th + 2 ... for wider rows)
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+
+    for (int i = tid; i < 8 * SLOT / 16; i += 512) reinterpret_cast<float4*>(ring)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 256; i += 512) redbuf[i] = 0.0;
+
+    // weights: step s, lane (column 32 nt + li, half hi) = pair q = 2 s + hi = (channel q / 7, kernel row q % 7), slot j = kx + 1 (j = 0
+    // and the 22nd pair: zero); packed operand [k / 4][Npad][4] with k = 49 c + 7 ky + kx
+    u32x4 bh[STF_STEPS], bm[STF_STEPS], bl[STF_STEPS];
+    const int q_lane0 = hi;                                       // q = 2 s + hi
+#pragma unroll
+    for (int s8 = 0; s8 < STF_STEPS; ++s8) {
+        const int q = 2 * s8 + q_lane0;
+        float f[8];
+        f[0] = 0.f;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            const int k = q * 7 + (j - 1);                        // = 49 c + 7 ky + kx
+            f[j] = (q < 21) ? ldg1(p.wB + ((size_t)(k >> 2) * p.Npad + nt * 32 + li) * 4 + (k & 3)) : 0.f;
+        }
+        split_bf16x3(f, bh[s8], bm[s8], bl[s8]);
+    }
+
+    // staging plan: an input row is 3 channels x IW / 4 float4; two rows per output row: thread t takes float4 t of the pair
+    const int per_row = 3 * (IW >> 2);
+    const int NR = p.M / OW;                                     // output rows in the batch
+    const int r_begin = blockIdx.x * rows_per_wg;
+    int r_end = r_begin + rows_per_wg;
+    if (r_end > NR) r_end = NR;
+    auto stage_item = [&](int n, int iy, int it, f32x4n& v) {     // request float4 `it` of input row iy of image n (zeros outside the image)
+        const int c = it / (IW >> 2), x4 = (it - c * (IW >> 2)) << 2;
+        const bool ok = iy >= 0 && iy < IH;
+        const f32x4n z = {0.f, 0.f, 0.f, 0.f};
+        v = ok ? *reinterpret_cast<const f32x4n*>(p.img + ((size_t)(n * 3 + c) * IH + iy) * IW + x4) : z;
+    };
+    auto commit_item = [&](int iy, int it, const f32x4n& v) {     // cut and write into slot (iy + 3) & 7
+        const int c = it / (IW >> 2), x4 = (it - c * (IW >> 2)) << 2;
+        char* d = ring + (size_t)((iy + 3) & 7) * SLOT + (size_t)(c * 3) * RP + (x4 + 4) * 2;
+        u32x2n ph, pm, pl;
+        unsigned a0, a1, a2;
+        split_bf16x3_pair(f32x2_op{v[0], v[1]}, a0, a1, a2);
+        ph[0] = a0; pm[0] = a1; pl[0] = a2;
+        split_bf16x3_pair(f32x2_op{v[2], v[3]}, a0, a1, a2);
+        ph[1] = a0; pm[1] = a1; pl[1] = a2;
+        *reinterpret_cast<u32x2n*>(d) = ph;
+        *reinterpret_cast<u32x2n*>(d + RP) = pm;
+        *reinterpret_cast<u32x2n*>(d + 2 * RP) = pl;
+    };
+    auto stage_rows_blocking = [&](int n, int oy, int ky0, int ky1) {      // input rows 2 oy - 3 + ky, ky0 <= ky < ky1
+        for (int ky = ky0; ky < ky1; ++ky)
+            for (int it = tid; it < per_row; it += 512) {
+                f32x4n v;
+                stage_item(n, 2 * oy - 3 + ky, it, v);
+                commit_item(2 * oy - 3 + ky, it, v);
+            }
+    };
+    __syncthreads();                                              // zeros in place
+    if (r_begin < r_end) stage_rows_blocking(r_begin / OH, r_begin % OH, 0, 7);
+    __syncthreads();
+
+    double dsum = 0.0, dsq = 0.0;                                 // this lane's column, summed over its rows
+    for (int R = r_begin; R < r_end; ++R) {
+        const int n = R / OH, oy = R - n * OH;
+        // the next output row's two new input rows (2 oy + 4, 2 oy + 5): requested now, cut into the ring after this row's MFMAs
+        const bool more = R + 1 < r_end;
+        const bool next_same = more && oy + 1 < OH;
+        f32x4n pv[2];
+        int pit[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pit[u] = tid + 512 * u;
+            const int row = pit[u] / per_row, it = pit[u] - row * per_row;
+            const f32x4n z = {0.f, 0.f, 0.f, 0.f};
+            pv[u] = z;
+            if (next_same && pit[u] < 2 * per_row) stage_item(n, 2 * oy + 4 + row, it, pv[u]);
+        }
+        const int ntx = OW >> 5;
+        for (int tx = 2 * th; tx < ntx; tx += 4) {                // (two consecutive tiles per wave and pass: OW = 128 -> one pass)
+#pragma unroll 1
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int txx = tx + t2;
+                if (txx >= ntx) break;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const char* abase = ring + 4 * (txx * 32 + li);
+                auto fetch_a = [&](int s8, u32x4& h, u32x4& m, u32x4& l) {
+                    // LDS row of this lane's (channel, kernel row) pair of the step (computed here: eleven offsets held across the tile
+                    // loop cost eleven registers of a budget the weights fill)
+                    int q = 2 * s8 + hi;
+                    q = q < 21 ? q : 20;                          // (the 22nd pair: any valid address, its weights are zero)
+                    const int c = (q * 37) >> 8, ky = q - c * 7;  // q / 7 for q <= 20
+                    const int ro = ((2 * oy + ky) & 7) * SLOT + c * 3 * RP;
+                    const unsigned* a0 = reinterpret_cast<const unsigned*>(abase + ro);
+                    const unsigned* a1 = reinterpret_cast<const unsigned*>(abase + ro + RP);
+                    const unsigned* a2 = reinterpret_cast<const unsigned*>(abase + ro + 2 * RP);
+                    h = u32x4{a0[0], a0[1], a0[2], a0[3]};
+                    m = u32x4{a1[0], a1[1], a1[2], a1[3]};
+                    l = u32x4{a2[0], a2[1], a2[2], a2[3]};
+                };
+                // one step ahead, pinned: left alone hipcc requests all eleven steps' fragments of both tiles up front (231 spilled registers)
+                u32x4 ah, am, al;
+                fetch_a(0, ah, am, al);
+#pragma unroll
+                for (int s8 = 0; s8 < STF_STEPS; ++s8) {
+                    u32x4 nh = ah, nm = am, nl = al;
+                    if (s8 + 1 < STF_STEPS) fetch_a(s8 + 1, nh, nm, nl);
+                    acc = mfma_split6(ah, am, al, bh[s8], bm[s8], bl[s8], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ah = nh; am = nm; al = nl;
+                }
+                // C layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 hi (pixel)
+                float s1 = 0.f, s2 = 0.f;
+                const size_t m0 = ((size_t)R * OW + txx * 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float v = acc[r];
+                    p.y[(m0 + px) * p.ldy + nt * 32 + li] = v;
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                }
+                dsum += (double)s1;
+                dsq += (double)s2;
+            }
+        }
+        __syncthreads();                                          // every wave is done reading this row's slots
+        if (more) {
+            if (next_same) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (pit[u] < 2 * per_row) {
+                        const int row = pit[u] / per_row, it = pit[u] - row * per_row;
+                        commit_item(2 * oy + 4 + row, it, pv[u]);
+                    }
+                }
+            } else {
+                stage_rows_blocking((R + 1) / OH, 0, 0, 7);       // a new image: all seven rows (three of them zero)
+            }
+        }
+        __syncthreads();
+    }
+    if (p.ystats != nullptr) {
+        const double a = dsum + shfl_xor_d(dsum, 32), b = dsq + shfl_xor_d(dsq, 32);
+        if (hi == 0) {
+            atomicAdd(&redbuf[(nt * 32 + li) * 2 + 0], a);
+            atomicAdd(&redbuf[(nt * 32 + li) * 2 + 1], b);
+        }
+        __syncthreads();
+        if (tid < 128) {
+            atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
+            atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
+        }
+    }
+}
+
+static bool stem_fwd_split_supported(const ConvArgs& a) {
+    return a.split && a.K == 147 && a.Nout == 128 && a.Npad >= 128 && a.Kpad >= 148 && a.IW % 64 == 0 && a.IH % 2 == 0 && a.H * 2 == a.IH &&
+           a.W * 2 == a.IW && a.M % (a.H * a.W) == 0 && a.IW <= 512 && a.mse_tgt == nullptr && a.qin_bits == 0;
+}
+
+static hipError_t launch_stem_fwd_split(const ConvArgs& a, int num_cus, hipStream_t s) {
+    const int NR = a.M / a.W;                                     // output rows in the batch
+    int rows = (NR + num_cus - 1) / num_cus;
+    if (rows < 1) rows = 1;
+    const int grid = (NR + rows - 1) / rows;
+    const size_t smem = (size_t)8 * 9 * (2 * a.IW + 16) + 256 * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(stem_fwd_split_kernel, dim3(grid), dim3(512), smem, s, a, rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 data gradient on a ring of dY rows, split contraction (round 4; planner options f32_split + dgrad3_ring):
 //     dz[m][c] = mask . sum_{tap, n} dY[m (+) tap][n] W_b[tap][n][c]      (32 -> 128 channels, autograd dgrad of models/cu_net.py:47)
 // The column-sliced kernel gathers the nine shifted taps of dY through per-lane global loads in every one of its four column slices
@@ -2494,6 +2698,8 @@ static hipError_t launch_conv_impl(const ConvArgs& a_in, const ConvArgs* b_in, i
     static const int ring_min_w = tune_int("CUNET_CONV_RING_MINW", 32);      // 3x3 forward on the LDS row ring at this width and above (64 and 32: +0.4 % over 64 only)
     if (!b_in && load == LD_3X3 && epi == EP_FWD && conv3x3_ring_supported(a_in) && a_in.W >= ring_min_w && a_in.M / a_in.W >= (a_in.ring_min_rows > 0 ? a_in.ring_min_rows : 512))
         return launch_conv3x3_ring(a_in, num_cus, s);
+    // the stem on the split contraction: output rows over an LDS ring of cut input rows (planner option stem_split)
+    if (!b_in && load == LD_STEM && epi == EP_FWD && a_in.split && stem_fwd_split_supported(a_in)) return launch_stem_fwd_split(a_in, num_cus, s);
     // fp32 3x3 data gradient at 64 x 64 / 32 x 32 on the split contraction: the dY row ring (planner option dgrad3_ring = least image rows)
     if (!b_in && load == LD_PLAIN3 && epi == EP_BWD && a_in.dgrad3_ring > 0 && dgrad3x3_ring_supported(a_in) && a_in.M / a_in.W >= a_in.dgrad3_ring)
         return launch_dgrad3x3_ring(a_in, num_cus, s);

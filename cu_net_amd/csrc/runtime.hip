@@ -177,6 +177,7 @@ int cunet_set_planner_option(const char* name, int value) {
     else if (n == "f32_split") o.f32_split = value;
     else if (n == "dgrad3_nt") o.dgrad3_nt = value;
     else if (n == "dgrad3_ring") o.dgrad3_ring = value;
+    else if (n == "stem_split") o.stem_split = value;
     else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
     return CUNET_OK;
 }
@@ -871,6 +872,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             a.img = x; a.IH = P.cfg.height; a.IW = P.cfg.width;
+            a.split = (P.opts.f32_split && P.opts.stem_split) ? 1 : 0;
             PROF(PC_STEMF, 2.0 * a.M * a.K * a.Nout, 4.0 * ((double)a.M * a.Nout + (double)o.N * 3 * a.IH * a.IW), launch_conv(a, LD_STEM, EP_FWD, cus, s));
         } else if (n.type == N_STEM_BNPOOL || n.type == N_POOL) {
             const int tin = n.segs[0].tensor;
@@ -974,6 +976,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             a.y = E.act(n.out); a.ldy = o.ld; a.Nout = c.Cout; a.ystats = training ? E.stats(n.out) : nullptr;
             a.M = (int)o.rows(); a.H = o.H; a.W = o.W;
             a.img = x; a.IH = P.cfg.height; a.IW = P.cfg.width;
+            a.split = (P.opts.f32_split && P.opts.stem_split) ? 1 : 0;
             HIPCHK(launch_conv(a, LD_STEM, EP_FWD, cus, s));
         } else if (n.type == N_STEM_BNPOOL) {
             const int tin = n.segs[0].tensor;

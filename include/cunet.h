@@ -268,6 +268,10 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "dgrad_nt"           fp32 1x1 data gradient: a wave owns up to this many 32-channel tiles of dz for its 32 rows (default 4): dY is
  *                        read once per dgrad_nt * 32 output channels and each of its fragments feeds that many independent MFMA
  *                        accumulator chains; 1 = one tile per wave (rounds 2-3: dY re-read by every 32-channel slice)
+ *   "stem_split"         1 (default; with f32_split): the stem's 7x7 / 2 convolution walks output rows over an LDS ring of input rows, every
+ *                        image element cut into its bf16 pieces once, the contraction's k re-ordered to (channel, kernel row) x 8 consecutive
+ *                        pixels (stem_fwd_split_kernel): 206 -> 106 us per launch at batch 24 (CU-Net-2 step +1.6 %, eval forward +6 %);
+ *                        0: the im2col-gather kernel on the fp32 matrix pipe.  Also used by the bf16 storage modes (their stem is fp32)
  *   "dgrad3_ring"        fp32 3x3 data gradient on the split contraction: launches over at least this many image rows (N * H; default 768 = the
  *                        64 x 64 and 32 x 32 levels at batch 24; 0 = never) walk image rows of a 32-pixel strip with dY in an LDS ring, every
  *                        element cut into its bf16 pieces once (dgrad3x3_ring_split_kernel) instead of gathering nine shifted taps per

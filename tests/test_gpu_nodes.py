@@ -124,6 +124,49 @@ def test_every_node_backward_rectangular_full_width(mode):
     _check_all_nodes(cfg, st, x, bf16=mode, wgrad3_all=True)
 
 
+@pytest.mark.parametrize('n,h,w', [(1, 256, 256), (3, 128, 256), (5, 256, 128), (24, 256, 256), (30, 128, 128)])
+def test_stem_forward_on_the_input_row_ring(n, h, w):
+    """stem_fwd_split_kernel (planner option stem_split with f32_split): conv0 7x7 / 2 pad 3 (models/cu_net.py:300) computed from an LDS
+    ring of input rows cut into bf16 pieces, k re-ordered to (channel, kernel row) x 8 consecutive pixels.  Against torch's conv2d on the
+    same image and weights, and the per-channel batch statistics the kernel emits against the output's own sums: one image (fewer output
+    rows than workgroups), rectangular images (64 / 128 output columns; row ranges that cross image boundaries: the rows above an
+    image's top edge are zeros, not the previous image's rows), the bench batch, many small images."""
+    import torch.nn.functional as F
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=37)
+    gen = torch.Generator().manual_seed(38)
+    x = torch.rand(n, 3, h, w, generator=gen) * 2.0 - 0.5
+    outs = {}
+    try:
+        for opt in (1, 0):
+            set_planner_option('stem_split', opt)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(n, h, w, True)
+            plan.forward(x.cuda(), True, want_outputs=False)
+            torch.cuda.synchronize()
+            d = plan.handle.describe()
+            assert d['nodes'][0]['op'] == 'stem_conv'
+            name = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][0]['out']][0]
+            outs[opt] = plan.debug_tensor(name).clone()
+            del plan, net
+    finally:
+        set_planner_option('stem_split', STEM_SPLIT_DEFAULT)
+    ref = F.conv2d(x.double(), st['features.conv0.weight'].double(), None, 2, 3).float().cuda()
+    scale = float(ref.abs().max())
+    for opt in (1, 0):
+        assert outs[opt].shape == ref.shape
+        err = float((outs[opt] - ref).abs().max())
+        assert err <= 2e-6 * scale, (opt, err, scale)
+
+
+STEM_SPLIT_DEFAULT = 1      # planner option stem_split as plan.h ships it
+
+
 @pytest.mark.parametrize('n,h,w', [(1, 256, 256), (3, 128, 256), (5, 256, 128), (30, 128, 128)])
 def test_stem_weight_gradient_shapes(n, h, w):
     """The LDS-staged stem weight gradient (wgrad3_stem_kernel) over its planning range: one output row per workgroup (N = 1),

@@ -34,6 +34,7 @@ EXPECT = {
         'conv_kernelILi3ELi1ELi1ELb1ELi6E': 128,
         'conv3x3_ring_split_kernel': 256,
         'dgrad3x3_ring_split_kernel': 256,
+        'stem_fwd_split_kernel': (256, 6),                 # (six registers spilled before the row loop, reloaded once per output row / at the end: none inside the tile loop)
         'dgrad1x1_rows_split_kernel': 256,
     },
     'wgrad3_kernels.hip': {
