@@ -151,3 +151,29 @@ def test_adapter_pairs_are_marked_on_the_down_blocks():
                 assert d['tensors'][a['out']]['C'] == d['tensors'][b['out']]['C']
     finally:
         set_planner_option('pair_adapters', 1)
+
+
+def test_planner_options_through_the_abi():
+    """cunet_set_planner_option (include/cunet.h): unknown names and negative values are refused (dgrad_rows = -1, its "by f32_split"
+    default, is the one negative value accepted), and the options of round 4 reach the plan: with the split contraction (f32_split = 1,
+    the default) an fp32 weight-gradient launch is cut into at most 192 workgroups, on the fp32 matrix pipe into at most 256."""
+    from cu_net_amd._lib import CUNetError, PlanHandle, set_planner_option
+    with pytest.raises(CUNetError):
+        set_planner_option('no_such_option', 1)
+    for name in ('f32_split', 'stem_split', 'dgrad3_ring', 'dgrad3_nt', 'wgrad3_max_splits', 'heads_on_side'):
+        with pytest.raises(CUNetError):
+            set_planner_option(name, -1)
+    set_planner_option('dgrad_rows', -1)
+    with pytest.raises(CUNetError):
+        set_planner_option('dgrad_rows', -2)
+    smax = {}
+    try:
+        for split in (1, 0):
+            set_planner_option('f32_split', split)
+            plan = PlanHandle(4, 32, 128, 68, 2, 1, 2, batch=24, height=256, width=256)
+            d = plan.describe()
+            smax[split] = max(nd.get('wg3', 0) for nd in d['nodes'] if nd['op'] == 'conv')
+            del plan
+    finally:
+        set_planner_option('f32_split', 1)
+    assert smax[1] == 192 and smax[0] == 256, smax
