@@ -504,6 +504,7 @@ def main():
         }
         if mode == 'fp32':
             out['contraction'] = SPLIT_NOTE if split else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32), planner option f32_split=0'
+            out['config']['contraction'] = 'split-bf16, 6 products, fp32 accumulate (f32_split=1)' if split else 'fp32 MFMA (f32_split=0)'
         for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
             if k in r:
                 out[k] = r[k]
