@@ -1660,12 +1660,21 @@ __global__ __launch_bounds__(512, 2) void dgrad3x3_ring_split_kernel(const ConvA
     if (grp1 == 0 && g_begin < g_end) request_x(g_begin, xp);
     __syncthreads();
 
+    // tuning builds, CUNET_CONV_DBG & 4096: shader cycles of a wave's phases summed over tiles into g_conv_phase (tools/ring_phase_clocks.py):
+    // [1] requests, [2] MFMAs (LDS fragment reads + chain), [3] partial hand-over + first barrier, [4] ring commit (+ partial add), [5] epilogue
+    // (first tap group), [6] second barrier; [0] wave-tiles, [7] whole kernel
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const bool stamp = CUNET_DBG(p, 4096) != 0;
+    auto now = [&]() -> unsigned long long { return stamp ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long tk0 = now();
     for (int g = g_begin; g < g_end; ++g) {
         const int y = g % H;
+        const unsigned long long t0 = now();
         dv = dvn; dok = dokn;                                     // row g + 2, requested one iteration ago
         issue_d(g + 3, dvn, dokn);                                // in flight across this whole iteration
         const size_t m0 = (size_t)g * W + x0;                     // first output row of this tile
         if (grp1 == 0) request_x(g + 1 < g_end ? g + 1 : g, xn);  // the next tile's x pieces likewise
+        const unsigned long long t1 = now();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1684,15 +1693,21 @@ __global__ __launch_bounds__(512, 2) void dgrad3x3_ring_split_kernel(const ConvA
                 acc = mfma_split6(ah, am, al, bh[2 * u + s2], bm[2 * u + s2], bl[2 * u + s2], acc);
             }
         }
+        if (stamp) asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[15]));      // (the chain has landed before the stamp)
+        const unsigned long long t2 = now();
         if (grp1 == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mypart[r * 64 + lane] = acc[r];
         }
         __syncthreads();                                          // partial tiles written; every wave is done reading the ring rows of g
+        const unsigned long long t3 = now();
         commit_d(g + 2);                                          // (into the ring row of g - 1)
         if (grp1 == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += mypart[r * 64 + lane];
+        }
+        const unsigned long long t4 = now();
+        if (grp1 == 0) {
             // BatchNorm / ReLU backward, first half (as conv_body's LDS-tile epilogue)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + (pr0 + 8 * j) * 36 + 4 * pc4) = xp[j];
@@ -1727,8 +1742,19 @@ __global__ __launch_bounds__(512, 2) void dgrad3x3_ring_split_kernel(const ConvA
 #pragma unroll
             for (int j = 0; j < 4; ++j) xp[j] = xn[j];
         }
+        const unsigned long long t5 = now();
         __syncthreads();                                          // the new ring row is complete; the partial tiles have been read
+        const unsigned long long t6 = now();
+        ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += t6 - t5;
     }
+#ifdef CUNET_TUNING
+    if (stamp && lane == 0) {
+        atomicAdd(&g_conv_phase[0], (unsigned long long)(g_end > g_begin ? g_end - g_begin : 0));
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
+        atomicAdd(&g_conv_phase[7], now() - tk0);
+    }
+#endif
+    (void)tk0; (void)ph;
     if (p.ystats != nullptr && tid < 128) {
         atomic_add_f64(p.ystats + tid, redbuf[tid * 2 + 0]);
         atomic_add_f64(p.ystats + p.Nout + tid, redbuf[tid * 2 + 1]);
@@ -1741,7 +1767,10 @@ static bool dgrad3x3_ring_supported(const ConvArgs& a) {
            a.wg_part == nullptr && a.mse_tgt == nullptr && a.Npad >= 128;
 }
 
-static hipError_t launch_dgrad3x3_ring(const ConvArgs& a, int num_cus, hipStream_t s) {
+static hipError_t launch_dgrad3x3_ring(const ConvArgs& a_in, int num_cus, hipStream_t s) {
+    ConvArgs a = a_in;
+    static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: phase clocks (4096)
+    a.dbg = dbg;
     const int NH = a.M / a.W;
     const int nstrip = a.W / 32;
     int rows = (NH * nstrip + num_cus - 1) / num_cus;
