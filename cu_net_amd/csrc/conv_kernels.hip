@@ -2261,8 +2261,15 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
     __syncthreads();
 
     double dsum = 0.0, dsq = 0.0;
+    // tuning builds, CUNET_CONV_DBG & 8192: phase clocks as in dgrad3x3_ring_split_kernel -- [1] requests, [2] MFMAs, [3] partial tiles to
+    // LDS + barrier, [4] sum of the eight partial tiles + store + statistics, [5] barrier, [6] ring commit + barrier
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const bool stamp = CUNET_DBG(p, 8192) != 0;
+    auto now = [&]() -> unsigned long long { return stamp ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long tk0 = now();
     for (int g = g_begin; g < g_end; ++g) {
         const int y = g % H;
+        const unsigned long long t0 = now();
 #pragma unroll
         for (int j = 0; j < 3; ++j) xv[j] = xvn[j];               // row g + 2, requested one iteration ago
         xok = xokn;
@@ -2270,6 +2277,7 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
         const bool rvalid = (y + dy >= 0) && (y + dy < H);
         const bool xvalid = y + 1 < H;                            // tap 8 = (dy, dx) = (+1, +1)
         const int sl = (g + dy + 3) % 3, slx = (g + 1) % 3;
+        const unsigned long long t1 = now();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -2290,9 +2298,12 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
             const u32x4 al = *reinterpret_cast<const u32x4*>(ap + 512);
             acc = mfma_split6(ah, am, al, bh[8], bm[8], bl[8], acc);
         }
+        if (stamp) asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[15]));      // (the chain has landed before the stamp)
+        const unsigned long long t2 = now();
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[tap * 1024 + r * 64 + lane] = acc[r];
         __syncthreads();
+        const unsigned long long t3 = now();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + R3_THREADS * u;
@@ -2305,10 +2316,22 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
             dsum += (double)vsum;
             dsq += (double)vsum * (double)vsum;
         }
+        const unsigned long long t4 = now();
         __syncthreads();                                          // everyone is done with row g-1's ring row and with `part`
+        const unsigned long long t5 = now();
         commit_x(g + 2);
         __syncthreads();
+        const unsigned long long t6 = now();
+        ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += t6 - t5;
     }
+#ifdef CUNET_TUNING
+    if (stamp && lane == 0) {
+        atomicAdd(&g_conv_phase[0], (unsigned long long)(g_end > g_begin ? g_end - g_begin : 0));
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
+        atomicAdd(&g_conv_phase[7], now() - tk0);
+    }
+#endif
+    (void)tk0; (void)ph;
     if (p.ystats != nullptr) {                                    // a thread's column is tid & 31 in both passes (512 = 16 * 32)
         atomicAdd(&redbuf[(tid & 31) * 2 + 0], dsum);
         atomicAdd(&redbuf[(tid & 31) * 2 + 1], dsq);
@@ -2328,6 +2351,9 @@ static bool conv3x3_ring_supported(const ConvArgs& a) {
 static hipError_t launch_conv3x3_ring(const ConvArgs& a, int num_cus, hipStream_t s) {
     const int NH = a.M / a.W;
     if (a.split) {                      // 32-pixel strips: (W / 32) strips x row blocks
+        ConvArgs ad = a;
+        static const int dbg = tune_int("CUNET_CONV_DBG", 0);      // tuning builds only: phase clocks (8192)
+        ad.dbg = dbg;
         const int nstrip = a.W / 32;
         int rows = (NH * nstrip + num_cus - 1) / num_cus;
         if (rows < 2) rows = 2;
@@ -2339,7 +2365,7 @@ static hipError_t launch_conv3x3_ring(const ConvArgs& a, int num_cus, hipStream_
             if (e != hipSuccess) return e;
             attr_split = true;
         }
-        hipLaunchKernelGGL(conv3x3_ring_split_kernel, dim3(grid), dim3(R3_THREADS), smem, s, a, rows);
+        hipLaunchKernelGGL(conv3x3_ring_split_kernel, dim3(grid), dim3(R3_THREADS), smem, s, ad, rows);
         return hipGetLastError();
     }
     int rows = (NH + num_cus - 1) / num_cus;

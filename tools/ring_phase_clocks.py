@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Where a wave of the 3x3 data gradient's row-ring kernel spends its cycles (tools only; the -DCUNET_TUNING library, CUNET_CONV_DBG=4096).
+"""Where a wave of a row-ring kernel spends its cycles (tools only; the -DCUNET_TUNING library, CUNET_CONV_DBG = 4096 / 8192).
 
-    CUNET_LIB_PATH=.../libcunet_hip_tuning.so python tools/ring_phase_clocks.py [--serial]
+    CUNET_LIB_PATH=.../libcunet_hip_tuning.so python tools/ring_phase_clocks.py [--fwd] [--serial]
+
+Default: dgrad3x3_ring_split_kernel (the 3x3 data gradient); --fwd: conv3x3_ring_split_kernel (the 3x3 forward: requests, MFMAs, partial
+tiles to LDS + barrier, sum of the eight partial tiles + store + statistics, barrier, ring commit + barrier).
 
 Runs BASELINE config 2 (CU-Net-2, K = 68, bs 24) for a few steps with s_memtime stamps around the phases of
 dgrad3x3_ring_split_kernel's row loop and prints shader cycles per wave and 32-pixel tile: requests (next dY row, next tile's x pieces),
@@ -16,7 +19,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('CUNET_LIB_PATH', os.path.join(ROOT, 'cu_net_amd', 'libcunet_hip_tuning.so'))
-os.environ['CUNET_CONV_DBG'] = '4096'
+FWD = '--fwd' in sys.argv
+os.environ['CUNET_CONV_DBG'] = '8192' if FWD else '4096'
 if '--serial' in sys.argv:
     os.environ['CUNET_NO_SIDE_STREAM'] = '1'
 import torch  # noqa: E402
@@ -46,9 +50,11 @@ torch.cuda.synchronize()
 assert fn(buf, 1) == 0
 v = [int(b) for b in buf]
 tiles = max(v[0], 1)
-names = ['requests (dY row g + 3, next x pieces)', 'MFMAs (fragment reads + chain)', 'partial hand-over + barrier 1', 'ring commit (+ partial add)',
-         'epilogue (first tap group)', 'barrier 2']
-print(f'{steps} steps, {v[0]} wave-tiles of the 3x3 data gradient on the row ring ({v[0] // steps} per step)')
+names = (['requests (row g + 3)', 'MFMAs (fragment reads + chain)', 'partial tiles to LDS + barrier 1', 'sum of partials + store + statistics', 'barrier 2',
+          'ring commit + barrier 3'] if FWD else
+         ['requests (dY row g + 3, next x pieces)', 'MFMAs (fragment reads + chain)', 'partial hand-over + barrier 1', 'ring commit (+ partial add)',
+          'epilogue (first tap group)', 'barrier 2'])
+print(f'{steps} steps, {v[0]} wave-tiles of the 3x3 {"forward" if FWD else "data gradient"} on the row ring ({v[0] // steps} per step)')
 tot = sum(v[1:7])
 for n, c in zip(names, v[1:7]):
     print(f'  {n:42s} {c / tiles:9.0f} cycles per wave and tile  {100.0 * c / max(tot, 1):5.1f} %')
