@@ -97,7 +97,7 @@ def host_cpu():
 def cpu_baseline(layers, class_num, steps):
     """CPU oracle (kind 'port': restatement of the reference, bit-exact to it on the golden vectors) timed on this host:
     CU-Net-L order 1, bs=4, 256x256 (BASELINE.json configs[0]), full train step -- with torch.set_num_threads(n) for
-    n = the host's physical cores (the headline `value` / `cores`) and n = 8 (comparable with SURVEY 8d's 8-vCPU probe)."""
+    n = the host's physical cores, 32 and 8 (comparable with SURVEY 8d's 8-vCPU probe); `value` / `cores` = the fastest of them."""
     from oracle import cunet_ref as O
     model, phys = host_cpu()
     usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -122,13 +122,13 @@ def cpu_baseline(layers, class_num, steps):
         v32 = run(n32) if n32 not in (n_main, min(8, usable)) else (v_main if n32 == n_main else v8)
     finally:
         torch.set_num_threads(saved)
-    # (at bs = 4 torch's CPU kernels do not scale to a whole two-socket host: the all-cores figure SURVEY 8d asks for is the headline, the
-    # fastest thread count tried is named next to it)
+    # (at bs = 4 torch's CPU kernels do not scale to a whole two-socket host: `value` / `cores` is the FASTEST thread count tried -- the
+    # baseline a user of the reference would actually get on this host; the all-cores figure SURVEY 8d also asks for is next to it)
     best = max((v_main, n_main), (v32, n32), (v8, min(8, usable)))
-    return {'value': v_main, 'unit': 'images/sec', 'cores': n_main, 'kind': 'port',
+    return {'value': best[0], 'unit': 'images/sec', 'cores': best[1], 'kind': 'port',
             'cpu_model': model, 'physical_cores': phys, 'logical_cpus_usable': usable,
+            'at_all_physical_cores': {'value': v_main, 'cores': n_main},
             'at_8_threads': {'value': v8, 'cores': min(8, usable)}, 'at_32_threads': {'value': v32, 'cores': n32},
-            'best_of_the_three': {'value': best[0], 'cores': best[1]},
             'sample': f'CU-Net-{layers} order 1 K={class_num}, bs=4, 256x256 fp32, {steps} full train steps '
                       f'(fwd+MSE+bwd+RMSprop) after 1 warm-up at each thread count, torch CPU {torch.__version__}'}
 

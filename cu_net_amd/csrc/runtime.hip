@@ -152,33 +152,55 @@ extern "C" {
 const char* cunet_last_error(void) { return g_err.c_str(); }
 const char* cunet_version(void) { return "cunet-hip 0.2 (gfx950; fp32 mode: split-bf16 or fp32 MFMA by planner option f32_split; bf16 storage: bf16 MFMA)"; }
 
+// name -> member of PlannerOptions (one table for the setter and the getter)
+static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
+    if (n == "wgrad3_min_rows") return &o.wgrad3_min_rows;
+    if (n == "wgrad3_min_chunks") return &o.wgrad3_min_chunks;
+    if (n == "wgrad3_max_splits") return &o.wgrad3_max_splits;
+    if (n == "wgrad3_min_chunks_bf16") return &o.wgrad3_min_chunks_bf16;
+    if (n == "wgrad3_max_splits_bf16") return &o.wgrad3_max_splits_bf16;
+    if (n == "wgrad3_stem") return &o.wgrad3_stem;
+    if (n == "conv3x3_ring_min_rows") return &o.conv3x3_ring_min_rows;
+    if (n == "wgrad_fork_group") return &o.wgrad_fork_group;
+    if (n == "wgrad_fork_group_bf16") return &o.wgrad_fork_group_bf16;
+    if (n == "fwd_fork_min_w") return &o.fwd_fork_min_w;
+    if (n == "pair_adapters") return &o.pair_adapters;
+    if (n == "heads_on_side") return &o.heads_on_side;
+    if (n == "dgrad_nt") return &o.dgrad_nt;
+    if (n == "wgrad_bf16_dma") return &o.wgrad_bf16_dma;
+    if (n == "fuse_wgrad") return &o.fuse_wgrad;
+    if (n == "dgrad_prefetch") return &o.dgrad_prefetch;
+    if (n == "dgrad_rows") return &o.dgrad_rows;
+    if (n == "f32_split") return &o.f32_split;
+    if (n == "dgrad3_nt") return &o.dgrad3_nt;
+    if (n == "dgrad3_ring") return &o.dgrad3_ring;
+    if (n == "stem_split") return &o.stem_split;
+    return nullptr;
+}
+
 int cunet_set_planner_option(const char* name, int value) {
     if (!name) return fail(CUNET_ERR_INVALID, "bad planner option");
-    PlannerOptions& o = planner_options();
     const std::string n(name);
     if (value < 0 && !(n == "dgrad_rows" && value == -1)) return fail(CUNET_ERR_INVALID, "bad planner option");      // (dgrad_rows = -1: its default, "by f32_split")
-    if (n == "wgrad3_min_rows") o.wgrad3_min_rows = value;
-    else if (n == "wgrad3_min_chunks") o.wgrad3_min_chunks = value;
-    else if (n == "wgrad3_max_splits") o.wgrad3_max_splits = value;
-    else if (n == "wgrad3_min_chunks_bf16") o.wgrad3_min_chunks_bf16 = value;
-    else if (n == "wgrad3_max_splits_bf16") o.wgrad3_max_splits_bf16 = value;
-    else if (n == "wgrad3_stem") o.wgrad3_stem = value;
-    else if (n == "conv3x3_ring_min_rows") o.conv3x3_ring_min_rows = value;
-    else if (n == "wgrad_fork_group") o.wgrad_fork_group = value;
-    else if (n == "wgrad_fork_group_bf16") o.wgrad_fork_group_bf16 = value;
-    else if (n == "fwd_fork_min_w") o.fwd_fork_min_w = value;
-    else if (n == "pair_adapters") o.pair_adapters = value;
-    else if (n == "heads_on_side") o.heads_on_side = value;
-    else if (n == "dgrad_nt") o.dgrad_nt = value;
-    else if (n == "wgrad_bf16_dma") o.wgrad_bf16_dma = value;
-    else if (n == "fuse_wgrad") o.fuse_wgrad = value;
-    else if (n == "dgrad_prefetch") o.dgrad_prefetch = value;
-    else if (n == "dgrad_rows") o.dgrad_rows = value;
-    else if (n == "f32_split") o.f32_split = value;
-    else if (n == "dgrad3_nt") o.dgrad3_nt = value;
-    else if (n == "dgrad3_ring") o.dgrad3_ring = value;
-    else if (n == "stem_split") o.stem_split = value;
-    else return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
+    int* slot = planner_option_slot(planner_options(), n);
+    if (!slot) return fail(CUNET_ERR_INVALID, "unknown planner option " + n);
+    *slot = value;
+    return CUNET_OK;
+}
+
+int cunet_get_planner_option(const char* name, int* value) {
+    if (!name || !value) return fail(CUNET_ERR_INVALID, "bad planner option");
+    const int* slot = planner_option_slot(planner_options(), std::string(name));
+    if (!slot) return fail(CUNET_ERR_INVALID, std::string("unknown planner option ") + name);
+    *value = *slot;
+    return CUNET_OK;
+}
+
+int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value) {
+    // only launch-time choices between bit-identical kernels may change under a live plan (everything else shaped its layout)
+    if (!plan || !name || value < 0) return fail(CUNET_ERR_INVALID, "bad plan option");
+    if (std::string(name) != "wgrad_bf16_dma") return fail(CUNET_ERR_INVALID, std::string("not a launch-time option: ") + name);
+    plan->plan.opts.wgrad_bf16_dma = value;
     return CUNET_OK;
 }
 
@@ -680,7 +702,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
             w.xbf16 = E.xmode;
             w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
             w.split = E.xmode == 0 ? P.opts.f32_split : 0;
-            w.bf16_dma = planner_options().wgrad_bf16_dma;      // (a launch-time choice between bit-identical kernels: read live, not from the plan's snapshot)
+            w.bf16_dma = P.opts.wgrad_bf16_dma;      // (the plan's snapshot, like every other option; cunet_debug_set_plan_option flips it on a live plan for the bit-identity test)
             if (c.taps == 9 && wg3_active(P, n, E.xmode) && wgrad3_3x3_supported(w)) {
                 // LDS ring of activated image rows, partial tiles [split][tap][n][c] (reduced + transposed per bucket)
                 const bool on16 = wgrad3_3x3_on_bf16_mfma(w);

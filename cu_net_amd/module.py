@@ -162,6 +162,10 @@ class _BoundPlan:
         """With bf16 gradient storage every gradient tensor is bf16 except d(loss)/d(stem conv output)."""
         return t['id'] != d['nodes'][0]['out']
 
+    def debug_set_option(self, name: str, value: int):
+        """include/cunet.h cunet_debug_set_plan_option: flips a launch-time option (wgrad_bf16_dma) in this live plan's snapshot."""
+        check(lib().cunet_debug_set_plan_option(self.handle.h, name.encode(), int(value)), 'cunet_debug_set_plan_option')
+
     def debug_run_node_backward(self, node_index: int):
         check(lib().cunet_debug_run_node_backward(self.handle.h, node_index, _stream_ptr(self.workspace.device)),
               'cunet_debug_run_node_backward')

@@ -294,17 +294,25 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        fp32 as before; inputs, outputs, statistics and every tensor in HBM stay fp32.  The dropped terms are below 2^-24
  *                        of |x y|: measured against fp64 the result is as close as the fp32 MFMA's (profiles/r04_split_bf16_probe.txt;
  *                        tests/test_gpu_exact.py::test_backward_error_vs_fp64_tracks_torch_fp32[*-1]).  Kernels: 1x1 forward, heads, 1x1 and
- *                        3x3 data gradients (conv_body XBG = 6 / 7), 3x3 forward on the row ring.  0 (default): the fp32 matrix pipe
+ *                        3x3 data gradients (conv_body XBG = 6 / 7), 3x3 forward on the row ring, weight gradients, stem.  1 (DEFAULT since round 4).
+ *                        0: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; rounds 1-3).  Limitation of 1: an operand that is +-Inf, NaN or
+ *                        finite above the bf16 maximum (3.39e38) contributes NaN (h = Inf, x - h = NaN) where the fp32 MFMA would give
+ *                        +-Inf; a diverged run shows as NaN loss instead of Inf loss.  Finite values below that are exact
  *   "fuse_wgrad"         1: the fp32 data gradient of a 1x1 node (128 output channels) also computes the node's weight gradient from the dY
  *                        and x tiles it holds and writes one partial tile per row block (summed by the bucket's reduce): one pass over dY
  *                        and x per node, no wgrad launch on the side stream.  0 (default): separate launches -- measured 4.8 % faster in
  *                        the overlapped CU-Net-2 step on MI355X (the fused kernel is 1.9 % faster when nothing overlaps)
  *   "wgrad_bf16_dma"     1 (default): the 1x1 weight gradient of the bf16 storage mode streams dY and x into an LDS ring by LDS-DMA
  *                        (global_load_lds) and takes its MFMA operands with the LDS transpose read where every pixel range is whole
- *                        32-pixel slots; 0: always the register-staged kernel of rounds 2-3 (bit-identical results).  Unlike the other
- *                        options this one is read at every launch, also by live plans
+ *                        32-pixel slots; 0: always the register-staged kernel of rounds 2-3 (bit-identical results).  Snapshotted
+ *                        into the plan like every other option (round 5); cunet_debug_set_plan_option flips it on a live plan
  * Returns 0, or CUNET_ERR_INVALID for an unknown name / negative value. */
 int cunet_set_planner_option(const char* name, int value);
+/* reads the process-wide value back (tests save / restore the options they change).  0, or CUNET_ERR_INVALID for an unknown name. */
+int cunet_get_planner_option(const char* name, int* value);
+/* debugging aid of the test-suite: changes "wgrad_bf16_dma" -- the one option that only picks between bit-identical kernels at
+ * launch time -- in the snapshot of a LIVE plan.  Any other name: CUNET_ERR_INVALID (those options shaped the plan's layout). */
+int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value);
 
 /* training-sample preparation on the device: replaces the per-sample CPU work of data/mpii_for_mpii_22.py:127-141 between the
  * decoded image and the network input -- horizontal flip (pylib/HumanAug.py:267-271), per-channel colour gain with clamp to

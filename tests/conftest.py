@@ -20,6 +20,11 @@ def pytest_collection_modifyitems(config, items):
         has_gpu = torch.cuda.is_available()
     except Exception:
         has_gpu = False
+    # Reference parity first: under `-x` one miss in a hand-calibrated kernel-level test must not hide the tests that compare
+    # with the reference's own vectors (round 4 lost all of test_gpu_parity / test_gpu_quant behind one node test).
+    order = ['test_gpu_parity', 'test_gpu_quant', 'test_gpu_configs', 'test_gpu_dp', 'test_gpu_augment', 'test_gpu_exact', 'test_gpu_nodes']
+    rank = {name: i for i, name in enumerate(order)}
+    items.sort(key=lambda it: rank.get(os.path.splitext(os.path.basename(str(it.fspath)))[0], len(order)))      # (stable: order inside a file is kept)
     if has_gpu:
         return
     skip = pytest.mark.skip(reason='no GPU visible')
@@ -38,3 +43,20 @@ def pytest_sessionstart(session):
     for kv in opts.split(','):
         name, val = kv.split('=')
         set_planner_option(name.strip(), int(val))
+
+
+@pytest.fixture(autouse=True)
+def _planner_options_are_restored():
+    """Every test starts from -- and leaves behind -- the planner options in effect when it began (the library's defaults, or what
+    CUNET_TEST_PLANNER_OPTS selected for the whole session): a test that switches `f32_split`, `wgrad3_min_rows`, ... cannot leak its
+    selection into the tests behind it, whatever it restores by hand."""
+    from cu_net_amd import _lib
+    try:
+        before = _lib.planner_options_snapshot()
+    except Exception:      # library not built: the CPU tests that need it fail on their own
+        yield
+        return
+    yield
+    for k, v in before.items():
+        if _lib.get_planner_option(k) != v:
+            _lib.set_planner_option(k, v)

@@ -480,7 +480,7 @@ def test_bf16_weight_gradient_on_lds_dma_is_bit_identical(n):
             plan.debug_poke(t['name'], torch.randn((t['N'], t['C'], t['H'], t['W']), generator=gen), grad=True)      # this node's d(loss)/d(out)
             got = {}
             for dma in (1, 0):
-                set_planner_option('wgrad_bf16_dma', dma)
+                plan.debug_set_option('wgrad_bf16_dma', dma)        # (the plan's own snapshot: nothing process-wide changes)
                 plan.debug_run_node_backward(k)
                 torch.cuda.synchronize()
                 got[dma] = net._grad_arena[o:o + nmel].clone()
@@ -490,7 +490,7 @@ def test_bf16_weight_gradient_on_lds_dma_is_bit_identical(n):
                 bad.append(f'{nd["name"]}: {int((d > 0).sum())}/{nmel} elements differ, max {float(d.max()):.3e} of {float(got[0].abs().max()):.3e}')
             assert float(got[0].abs().max()) > 0
     finally:
-        set_planner_option('wgrad_bf16_dma', 1)
+        plan.debug_set_option('wgrad_bf16_dma', 1)
     assert not bad, '\n'.join(bad[:20])
     assert {4, 5, 6, 8, 9, 10} <= seen_ct, seen_ct
 

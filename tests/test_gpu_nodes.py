@@ -19,10 +19,14 @@ from tests._golden import Golden
 pytestmark = pytest.mark.gpu
 
 
-def _close(name, got, ref, bad, rtol=2e-4, frac=1e-3, l2=1e-3):
+def _close(name, got, ref, bad, rtol=2e-4, frac=1e-3, l2=1e-3, slack=None):
+    """slack: per-element absolute allowance that the CALLER derived from the inputs (see _quantiser_tie_slack) -- it is
+    subtracted from the difference before any of the tolerances is applied, element by element."""
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     mag = ref.abs().max().item()
     diff = (got - ref).abs()
+    if slack is not None:
+        diff = (diff - slack.detach().float().cpu()).clamp_min(0.0)
     allowed = max(2, int(frac * ref.numel()))      # elements whose ReLU mask may legitimately flip (z == 0 +- rounding)
     nbad = int((diff > rtol * mag + 1e-7).sum())
     # relative L2 without the `allowed` worst elements: one flipped mask under a large dy would otherwise dominate it
@@ -208,6 +212,45 @@ def test_every_node_backward_full_width_bf16_gradient_tensors():
     _check_all_nodes(cfg, st, x, bf16=2)
 
 
+TIE_BAND = 2e-3      # in quantiser steps: an activation this close to a rounding boundary may land on either neighbouring level
+
+
+def _quantiser_tie_slack(pre_q, dy, bits, taps):
+    """The weight gradient at a QuanInput2d site contracts dY with the QUANTISED activation round(a * 2^(bits-1)) / 2^(bits-1)
+    (utils/quantize.py:33-42,47-63).  The reference side of this test recomputes `a` (BatchNorm + ReLU) on the CPU from the GPU's
+    tensors; the kernel computes the same `a` with its own fp64-statistics BatchNorm table, equal to a few ulps -- so an `a` that
+    sits within rounding of a bucket boundary (k + 1/2) * 2^-(bits-1) lands on the OTHER level on one side.  That is a legitimate,
+    discontinuous difference of exactly one quantiser step of one activation, and each such activation (pixel p, channel c) moves
+    dW[o, c, tap] by dy[o, p + tap] * 2^-(bits-1).  Rather than widening a tolerance, the bound is computed from the inputs:
+        slack[o, c, tap] = 2^-(bits-1) * sum_{p : a[c, p] within TIE_BAND steps of a boundary}  |dy[o, p + tap]|
+    i.e. the weight gradient of the tie mask against |dY|.  TIE_BAND = 2e-3 steps = 1.6e-5 absolute at 8 bits, ~100 ulps of a value
+    near 1 (the BatchNorm tables differ by fp32 rounding of scale and shift: |x * scale| and |shift| of a few units each);
+    about 4e-3 of the positive activations are inside the band, each worth <= |dy| / 128 in 9 x Cout elements, so everything NOT
+    explained by a possible tie flip is still held to the unchanged fp32 tolerance.  (round 4: `hg.down_blocks.2.layers.0.conv2
+    dW: 135/36864 elements off, max err 2.386e-02` = 3.05 / 128 -- tools/diag_quan_tie.py identifies the flipped activation.)"""
+    step = 2.0 ** (bits - 1)
+    m = _quantiser_tie_mask(pre_q, bits)
+    pad = 1 if taps == 9 else 0
+    # weight gradient of conv2d(m, W) w.r.t. W under output gradient |dy|
+    wz = torch.zeros(dy.shape[1], m.shape[1], 3 if taps == 9 else 1, 3 if taps == 9 else 1, requires_grad=True)
+    F.conv2d(m, wz, None, 1, pad).backward(dy.abs())
+    return wz.grad / step
+
+
+def _quantiser_tie_mask(pre_q, bits):
+    step = 2.0 ** (bits - 1)
+    t = pre_q.double() * step
+    fr = t - torch.floor(t)
+    return (((fr - 0.5).abs() <= TIE_BAND) & (pre_q > 0) & (pre_q.double() < 1.0 - 1.0 / step + TIE_BAND / step)).float()
+
+
+def _quantiser_tie_slack_forward(pre_q, w, bits, taps):
+    """Forward twin of _quantiser_tie_slack: an activation inside the tie band may differ by one step 2^-(bits-1) between the two
+    sides, which moves output (o, p) by |w[o, c, tap]| * 2^-(bits-1): slack = conv2d(tie mask, |W|) / 2^(bits-1)."""
+    with torch.no_grad():
+        return F.conv2d(_quantiser_tie_mask(pre_q, bits), w.abs(), None, 1, 1 if taps == 9 else 0) / 2.0 ** (bits - 1)
+
+
 def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0, only_ops=None, check_forward=False):
     """wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
     False: the planner is told to keep them on the per-wave atomic kernel (wgrad2), which stays the path of narrow heads,
@@ -279,8 +322,11 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
             act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
             if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
                 from oracle.cunet_ref import _QuanInputFn       # QuanInput2d site: quantised forward, straight-through backward
+                pre_q = act.detach()
                 act = _QuanInputFn.apply(act, quan_input_bits)
             dw_tol = {}
+            if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
+                dw_tol = dict(slack=_quantiser_tie_slack(pre_q, dy, quan_input_bits, nd['taps']))
             if gb and nd.get('wg3', 0) > 0 and (nd['taps'] == 1 or T[nd['out']]['W'] in (16, 32, 64)):
                 # (an activation whose fp32 value sits within an ulp of a bf16 rounding boundary rounds the other way in the kernel:
                 # one bf16 step of one activation, 4e-3 * |act * dy|, in a sum over a few hundred rows is above 2e-4 of max|dW|)
@@ -408,23 +454,26 @@ def _check_composition(cfg, st, x, target, check_params=False, quan_bits_w=0, qu
             beta = st[nd['bn'] + '.bias'].clone().requires_grad_(check_params)
             wt = st[nd['conv'] + '.weight'].clone().requires_grad_(check_params)
             act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
-            if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
+            site = bool(quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0))
+            if site:
                 from oracle.cunet_ref import _QuanInputFn
+                pre_q = act.detach()
                 act = _QuanInputFn.apply(act, quan_input_bits)
             y = F.conv2d(act, wt, None, 1, 1 if nd['taps'] == 9 else 0)
             # the forward itself, node by node on the GPU's own inputs, in EVERY configuration (fp32 tolerance).  Quantised inputs: with
-            # ternary weights and 2^-7-grid activations the 3x3 / head convs are exact on both sides
-            # (an activation within rounding of a quantiser step lands on the neighbouring 2^-7 level on one side only: with
-            # fan-in 1152 about 1 % of the outputs contain such a flip, 1/128 each -- hence the wider element tolerance there)
-            site = quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0)
-            _close(f'{nd["name"]} forward', acts[oname], y, bad_fwd, **(dict(rtol=3e-3, frac=2e-3) if site else {}))
+            # ternary weights and 2^-7-grid activations the 3x3 / head convs are exact on both sides -- except that an activation within
+            # rounding of a quantiser boundary lands on the neighbouring 2^-7 level on one side only (with fan-in 1152 about 1 % of the
+            # outputs contain such a flip): the per-element allowance for exactly those activations, |w| / 128 each, comes from the
+            # inputs (_quantiser_tie_slack_forward); everything else is held to the plain fp32 tolerance
+            fwd_tol = dict(slack=_quantiser_tie_slack_forward(pre_q, wt.detach(), quan_input_bits, nd['taps'])) if site else {}
+            _close(f'{nd["name"]} forward', acts[oname], y, bad_fwd, **fwd_tol)
             y.backward(dy)
             for l, s in zip(leaves, nd['segs']):
                 add(T[s['t']]['name'], l.grad)
             if check_params:
                 # (at a QuanInput site the weight gradient contracts dY with the QUANTISED activation: an activation on a quantiser
-                # boundary that lands on the other 2^-7 level moves a dW element by dy / 128 -- 6e-4 of max|dW| measured)
-                site_tol = dict(rtol=2e-3, frac=5e-3) if (quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0)) else {}
+                # boundary that lands on the other 2^-7 level moves a dW element by dy / 128 -- allowed for exactly those activations)
+                site_tol = dict(slack=_quantiser_tie_slack(pre_q, dy, quan_input_bits, nd['taps'])) if site else {}
                 pcheck(f'{nd["name"]} dW', nd['conv'] + '.weight', wt.grad, **site_tol)
                 pcheck(f'{nd["name"]} dgamma', nd['bn'] + '.weight', gamma.grad)
                 pcheck(f'{nd["name"]} dbeta', nd['bn'] + '.bias', beta.grad)
