@@ -77,6 +77,7 @@ def lib():
         'cunet_rmsprop_step': (i32, [vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
         'cunet_get_preds': (i32, [vp, vp, i32, i32, i32, i32, vp]),
         'cunet_final_preds': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+        'cunet_final_preds_affine': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'cunet_flip_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         'cunet_augment_batch': (i32, [vp, vp, i32, vp, i32, vp]),
         'cunet_render_targets': (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
@@ -109,7 +110,7 @@ EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind', 'cunet_set_quant_input', 'cunet_set_popcount_live',
             'cunet_forward', 'cunet_loss_mse', 'cunet_loss_mse_fused', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
-            'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_flip_merge', 'cunet_augment_batch', 'cunet_render_targets',
+            'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_final_preds_affine', 'cunet_flip_merge', 'cunet_augment_batch', 'cunet_render_targets',
             'cunet_debug_tensor_offset', 'cunet_quant_prepare', 'cunet_quant_restore', 'cunet_quant_grad',
             'cunet_ternary_pack', 'cunet_ternary_conv', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
             'cunet_profile_num_classes', 'cunet_profile_class_name', 'cunet_profile_get', 'cunet_profile_get_stream']

@@ -4,6 +4,7 @@
 // All are vectorised (16 B per lane) streaming kernels; per-channel reductions are carried in
 // fp64 and committed with one atomic per channel per block.
 #include "common.h"
+#include <algorithm>
 
 namespace cunet {
 
@@ -127,6 +128,119 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
     }
 }
 
+// The same gather with the CHANNEL PIECE FIXED PER THREAD (round 5): when the pieces of a row divide the block (C / 4 = 8 or 32 -- every
+// tensor of the fp32 path), thread t owns piece t % gv of rows t / gv, + 256 / gv, ...: its E, D and A coefficients are loop-invariant
+// registers (the flat-index kernel above re-reads (2 + NSRC) x 4 floats from LDS and does a 64-bit division per 16-byte piece), row
+// arithmetic is 32-bit, two rows are in flight per thread (R = 2, plain consumers), and the launcher sizes the grid so that every
+// block walks the same number of row groups (3072 groups on 2048 blocks was 2 rounds for half of them, 1 for the rest).  Element for
+// element the same operations in the same order as the kernel above: bit-identical results.
+template <int NSRC, int UPS, int XBG>
+__global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherArgs p, int gshift) {
+    constexpr int XB = XBG != 0, GB = XBG == 2, V = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cE = reinterpret_cast<float*>(smem);
+    float* cD = cE + p.C;
+    float* cA = cD + p.C;
+    const int tid = threadIdx.x;
+    constexpr double mult = UPS ? 4.0 : 1.0;
+    const double invM = 1.0 / ((double)p.rows * mult);
+    for (int c = tid; c < p.C; c += 256) {
+        const double mean = p.stats[c] / p.count;
+        double var = p.stats[p.C + c] / p.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        double Es = 0.0, Ds = 0.0;
+#pragma unroll
+        for (int e = 0; e < NSRC; ++e) {
+            const int cc = p.src[e].choff + c;
+            const double scale = (double)p.src[e].gamma[cc] * istd;
+            const double c1 = p.src[e].red[cc] * invM;
+            const double c2 = p.src[e].red[p.src[e].lddz + cc] * invM;
+            const double D = scale * c2 * istd;
+            cA[e * p.C + c] = (float)scale;
+            Es += mult * (D * mean - scale * c1);
+            Ds += mult * D;
+        }
+        cE[c] = (float)Es;
+        cD[c] = (float)Ds;
+    }
+    __syncthreads();
+
+    const int c = V * (tid & ((1 << gshift) - 1));
+    const int rpb = 256 >> gshift;                     // rows per block and round
+    float rE[V], rD[V], rA[NSRC][V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { rE[k] = cE[c + k]; rD[k] = cD[c + k]; }
+#pragma unroll
+    for (int e = 0; e < NSRC; ++e)
+#pragma unroll
+        for (int k = 0; k < V; ++k) rA[e][k] = cA[e * p.C + c + k];
+    const int HW = p.H * p.W;
+    constexpr int U = UPS ? 4 : 1;
+    constexpr int R = UPS ? 1 : 2;                     // rows in flight per thread
+    const int stride = (int)gridDim.x * rpb;
+    for (int row0 = (int)blockIdx.x * rpb + (tid >> gshift); row0 < p.rows; row0 += R * stride) {
+        float d[R][NSRC][U][V], x[R][V], o[R][V];
+        bool live[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int row = row0 + q * stride;
+            live[q] = row < p.rows;
+            const int rr = live[q] ? row : row0;       // (a dead slot re-reads row0: no branch around the requests)
+            size_t drow = (size_t)rr;
+            if (UPS) {
+                const int ni = rr / HW;
+                const int rm = rr - ni * HW;
+                const int ys = rm / p.W, xs = rm - ys * p.W;
+                drow = (size_t)ni * 4 * HW + (size_t)(2 * ys) * (2 * p.W) + 2 * xs;
+            }
+#pragma unroll
+            for (int e = 0; e < NSRC; ++e) {
+                const size_t b = drow * p.src[e].lddz + p.src[e].choff + c;
+                ldxv<GB, V>(p.src[e].dz, b, d[q][e][0]);
+                if (UPS) {
+                    ldxv<GB, V>(p.src[e].dz, b + p.src[e].lddz, d[q][e][1 % U]);
+                    ldxv<GB, V>(p.src[e].dz, b + (size_t)2 * p.W * p.src[e].lddz, d[q][e][2 % U]);
+                    ldxv<GB, V>(p.src[e].dz, b + (size_t)(2 * p.W + 1) * p.src[e].lddz, d[q][e][3 % U]);
+                }
+            }
+            ldxv<XB, V>(p.x, (size_t)rr * p.ld + c, x[q]);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[q][k] = 0.f;
+            if (p.accumulate) ldxv<GB, V>(p.gx, (size_t)rr * p.ld + c, o[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            float r[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) r[k] = rE[k] - rD[k] * x[q][k];
+#pragma unroll
+            for (int e = 0; e < NSRC; ++e) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    float v = d[q][e][0][k];
+                    if (UPS) v = (d[q][e][0][k] + d[q][e][1 % U][k]) + (d[q][e][2 % U][k] + d[q][e][3 % U][k]);
+                    r[k] = fmaf(rA[e][k], v, r[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) r[k] += o[q][k];
+            if (live[q]) stxv<GB, V>(p.gx, (size_t)(row0 + q * stride) * p.ld + c, r);
+        }
+    }
+}
+
+template <int UPS, int XB>
+static hipError_t launch_gather_rows_n(const GradGatherArgs& a, dim3 grid, size_t smem, int gshift, hipStream_t s) {
+    switch (a.nsrc) {
+#define CUNET_G(N) case N: hipLaunchKernelGGL((grad_gather_rows_kernel<N, UPS, XB>), grid, dim3(256), smem, s, a, gshift); break;
+        CUNET_G(1) CUNET_G(2) CUNET_G(3) CUNET_G(4) CUNET_G(5) CUNET_G(6) CUNET_G(7) CUNET_G(8)
+#undef CUNET_G
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int UPS, int XB, int V>
 static hipError_t launch_gather_nv(const GradGatherArgs& a, dim3 grid, size_t smem, hipStream_t s) {
     switch (a.nsrc) {
@@ -156,6 +270,20 @@ hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t 
     if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
     const size_t smem = (size_t)a.C * 4 * (2 + a.nsrc);
+    const int gv = a.C / 4;
+    if (a.xbf16 != 2 && a.C % 4 == 0 && gv >= 1 && gv <= 256 && (gv & (gv - 1)) == 0 && (long)a.rows * a.ld < (1L << 31)) {
+        // fixed channel piece per thread (fp32 gradient tensors; C / 4 a power of two <= 256)
+        int gshift = 0;
+        while ((1 << gshift) < gv) ++gshift;
+        const int rpb = 256 >> gshift;
+        const long groups = ((long)a.rows + rpb - 1) / rpb;                 // row groups of one block round
+        const int R = a.src[0].ups ? 1 : 2;
+        long blocks = std::min(groups, 8L * num_cus);
+        const long rounds = (groups + blocks * R - 1) / (blocks * R);       // rounds of R row groups per block ...
+        blocks = std::max(1L, (groups + rounds * R - 1) / (rounds * R));    // ... and the fewest blocks that need no more
+        if (a.xbf16) return a.src[0].ups ? launch_gather_rows_n<1, 1>(a, dim3((unsigned)blocks), smem, gshift, s) : launch_gather_rows_n<0, 1>(a, dim3((unsigned)blocks), smem, gshift, s);
+        return a.src[0].ups ? launch_gather_rows_n<1, 0>(a, dim3((unsigned)blocks), smem, gshift, s) : launch_gather_rows_n<0, 0>(a, dim3((unsigned)blocks), smem, gshift, s);
+    }
     if (a.xbf16 == 2) {
         bool v8 = a.C % 8 == 0 && a.ld % 8 == 0;                 // 16-byte bf16 pieces everywhere
         for (int e = 0; e < a.nsrc; ++e) v8 = v8 && a.src[e].lddz % 8 == 0 && a.src[e].choff % 8 == 0;
@@ -761,8 +889,13 @@ __global__ __launch_bounds__(256) void get_preds_kernel(const float* __restrict_
 // quarter-pixel shift toward the larger neighbour, +0.5, inverse crop transform (Evaluation.py:152-187 with
 // size = 200): the reference builds the 3x3 matrix from float32 scalars, inverts it in float64 (LAPACK on an
 // upper-triangular matrix: inv[0][2] = -(b * (1/a))) and truncates toward zero; the same sequence is used here.
+// `inv` != nullptr (rot != 0, pylib/Evaluation.py:163-178): the caller hands over rows 0 and 1 of the inverted 3x3 transform per image
+// ([N][6] float64, built on the host with the reference's own numpy operations -- cu_net_amd/trainer.py) and the kernel applies it as
+// np.dot(t, [x - 1, y - 1, 1]) does: a 3-term float64 dot product per coordinate, accumulated in k order by fused multiply-adds from
+// zero (what the BLAS dgemm kernels behind np.dot do on x86-64), then astype(int) + 1.
 __global__ __launch_bounds__(256) void final_preds_kernel(const float* __restrict__ heat, const float* __restrict__ center,
-                                                          const float* __restrict__ scale, float* __restrict__ preds,
+                                                          const float* __restrict__ scale, const double* __restrict__ inv,
+                                                          float* __restrict__ preds,
                                                           int maps, int K, int H, int W, int res0, int res1) {
     const int lane = threadIdx.x & 63;
     const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -795,6 +928,15 @@ __global__ __launch_bounds__(256) void final_preds_kernel(const float* __restric
     x += 0.5f;
     y += 0.5f;
     const int n = map / K;
+    if (inv != nullptr) {
+        const double* t = inv + (size_t)n * 6;
+        const double xd = (double)(x - 1.f), yd = (double)(y - 1.f);      // (pts - 1 is float32 arithmetic, then concatenated to float64)
+        const double nx = __fma_rn(t[2], 1.0, __fma_rn(t[1], yd, __dmul_rn(t[0], xd)));
+        const double ny = __fma_rn(t[5], 1.0, __fma_rn(t[4], yd, __dmul_rn(t[3], xd)));
+        preds[(size_t)map * 2 + 0] = (float)((long long)nx + 1);
+        preds[(size_t)map * 2 + 1] = (float)((long long)ny + 1);
+        return;
+    }
     const float hh = 200.f * scale[n];                       // float32 arithmetic, as numpy does for float32 scalars
     const float a32 = (float)res0 / hh;
     const float b32 = (float)res0 * (-center[2 * n + 0] / hh + 0.5f);
@@ -807,9 +949,9 @@ __global__ __launch_bounds__(256) void final_preds_kernel(const float* __restric
     preds[(size_t)map * 2 + 1] = (float)((long long)ny + 1);
 }
 
-hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,
+hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, const double* inv, float* preds, int N, int K,
                               int H, int W, int res0, int res1, hipStream_t s) {
-    hipLaunchKernelGGL(final_preds_kernel, dim3((N * K + 3) / 4), dim3(256), 0, s, heat, center, scale, preds, N * K, K, H, W, res0, res1);
+    hipLaunchKernelGGL(final_preds_kernel, dim3((N * K + 3) / 4), dim3(256), 0, s, heat, center, scale, inv, preds, N * K, K, H, W, res0, res1);
     return hipGetLastError();
 }
 

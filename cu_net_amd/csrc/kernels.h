@@ -44,7 +44,7 @@ hipError_t launch_conv_bf16(const ConvArgs& a, int out_f32, int num_cus, hipStre
 hipError_t launch_conv_bf16_pair(const ConvArgs& a, const ConvArgs& b, int num_cus, hipStream_t s);       // as launch_conv_pair (bf16 out)
 hipError_t launch_render_targets(const double* pts, const float* patch, int half, float* out, int NK, int H, int W, hipStream_t s);
 hipError_t launch_flip_merge(const float* a, const float* b, const int* perm, float* out, int N, int K, int H, int W, hipStream_t s);
-hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, float* preds, int N, int K,
+hipError_t launch_final_preds(const float* heat, const float* center, const float* scale, const double* inv, float* preds, int N, int K,
                               int H, int W, int res0, int res1, hipStream_t s);
 hipError_t launch_augment(const AugSample* tab_dev, const AugSample* tab_host, int n, float* out, int res, hipStream_t s);
 hipError_t launch_get_preds(const float* heat, float* preds, int maps, int H, int W, hipStream_t s);

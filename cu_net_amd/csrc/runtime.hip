@@ -1329,7 +1329,15 @@ int cunet_final_preds(const float* heat, const float* center, const float* scale
     // out of bounds -- the reference raises IndexError there
     if (res0 < 1 || res1 < 1 || res0 > w || res1 > hh) return fail(CUNET_ERR_INVALID, "final_preds: res exceeds the heat map");
     if (hh != w) return fail(CUNET_ERR_INVALID, "final_preds: square heat maps only (the reference's y = floor(idx / size(2)) + 1 is a row index only then)");
-    HIPCHK(launch_final_preds(heat, center, scale, preds, n, k, hh, w, res0, res1, (hipStream_t)stream));
+    HIPCHK(launch_final_preds(heat, center, scale, nullptr, preds, n, k, hh, w, res0, res1, (hipStream_t)stream));
+    return CUNET_OK;
+}
+
+int cunet_final_preds_affine(const float* heat, const double* inv, float* preds, int n, int k, int hh, int w, int res0, int res1, void* stream) {
+    if (!heat || !inv || !preds || n < 1 || k < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    if (res0 < 1 || res1 < 1 || res0 > w || res1 > hh) return fail(CUNET_ERR_INVALID, "final_preds: res exceeds the heat map");
+    if (hh != w) return fail(CUNET_ERR_INVALID, "final_preds: square heat maps only (the reference's y = floor(idx / size(2)) + 1 is a row index only then)");
+    HIPCHK(launch_final_preds(heat, nullptr, nullptr, inv, preds, n, k, hh, w, res0, res1, (hipStream_t)stream));
     return CUNET_OK;
 }
 

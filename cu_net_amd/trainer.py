@@ -135,16 +135,49 @@ def get_preds(scores: torch.Tensor) -> torch.Tensor:
     return preds
 
 
+def _inverse_crop_transforms(center: torch.Tensor, scale: torch.Tensor, rot: torch.Tensor, res: int, size: int = 200):
+    """Rows 0 and 1 of inv(GetTransform(center, scale, rot, res, size)) per image, N x 6 float64 (pylib/Evaluation.py:152-178,
+    inverted as TransformPts :183-184 does).  Host-side numpy with the REFERENCE'S dtypes: it receives float32 0-d arrays
+    (`center[i].numpy()` ...), so size * scale, res / h, the translation terms and the angle in radians -- hence sin / cos -- are
+    float32 results stored into a float64 matrix; the 3x3 products and the inverse are float64 (np.dot / np.linalg.inv)."""
+    import numpy as np
+    c = center.detach().cpu().float().numpy()
+    s = scale.detach().cpu().float().numpy()
+    r = rot.detach().cpu().float().numpy()
+    out = np.zeros((c.shape[0], 6))
+    half = res / 2
+    to_centre = np.array([[1.0, 0.0, -half], [0.0, 1.0, -half], [0.0, 0.0, 1.0]])
+    back = np.array([[1.0, 0.0, half], [0.0, 1.0, half], [0.0, 0.0, 1.0]])
+    for i in range(c.shape[0]):
+        h = size * s[i]                                    # float32
+        zoom = float(res) / h                              # float32
+        t = np.array([[zoom, 0.0, res * (-float(c[i, 0]) / h + .5)],
+                      [0.0, zoom, res * (-float(c[i, 1]) / h + .5)],
+                      [0.0, 0.0, 1.0]], dtype=np.float64)
+        if r[i] != 0:
+            rad = -r[i] * np.pi / 180                      # float32 (to match the direction of the crop's rotation, :164)
+            sn, cs = np.sin(rad), np.cos(rad)              # float32
+            turn = np.array([[cs, -sn, 0.0], [sn, cs, 0.0], [0.0, 0.0, 1.0]], dtype=np.float64)
+            t = np.dot(back, np.dot(turn, np.dot(to_centre, t)))          # rotate about the centre of the crop (:171-177)
+        out[i] = np.linalg.inv(t)[:2].reshape(6)
+    return out
+
+
 def final_preds(output: torch.Tensor, center: torch.Tensor, scale: torch.Tensor, res, rot=None) -> torch.Tensor:
-    """pylib/Evaluation.py:108-132 on the GPU for rot == 0 (the validation path, cu-net.py:272):
-    N x K x H x W heat maps + per-image crop centre / scale -> N x K x 2 original-image coordinates."""
-    if rot is not None and bool(torch.as_tensor(rot).ne(0).any()):
-        raise CUNetError('final_preds: only rot == 0 (validation) is implemented on the HIP path')
+    """pylib/Evaluation.py:108-132 on the GPU: N x K x H x W heat maps + per-image crop centre / scale (/ rotation in degrees) ->
+    N x K x 2 original-image coordinates.  rot == 0 everywhere (the validation path, cu-net.py:272): the whole transform on the
+    device (cunet_final_preds); any rot != 0: the 3x3 inverse per image on the host, applied on the device (cunet_final_preds_affine)."""
     if not output.is_cuda:
         raise CUNetError('final_preds: GPU tensor required (the CPU oracle is oracle/decode_ref.py)')
     s = output.contiguous().float()
     n, k, h, w = s.shape
     dev = s.device
+    if rot is not None and bool(torch.as_tensor(rot).ne(0).any()):
+        inv = torch.from_numpy(_inverse_crop_transforms(center, scale, torch.as_tensor(rot), int(res[0]))).to(dev)
+        preds = torch.empty((n, k, 2), dtype=torch.float32, device=dev)
+        check(lib().cunet_final_preds_affine(_ptr(s), _ptr(inv), _ptr(preds), n, k, h, w, int(res[0]), int(res[1]),
+                                             _stream_ptr(dev)), 'cunet_final_preds_affine')
+        return preds
     c = center.contiguous().float().to(dev)
     sc = scale.contiguous().float().to(dev)
     preds = torch.empty((n, k, 2), dtype=torch.float32, device=dev)

@@ -219,6 +219,12 @@ int cunet_profile_get_stream(const cunet_plan_t* plan, int cls, int which, int64
  *   center: N x 2, scale: N (fp32, device); res0/res1: heat-map resolution bounds of the refinement test */
 int cunet_final_preds(const float* heat, const float* center, const float* scale, float* preds, int n, int k,
                       int h, int w, int res0, int res1, void* stream);
+/* the same decode for ANY crop transform, i.e. rot != 0 (pylib/Evaluation.py:163-178, the rotation branch of GetTransform):
+ *   inv: N x 6 float64 (device) -- rows 0 and 1 of np.linalg.inv(GetTransform(center, scale, rot, res, 200)) per image, built by the
+ *   host (cu_net_amd/trainer.py:_inverse_crop_transforms does it with the reference's numpy operations and dtypes);
+ *   new = inv . [x - 1, y - 1, 1] in float64 (fused multiply-adds in k order), truncated toward zero, + 1 (:180-187). */
+int cunet_final_preds_affine(const float* heat, const double* inv, float* preds, int n, int k, int h, int w, int res0, int res1,
+                             void* stream);
 
 /* flip test-time augmentation merge: replaces cu-net.py:247-249 + pylib/HumanAug.py:177-208
  * (flip_channels, shuffle_channels_for_horizontal_flipping), which the reference runs on the CPU:

@@ -78,7 +78,8 @@ def final_preds(output: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
     coords += 0.5
     preds = coords.clone()
     for i in range(coords.size(0)):
-        pts = transform_pts(coords[i].numpy(), center[i].numpy(), scale[i].numpy(), float(rot[i]), res[0], size=200, invert=1)
+        # (transform_preds :134-150 hands GetTransform float32 0-d arrays -- `rot.numpy()` too: the angle, its sine and cosine are float32)
+        pts = transform_pts(coords[i].numpy(), center[i].numpy(), scale[i].numpy(), rot[i].float().numpy(), res[0], size=200, invert=1)
         preds[i] = torch.from_numpy(pts)
     return preds
 

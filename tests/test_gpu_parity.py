@@ -343,6 +343,24 @@ def test_decode_matches_reference_vectors():
     assert torch.equal(fp.cpu(), torch.from_numpy(z['final_preds']))
 
 
+def test_decode_with_rotation_matches_reference_vectors():
+    """final_preds with rot != 0 (the rotation branch of GetTransform, pylib/Evaluation.py:163-178; one image of the batch keeps
+    rot == 0) against the EXECUTED reference (G8r): bit-exact integer coordinates."""
+    import numpy as np
+    from tests._golden import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'G8r_decode_rot.npz'))
+    hm = torch.from_numpy(z['heat']).cuda()
+    fp = cu_net_amd.final_preds(hm, torch.from_numpy(z['center']), torch.from_numpy(z['scale']), [64, 64], torch.from_numpy(z['rot']))
+    assert torch.equal(fp.cpu(), torch.from_numpy(z['final_preds']))
+    z0 = np.load(os.path.join(GOLDEN_DIR, 'G8_decode.npz'))      # and the affine entry point reproduces the rot == 0 vectors as well
+    from cu_net_amd.trainer import _inverse_crop_transforms, _ptr, _stream_ptr
+    from cu_net_amd._lib import check, lib
+    inv = torch.from_numpy(_inverse_crop_transforms(torch.from_numpy(z0['center']), torch.from_numpy(z0['scale']), torch.zeros(hm.shape[0]), 64)).cuda()
+    preds = torch.empty((hm.shape[0], hm.shape[1], 2), dtype=torch.float32, device='cuda')
+    check(lib().cunet_final_preds_affine(_ptr(hm), _ptr(inv), _ptr(preds), hm.shape[0], hm.shape[1], 64, 64, 64, 64, _stream_ptr(hm.device)), 'affine')
+    assert torch.equal(preds.cpu(), torch.from_numpy(z0['final_preds']))
+
+
 def test_flip_merge_and_accuracy_bit_exact():
     """Validation-loop pieces on the GPU vs the reference's vectors (G10) and the oracle: flip-TTA merge is
     bit-exact ((a + b) / 2 in fp32), PCK accuracy is exact (integer coordinates, IEEE sqrt / divide)."""

@@ -37,6 +37,43 @@ def test_decode_oracle_matches_reference_vectors():
     assert DR.get_preds(hm)[1, 2].tolist() == [21.0, 11.0]             # tie -> lowest flat index (y=10, x=20)
 
 
+def test_decode_with_rotation_oracle_and_host_transform_match_reference_vectors():
+    """G8r: final_preds with rot != 0, executed reference (pylib/Evaluation.py:108-187).  The oracle reproduces it, and so does the
+    product's HOST half of the rotated decode -- cu_net_amd.trainer._inverse_crop_transforms, the per-image inverse 3x3 transform --
+    applied the way the device kernel applies it (3-term float64 dot product by fused multiply-adds in k order, emulated exactly with
+    rationals; truncation; + 1) to the oracle's refined coordinates."""
+    from fractions import Fraction
+    from cu_net_amd.trainer import _inverse_crop_transforms
+    z = np.load(os.path.join(GOLDEN_DIR, 'G8r_decode_rot.npz'))
+    hm, center, scale, rot = (torch.from_numpy(z[k]) for k in ('heat', 'center', 'scale', 'rot'))
+    want = torch.from_numpy(z['final_preds'])
+    assert torch.equal(DR.final_preds(hm, center, scale, [64, 64], rot), want)
+    inv = _inverse_crop_transforms(center, scale, rot, 64)
+    assert inv.shape == (4, 6) and inv.dtype == np.float64
+    # refined heat-map coordinates: final_preds with the identity crop (center = res / 2 = 32, scale = res / 200: zoom 1, no shift) gives
+    # trunc(c - 1) + 1; recover c itself from the oracle's pieces instead: get_preds + the quarter-pixel shift + 0.5
+    coords = DR.get_preds(hm)
+    for n in range(coords.size(0)):
+        for p in range(coords.size(1)):
+            px, py = int(np.floor(float(coords[n, p, 0]))), int(np.floor(float(coords[n, p, 1])))
+            if 1 < px < 64 and 1 < py < 64:
+                d = torch.tensor([hm[n, p, py - 1, px] - hm[n, p, py - 1, px - 2], hm[n, p, py, px - 1] - hm[n, p, py - 2, px - 1]])
+                coords[n, p] += d.sign() * .25
+    coords += 0.5
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))      # exact product and sum, one rounding
+
+    got = torch.zeros_like(want)
+    for n in range(coords.size(0)):
+        t = [float(v) for v in inv[n]]
+        for p in range(coords.size(1)):
+            xd, yd = float(np.float32(coords[n, p, 0]) - np.float32(1)), float(np.float32(coords[n, p, 1]) - np.float32(1))
+            got[n, p, 0] = int(fma(t[2], 1.0, fma(t[1], yd, t[0] * xd))) + 1
+            got[n, p, 1] = int(fma(t[5], 1.0, fma(t[4], yd, t[3] * xd))) + 1
+    assert torch.equal(got, want)
+
+
 def test_ternary_reference_is_exact_in_fp32():
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 64, 6, 6, generator=g)

@@ -181,3 +181,61 @@ def test_shard_batch_matches_dataparallel_chunking():
             lo, hi = shard_batch(192, r, world)
             assert torch.equal(x[lo:hi], chunks[r])
     assert shard_batch(10, 3, 4) == (9, 10)
+
+
+CFG4 = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=8, order=1, loss_num=8)      # BASELINE config 4's network
+
+
+def _worker8(rank, world, port, q):
+    """World size 8 over gloo with the REAL bucket table of BASELINE config 4 (CU-Net-8, K = 16: nine buckets, 32 MB of gradients,
+    24 images per rank): state broadcast from rank 0, the nine all-reduces in backward's completion order with `overlap=True`,
+    finish(), 1/world.  Every element of the arena is an exactly representable small integer pattern (rank + 1) * f(index), so the
+    sum over 8 ranks is exact in fp32 whatever order gloo's ring adds in: the check is torch.equal, per bucket."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        plan = PlanHandle(**CFG4, batch=24, height=256, width=256)
+        buckets, numel, order = plan.buckets(), plan.param_numel, plan.bucket_order()
+        assert len(buckets) == 9 and order == [7, 6, 5, 4, 3, 2, 1, 0, 8]
+        assert 31e6 < 4 * sum(c for _, c in buckets) < 33e6                      # SURVEY 8(e): 32.0 MB
+        assert shard_batch(192, rank, world) == (24 * rank, 24 * rank + 24)      # cu-net.py:59: contiguous chunks of the global batch
+        pg = dist.group.WORLD
+        base = (torch.arange(numel, dtype=torch.float32) % 1021.0) - 510.0       # |value| <= 510; times 36 = sum of (rank + 1): < 2^24
+        params = base * (1.0 if rank == 0 else -float(rank))
+        broadcast_state([params], 0, pg)
+        assert torch.equal(params, base)
+        grads = base * float(rank + 1)
+        red = BucketAllReducer(buckets, pg, overlap=True)
+        red.begin_step()
+        for b in order:
+            red.reduce_bucket(grads, b)
+        red.finish(grads)
+        assert red.reduced == order and red.world == 8
+        total = float(sum(range(1, world + 1)))
+        inside = torch.zeros(numel, dtype=torch.bool)
+        for b, (begin, count) in enumerate(buckets):
+            inside[begin:begin + count] = True
+            assert torch.equal(grads[begin:begin + count], base[begin:begin + count] * total), f'bucket {b}'
+        assert torch.equal(grads[~inside], (base * float(rank + 1))[~inside])   # alignment padding between buckets: untouched
+        q.put((rank, 'ok'))
+    except Exception:   # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_config4_bucket_table_gloo():
+    """The first time 8 ranks meet must not be the first hardware run (cu-net.py:59 on the 8 GPUs of a node)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(r, 'ok') for r in range(8)], res

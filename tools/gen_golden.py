@@ -540,6 +540,15 @@ def decode_parity():
     np.savez_compressed(os.path.join(OUT, 'G8_decode.npz'), heat=to_np(hm), center=to_np(center), scale=to_np(scale),
                         get_preds=to_np(ref_gp), final_preds=to_np(ref_fp))
     print('G8: get_preds / final_preds on 4x16 maps: oracle == reference')
+    # G8r: the rotation branch of GetTransform (pylib/Evaluation.py:163-178) -- the same maps decoded with per-image rot != 0 (one image
+    # keeps rot == 0: a batch may mix them), augmentation-sized and large angles
+    rot = torch.tensor([30.0, -17.5, 0.0, 171.25])
+    ref_fr = ev.final_preds(hm, center, scale, [64, 64], rot)
+    check('G8r/final_preds', ref_fr, DR.final_preds(hm, center, scale, [64, 64], rot))
+    assert not torch.equal(ref_fr, ref_fp)
+    np.savez_compressed(os.path.join(OUT, 'G8r_decode_rot.npz'), heat=to_np(hm), center=to_np(center), scale=to_np(scale), rot=to_np(rot),
+                        final_preds=to_np(ref_fr))
+    print('G8r: final_preds with rot != 0 on 4x16 maps: oracle == reference')
 
 
 
