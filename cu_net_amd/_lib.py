@@ -87,6 +87,7 @@ def lib():
         'cunet_quant_grad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         'cunet_ternary_pack': (i32, [vp, vp, vp, i32, i32, i32, vp]),
         'cunet_ternary_conv': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+        'cunet_ternary_conv_ex': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
         'cunet_debug_run_node_backward': (i32, [vp, i32, vp]),
         'cunet_profile_begin': (i32, [vp, i32, i32]),
         'cunet_profile_reset': (i32, [vp]),
@@ -112,7 +113,7 @@ EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set
             'cunet_forward', 'cunet_loss_mse', 'cunet_loss_mse_fused', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
             'cunet_bucket_range', 'cunet_rmsprop_step', 'cunet_get_preds', 'cunet_final_preds', 'cunet_final_preds_affine', 'cunet_flip_merge', 'cunet_augment_batch', 'cunet_render_targets',
             'cunet_debug_tensor_offset', 'cunet_quant_prepare', 'cunet_quant_restore', 'cunet_quant_grad',
-            'cunet_ternary_pack', 'cunet_ternary_conv', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
+            'cunet_ternary_pack', 'cunet_ternary_conv', 'cunet_ternary_conv_ex', 'cunet_debug_run_node_backward', 'cunet_profile_begin', 'cunet_profile_reset', 'cunet_profile_collect',
             'cunet_profile_num_classes', 'cunet_profile_class_name', 'cunet_profile_get', 'cunet_profile_get_stream']
 
 
@@ -126,7 +127,7 @@ def check(rc: int, what: str = ''):
 PLANNER_OPTIONS = ('wgrad3_min_rows', 'wgrad3_min_chunks', 'wgrad3_max_splits', 'wgrad3_min_chunks_bf16', 'wgrad3_max_splits_bf16',
                    'wgrad3_stem', 'conv3x3_ring_min_rows', 'wgrad_fork_group', 'wgrad_fork_group_bf16', 'fwd_fork_min_w', 'pair_adapters',
                    'heads_on_side', 'dgrad_nt', 'wgrad_bf16_dma', 'fuse_wgrad', 'dgrad_prefetch', 'dgrad_rows', 'f32_split', 'dgrad3_nt',
-                   'dgrad3_ring', 'stem_split')
+                   'dgrad3_ring', 'stem_split', 'dgrad_rows_v', 'popcount_pixels')
 
 
 def set_planner_option(name: str, value: int):

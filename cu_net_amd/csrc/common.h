@@ -88,6 +88,8 @@ struct ConvArgs {
                            // block's partial tile into wg_part[row block][K][Nout]; the bucket's reduce kernel sums the row blocks
     int dgrad_rows;        // EP_BWD, fp32 1x1 over K = 128: > 0 = launches with at least this many 32-row tiles run dgrad1x1_rows_kernel (all columns
                            // of a row tile in one workgroup, dY staged once by LDS-DMA); 0 = always the column-sliced kernel (planner option dgrad_rows)
+    int dgrad_rows_v;      // which row-tile kernel on the split contraction: 2 = dgrad1x1_rows_split2_kernel (round 5: counted waits, pipelined plane
+                           // reads), 1 = dgrad1x1_rows_split_kernel (round 4) -- planner option dgrad_rows_v
     int dgrad_prefetch;    // EP_BWD, fp32 1x1 over K = 128, one channel tile per wave: 2 = two chunks of dY in flight per wave (conv_body's PF2 loop),
                            // else one (the plan's snapshot of planner option dgrad_prefetch)
     int dgrad3_ring;       // EP_BWD, fp32 3x3 on the split contraction: > 0 = launches over at least this many image rows run dgrad3x3_ring_split_kernel
@@ -261,6 +263,8 @@ struct TernArgs {
     const float* gamma; const float* beta; const float* rmean; const float* rvar;
     int training;
     double* ystats;          // [2][O] sum / sum of squares of the output (or null)
+    int variant;             // plan path: 1 = ternary_conv_pixels_kernel (lane = pixel, round 5), 0 = ternary_conv_planes_kernel (wave = pixel)
+    int pad_;
     uint64_t* planes;        // plan path: [M + 1][16] bit-plane records of the quantised input (ternary_planes_kernel), or null
 };
 // One record of 16 words per input pixel: words [7 g + b] = bit b of the quantised activation of channels 64 g .. 64 g + 63 (g < 2,

@@ -1334,6 +1334,217 @@ __global__ __launch_bounds__(DRS_MAX_WAVES * 64, 2) void dgrad1x1_rows_split_ker
     }
 }
 
+// Round 5: the same kernel with the vector-memory queue under the kernel's own control (planner option dgrad_rows_v = 2, the default).
+// What the round-4 kernel's ISA showed (tools/isa_scan.py and a reading of the tile loop): (1) every iteration began with
+// `s_waitcnt vmcnt(0)` and ended -- compiler-inserted, in front of the register moves that rotate the x look-ahead -- with another
+// vmcnt(0): the dz stores a wave had issued a few instructions earlier had to be ACKNOWLEDGED before the wave could even reach the
+// barrier, a full store round trip exposed per 32-row tile, twice; (2) the 24 ds_read_b128 of a tile's operand planes were issued three
+// at a time and waited for right in front of their MFMAs; (3) 128 lane-wise fp64 LDS atomics per wave and tile for the BatchNorm sums.
+// Here (1) the x pieces are requested by inline asm (invisible to the compiler's counter bookkeeping, like the LDS-DMA requests), go to
+// the wave's LDS tile at the TOP of the next iteration and their registers are re-used for the next request at once -- no look-ahead
+// copy, no compiler wait -- and the one wait per iteration is `vmcnt(4)`: everything this wave has asked for has landed EXCEPT the four
+// dz stores of the previous tile, which complete under this tile's work; (2) the planes of step s + 1 are requested in front of the six
+// MFMAs of step s (pinned with sched_barrier); (3) the sums stay in two fp64 registers per lane until the end of the launch.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void drs_req16(f32x4a& v, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+}
+template <int N> __device__ __forceinline__ void drs_wait(f32x4a& a, f32x4a& b, f32x4a& c, f32x4a& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(DRS_MAX_WAVES * 64, 2) void dgrad1x1_rows_split2_kernel(const ConvArgs p, int cgroups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    // LDS: [ring 3 x 16 KB][planes 2 x 24 KB][T tiles: waves x 32 x 36 floats][group table][sc sh mu is][fp64 sums 2 x Ccat]
+    char* ring = smem;
+    u32x4* planes = reinterpret_cast<u32x4*>(smem + DR_SLOTS * DR_SLOT);
+    float* tileT = reinterpret_cast<float*>(smem + DR_SLOTS * DR_SLOT + 2 * DRS_PLANES);
+    GrpEnt* grp = reinterpret_cast<GrpEnt*>(tileT + (size_t)nwaves * 32 * 36);
+    float* sc = reinterpret_cast<float*>(grp + (p.Ccat >> 2));
+    float* sh = sc + p.Ccat;
+    float* mu = sh + p.Ccat;
+    float* is = mu + p.Ccat;
+    double* redbuf = reinterpret_cast<double*>(is + p.Ccat);      // [Ccat][2]
+    const unsigned ring0 = (unsigned)(size_t)ring;
+
+    setup_concat<true, 0>(p, grp, sc, sh, mu, is);
+    for (int i = tid; i < 2 * p.Ccat; i += blockDim.x) redbuf[i] = 0.0;
+
+    const int group = blockIdx.x % cgroups;
+    const int col0 = (group * nwaves + wave) * 32;                // this wave's 32 columns
+    const bool active = col0 < p.Ccat;                            // (the last group may carry idle waves: they stage and cut with the others)
+    const int colw = active ? col0 : 0;
+    u32x4 bh[8], bm[8], bl[8];                                    // this wave's 128 x 32 slice of the backward operand, cut once per launch
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+        const float4 w0 = ldg4(p.wB + ((size_t)(4 * s8 + hi) * p.Npad + colw + li) * 4);
+        const float4 w1 = ldg4(p.wB + ((size_t)(4 * s8 + 2 + hi) * p.Npad + colw + li) * 4);
+        const float f[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        split_bf16x3(f, bh[s8], bm[s8], bl[s8]);
+    }
+
+    const int ntiles = p.M >> 5;
+    const int gstride = gridDim.x / cgroups;
+    int tile = blockIdx.x / cgroups;
+    auto issue = [&](int t, int slot) {                           // LDS-DMA requests of a tile: q = wave, wave + nwaves, ... < 16
+        const float* src = p.a + (size_t)(t * 32 + li) * p.lda + 4 * hi;
+        for (int q = wave; q < 16; q += nwaves)
+            dr_dma16(src + 8 * q, __builtin_amdgcn_readfirstlane(ring0 + (unsigned)(slot * DR_SLOT + q * 1024)));
+    };
+    auto cut = [&](int slot, int pb) {                            // ring slot -> operand planes pb: item (step s, lane l) = requests 2 s, 2 s + 1
+        const float4* R = reinterpret_cast<const float4*>(ring + slot * DR_SLOT);
+        u32x4* P = planes + (size_t)pb * (DRS_PLANES / 16);
+        for (int i = tid; i < 512; i += blockDim.x) {
+            const int s8 = i >> 6, l = i & 63;
+            const float4 a0 = R[(2 * s8) * 64 + l], a1 = R[(2 * s8 + 1) * 64 + l];
+            const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            u32x4 h, m, lo;
+            split_bf16x3(f, h, m, lo);
+            P[(s8 * 3 + 0) * 64 + l] = h;
+            P[(s8 * 3 + 1) * 64 + l] = m;
+            P[(s8 * 3 + 2) * 64 + l] = lo;
+        }
+    };
+    for (int k = 0; k < 3; ++k)
+        if (tile + k * gstride < ntiles) issue(tile + k * gstride, k);
+
+    const int pc4 = lane & 7, pr0 = lane >> 3;        // this lane's 16-byte pieces of a 32 x 32 tile: column piece, first row (+ 8 j)
+    const int HW = p.H * p.W;
+    __syncthreads();                                   // tables visible
+    const int col = colw + li;
+    const float csc = sc[col], csh = sh[col], cmu = mu[col], cis = is[col];
+    const GrpEnt pg = grp[(colw + 4 * pc4) >> 2];
+    f32x4a xq[4];                                      // the x pieces on the way (asm requests: the compiler does not count them)
+    auto request_x = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = t * 32 + pr0 + 8 * j;
+            int row = mm;
+            if (p.any_ups && pg.ups) {                 // (a branch around arithmetic only)
+                int ni, yy, xx;
+                if (p.wshift >= 0) { ni = mm >> p.hwshift; const int rm = mm & (HW - 1); yy = rm >> p.wshift; xx = rm & (p.W - 1); }
+                else { ni = mm / HW; const int rm = mm - ni * HW; yy = rm / p.W; xx = rm - yy * p.W; }
+                row = ni * (HW >> 2) + (yy >> 1) * (p.W >> 1) + (xx >> 1);
+            }
+            drs_req16(xq[j], pg.ptr + (size_t)row * pg.ld);
+        }
+    };
+    request_x(tile < ntiles ? tile : 0);
+    drs_wait<0>(xq[0], xq[1], xq[2], xq[3]);           // the first tiles' DMA pieces and x
+    __syncthreads();
+    if (tile < ntiles) cut(0, 0);
+    float* T = tileT + (size_t)wave * 32 * 36;
+    double sum1 = 0.0, sum2 = 0.0;                     // this lane's share of sum(dz), sum(dz * xhat) of column `col`
+    // tuning builds, CUNET_CONV_DBG & 16384: shader cycles of a wave's phases summed over tiles into g_conv_phase (tools/ring_phase_clocks.py --rows):
+    // [1] the counted wait, [2] barrier, [3] x -> LDS tile + the next requests (LDS-DMA, x), [4] cut of the next tile's planes, [5] MFMAs
+    // (plane reads + chain), [6] epilogue + dz stores; [0] wave-tiles, [7] whole kernel
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const bool stamp = CUNET_DBG(p, 16384) != 0;
+    auto now = [&]() -> unsigned long long { return stamp ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long tk0 = now();
+    int k = 0;                                         // tiles done by this workgroup: ring slot k % 3, planes k & 1
+    for (; tile < ntiles; tile += gstride, ++k) {
+        // Everything this wave has requested has landed -- its DMA pieces of the next tiles, this tile's x -- except the previous tile's
+        // dz stores (the youngest four entries of the in-order queue), which finish under this tile.
+        const unsigned long long t0 = now();
+        if (active && k > 0) drs_wait<4>(xq[0], xq[1], xq[2], xq[3]);
+        else drs_wait<0>(xq[0], xq[1], xq[2], xq[3]);
+        const unsigned long long t1 = now();
+        __syncthreads();                               // everyone's pieces have; planes k & 1 are complete; ring slot k % 3 (cut one tile ago) is free
+        const unsigned long long t2 = now();
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4a*>(T + (pr0 + 8 * j) * 36 + 4 * pc4) = xq[j];
+        }
+        if (tile + 3 * gstride < ntiles) issue(tile + 3 * gstride, k % 3);
+        const bool more = tile + gstride < ntiles;
+        request_x(more ? tile + gstride : tile);       // next tile's x, into the registers just written out (no branch around a request)
+        const unsigned long long t3 = now();
+        if (more) cut((k + 1) % 3, (k + 1) & 1);       // the next tile's operands, in front of this tile's MFMAs
+        unsigned long long t4 = now(), t5 = t4;
+        if (active) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const u32x4* P = planes + (size_t)(k & 1) * (DRS_PLANES / 16) + lane;
+            u32x4 ah = P[0], am = P[64], al = P[128];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                u32x4 nh = ah, nm = am, nl = al;
+                if (s8 < 7) {
+                    nh = P[((s8 + 1) * 3 + 0) * 64];
+                    nm = P[((s8 + 1) * 3 + 1) * 64];
+                    nl = P[((s8 + 1) * 3 + 2) * 64];
+                    __builtin_amdgcn_sched_barrier(0);         // (the requests stay in front of this step's MFMAs)
+                }
+                acc = mfma_split6(ah, am, al, bh[s8], bm[s8], bl[s8], acc);
+                ah = nh; am = nm; al = nl;
+            }
+            if (stamp) { asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[15])); t5 = now(); }      // (the chain has landed before the stamp)
+            // BatchNorm / ReLU backward, first half (as conv_body's LDS-tile epilogue); x is in T since the top of the iteration
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float s1 = 0.f, s2 = 0.f;
+            float* tcol = T + li;
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fmaf(xv[r], csc, csh);
+                const float dz = (z > 0.f && (p.qin_bits == 0 || z < 1.f)) ? acc[r] : 0.f;      // ReLU mask (+ QuanInput's straight-through mask)
+                s1 += dz;
+                s2 = fmaf(dz, (xv[r] - cmu) * cis, s2);
+                xv[r] = dz;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tcol[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36] = xv[r];
+            sum1 += (double)s1;
+            sum2 += (double)s2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = pr0 + 8 * j;
+                *reinterpret_cast<float4*>(p.y + (size_t)(tile * 32 + rr) * p.ldy + col0 + 4 * pc4) = *reinterpret_cast<const float4*>(T + rr * 36 + 4 * pc4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next tile's x pieces overwrite T)
+            __builtin_amdgcn_wave_barrier();
+        }
+        const unsigned long long t6 = now();
+        ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += t6 - t5;
+    }
+#ifdef CUNET_TUNING
+    if (stamp && lane == 0 && active) {
+        atomicAdd(&g_conv_phase[0], (unsigned long long)k);
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
+        atomicAdd(&g_conv_phase[7], now() - tk0);
+    }
+#endif
+    (void)tk0; (void)ph;
+    drs_wait<0>(xq[0], xq[1], xq[2], xq[3]);
+    if (active) {
+        atomicAdd(&redbuf[col * 2 + 0], sum1);
+        atomicAdd(&redbuf[col * 2 + 1], sum2);
+    }
+    __syncthreads();
+    if (p.ystats != nullptr) {
+        for (int c = tid; c < nwaves * 32; c += blockDim.x) {      // this column group's sums
+            const int cc = group * nwaves * 32 + c;
+            if (cc < p.Ccat) {
+                atomic_add_f64(p.ystats + cc, redbuf[cc * 2 + 0]);
+                atomic_add_f64(p.ystats + p.Nout + cc, redbuf[cc * 2 + 1]);
+            }
+        }
+    }
+}
+
 static bool dgrad1x1_rows_supported(const ConvArgs& a) {
     if (a.taps != 1 || a.K != 128 || a.Kpad != 128 || a.xbf16 || a.M % 32 || a.Nout % 32 || a.Nout != a.Ccat || a.ldy != a.Nout || a.lda % 4 ||
         a.Nout / 32 < 4 || a.Nout / 32 > DR_MAX_WAVES || a.wg_part != nullptr || a.mse_tgt != nullptr)
@@ -1802,6 +2013,16 @@ static hipError_t launch_dgrad1x1_rows(const ConvArgs& a_in, int num_cus, hipStr
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad1x1_rows_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_split = true;
+        }
+        if (a.dgrad_rows_v >= 2) {
+            static bool attr_split2 = false;
+            if (!attr_split2) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad1x1_rows_split2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_split2 = true;
+            }
+            hipLaunchKernelGGL(dgrad1x1_rows_split2_kernel, dim3(streams * cgroups), dim3(wpg * 64), smem, s, a, cgroups);
+            return hipGetLastError();
         }
         hipLaunchKernelGGL(dgrad1x1_rows_split_kernel, dim3(streams * cgroups), dim3(wpg * 64), smem, s, a, cgroups);
         return hipGetLastError();

@@ -134,9 +134,9 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
 // arithmetic is 32-bit, two rows are in flight per thread (R = 2, plain consumers), and the launcher sizes the grid so that every
 // block walks the same number of row groups (3072 groups on 2048 blocks was 2 rounds for half of them, 1 for the rest).  Element for
 // element the same operations in the same order as the kernel above: bit-identical results.
-template <int NSRC, int UPS, int XBG>
+template <int NSRC, int UPS, int XBG, int V = 4>
 __global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherArgs p, int gshift) {
-    constexpr int XB = XBG != 0, GB = XBG == 2, V = 4;
+    constexpr int XB = XBG != 0, GB = XBG == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cE = reinterpret_cast<float*>(smem);
     float* cD = cE + p.C;
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherA
     }
 }
 
-template <int UPS, int XB>
+template <int UPS, int XB, int V = 4>
 static hipError_t launch_gather_rows_n(const GradGatherArgs& a, dim3 grid, size_t smem, int gshift, hipStream_t s) {
     switch (a.nsrc) {
-#define CUNET_G(N) case N: hipLaunchKernelGGL((grad_gather_rows_kernel<N, UPS, XB>), grid, dim3(256), smem, s, a, gshift); break;
+#define CUNET_G(N) case N: hipLaunchKernelGGL((grad_gather_rows_kernel<N, UPS, XB, V>), grid, dim3(256), smem, s, a, gshift); break;
         CUNET_G(1) CUNET_G(2) CUNET_G(3) CUNET_G(4) CUNET_G(5) CUNET_G(6) CUNET_G(7) CUNET_G(8)
 #undef CUNET_G
         default: return hipErrorInvalidValue;
@@ -270,20 +270,28 @@ hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t 
     if (gx > 8L * num_cus) gx = 8L * num_cus;
     if (gx < 1) gx = 1;
     const size_t smem = (size_t)a.C * 4 * (2 + a.nsrc);
-    const int gv = a.C / 4;
-    if (a.xbf16 != 2 && a.C % 4 == 0 && gv >= 1 && gv <= 256 && (gv & (gv - 1)) == 0 && (long)a.rows * a.ld < (1L << 31)) {
-        // fixed channel piece per thread (fp32 gradient tensors; C / 4 a power of two <= 256)
-        int gshift = 0;
-        while ((1 << gshift) < gv) ++gshift;
-        const int rpb = 256 >> gshift;
-        const long groups = ((long)a.rows + rpb - 1) / rpb;                 // row groups of one block round
-        const int R = a.src[0].ups ? 1 : 2;
-        long blocks = std::min(groups, 8L * num_cus);
-        const long rounds = (groups + blocks * R - 1) / (blocks * R);       // rounds of R row groups per block ...
-        blocks = std::max(1L, (groups + rounds * R - 1) / (rounds * R));    // ... and the fewest blocks that need no more
-        if (a.xbf16) return a.src[0].ups ? launch_gather_rows_n<1, 1>(a, dim3((unsigned)blocks), smem, gshift, s) : launch_gather_rows_n<0, 1>(a, dim3((unsigned)blocks), smem, gshift, s);
-        return a.src[0].ups ? launch_gather_rows_n<1, 0>(a, dim3((unsigned)blocks), smem, gshift, s) : launch_gather_rows_n<0, 0>(a, dim3((unsigned)blocks), smem, gshift, s);
+#ifndef CUNET_GATHER_FLAT      // (probe builds: -DCUNET_GATHER_FLAT keeps every launch on the flat-index kernel of rounds 1-4)
+    {   // fixed channel piece per thread: pieces per row a power of two <= 256 (every tensor of the network)
+        bool v8 = a.xbf16 == 2 && a.C % 8 == 0 && a.ld % 8 == 0;             // bf16 gradient tensors: 16-byte pieces of 8 channels
+        for (int e = 0; e < a.nsrc; ++e) v8 = v8 && a.src[e].lddz % 8 == 0 && a.src[e].choff % 8 == 0;
+        const int V = v8 ? 8 : 4;
+        const int gv = a.C / V;
+        if ((a.xbf16 != 2 || v8) && a.C % V == 0 && gv >= 1 && gv <= 256 && (gv & (gv - 1)) == 0 && (long)a.rows * a.ld < (1L << 31)) {
+            int gshift = 0;
+            while ((1 << gshift) < gv) ++gshift;
+            const int rpb = 256 >> gshift;
+            const long groups = ((long)a.rows + rpb - 1) / rpb;                 // row groups of one block round
+            const int R = a.src[0].ups ? 1 : 2;
+            long blocks = std::min(groups, 8L * num_cus);
+            const long rounds = (groups + blocks * R - 1) / (blocks * R);       // rounds of R row groups per block ...
+            blocks = std::max(1L, (groups + rounds * R - 1) / (rounds * R));    // ... and the fewest blocks that need no more
+            const dim3 grid((unsigned)blocks);
+            if (v8) return a.src[0].ups ? launch_gather_rows_n<1, 2, 8>(a, grid, smem, gshift, s) : launch_gather_rows_n<0, 2, 8>(a, grid, smem, gshift, s);
+            if (a.xbf16) return a.src[0].ups ? launch_gather_rows_n<1, 1>(a, grid, smem, gshift, s) : launch_gather_rows_n<0, 1>(a, grid, smem, gshift, s);
+            return a.src[0].ups ? launch_gather_rows_n<1, 0>(a, grid, smem, gshift, s) : launch_gather_rows_n<0, 0>(a, grid, smem, gshift, s);
+        }
     }
+#endif
     if (a.xbf16 == 2) {
         bool v8 = a.C % 8 == 0 && a.ld % 8 == 0;                 // 16-byte bf16 pieces everywhere
         for (int e = 0; e < a.nsrc; ++e) v8 = v8 && a.src[e].lddz % 8 == 0 && a.src[e].choff % 8 == 0;

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
     const int G = (p.C + 63) >> 6;
     for (int c = tid; c < 128; c += 256) {
         float sc = 0.f, sh = 0.f;
-        if (c < p.C) {
+        if (c < p.C && p.scale != nullptr) {                  // (the stand-alone operator: a folded scale / shift handed in)
+            sc = p.scale[c]; sh = p.shift[c];
+        } else if (c < p.C) {
             double mean, istd;
             if (p.training) {
                 mean = p.xstats[c] / p.count;
@@ -428,6 +430,184 @@ __global__ __launch_bounds__(TCP_THREADS) void ternary_conv_planes_kernel(const 
     }
 }
 
+// Third-generation AND-popcount forward (round 5, planner option popcount_pixels = 1, the default): LANE = PIXEL, the weight masks are
+// SCALAR operands.  The wave-per-pixel kernel above spends one v_readlane per plane dword to turn a VECTOR value (the plane word of its
+// pixel) into the scalar operand of v_and -- 252 readlanes + 252 v_and + 252 v_bcnt per pixel and 32 output channels, both signs.  Here
+// a wave owns 64 consecutive pixels (lane l = pixel m0 + l) and TPX_OC = 8 output channels: a lane keeps the 14 plane words of ITS pixel's
+// neighbour record in registers (seven 16-byte loads per tap; the records of a tensor stay in L2), the masks of the 8 output channels
+// arrive through the scalar cache (the address is wave-uniform) and sit in SGPRs: v_and_b32 v, s, v + v_bcnt_u32_b32 per dword, nothing
+// else.  And only ONE mask per weight word is counted: with P / N the +1 / -1 masks and Z = ~(P | N) the zero weights,
+//     popc(P & x) - popc(N & x) = 2 popc(P & x) - popc(x) + popc(Z & x),
+// where sum_b 2^b popc(x_b) over a record is the pixel sum the plane kernel already stores in word 14, and the Z term is skipped by a
+// scalar branch when a word has no zero weight (binary weights, utils/quantize.py:125-149 with bits_w = 1: always).  Per 64 pixels and
+// output channel: 9 taps x (28 v_and + 28 v_bcnt + 7 shift-adds) = 567 vector instructions = 8.9 per pixel and channel against 23.6.
+// Work item = (group of 64 pixels, chunk of 8 output channels); every integer stays below 2^24: bit-identical to the kernels above and to
+// the MFMA forward of the same node.  The output's batch statistics: per item a reduce-scatter over the 64 lanes (8 values -> one per
+// lane group) in exact integer / fp64 arithmetic, two LDS atomics on 8 lanes, one pair of global atomics per channel and block.
+constexpr int TPX_THREADS = 256;
+constexpr int TPX_OC = 8;
+
+template <int TAPS>
+__global__ __launch_bounds__(TPX_THREADS) void ternary_conv_pixels_kernel(const TernArgs p) {
+    __shared__ double s_red[2][32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = (p.C + 63) >> 6;
+    const int ocol0 = blockIdx.y * 32;                                  // this block column's 32 output channels
+    const int ocols = p.O - ocol0 < 32 ? p.O - ocol0 : 32;
+    const int nch = (ocols + TPX_OC - 1) / TPX_OC;                      // chunks of 8 output channels
+    if (tid < 64) s_red[tid >> 5][tid & 31] = 0.0;
+    __syncthreads();
+    const float qs = exp2f((float)(p.bits_i - 1));
+    const int HW = p.H * p.W;
+    const int groups = (p.M + 63) >> 6;
+    const int items = groups * nch;
+    const int stride = gridDim.x * (TPX_THREADS / 64);
+    const uint4* planes = reinterpret_cast<const uint4*>(p.planes);    // a record = 8 uint4 (TERN_REC_WORDS * 8 bytes)
+    typedef const __attribute__((address_space(4))) uint64_t* cmask_t;
+    const cmask_t cpos = (cmask_t)(uintptr_t)p.wpos, cneg = (cmask_t)(uintptr_t)p.wneg;
+    // valid-channel masks per group (channels >= C carry zero planes; their "zero weights" must not trigger the Z term)
+    const uint64_t valid0 = p.C >= 64 ? ~0ull : ((1ull << p.C) - 1ull);
+    const uint64_t valid1 = p.C >= 128 ? ~0ull : (p.C > 64 ? ((1ull << (p.C - 64)) - 1ull) : 0ull);
+
+    for (int item = blockIdx.x * (TPX_THREADS / 64) + wave; item < items; item += stride) {
+        const int grp = item / nch;
+        const int oc = item - grp * nch;
+        const int o0 = ocol0 + oc * TPX_OC;                             // wave-uniform
+        const int m = grp * 64 + lane;
+        const bool live = m < p.M;
+        const int mc = live ? m : p.M - 1;
+        const int ni = mc / HW;
+        const int rem = mc - ni * HW;
+        const int py = rem / p.W, px = rem - py * p.W;
+        int A[TPX_OC], Zt[TPX_OC];
+#pragma unroll
+        for (int j = 0; j < TPX_OC; ++j) { A[j] = 0; Zt[j] = 0; }
+        int S = 0;
+        auto fetch = [&](int t, uint4 (&w)[7], unsigned& sum) {               // the record of tap t's neighbour pixel (t is wave-uniform)
+            int row = mc;
+            if (TAPS == 9) {
+                const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+                const int yy = py + dy, xx = px + dx;
+                const bool inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;      // zero padding is post-activation
+                row = inside ? mc + dy * p.W + dx : p.M;                            // record M is all zero
+            }
+            const uint4* rec = planes + (size_t)row * (TERN_REC_WORDS / 2);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) w[k] = rec[k];                              // plane words 0 .. 13 (7 g + b)
+            sum = reinterpret_cast<const unsigned*>(rec)[28];                       // word 14: the record's sum of quantised activations
+        };
+        uint4 wn[7];
+        unsigned sn;
+        fetch(0, wn, sn);
+#pragma unroll 1
+        for (int t = 0; t < TAPS; ++t) {                                          // (not unrolled: nine taps of 28 plane dwords do not fit the registers)
+            uint4 w[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) w[k] = wn[k];
+            S += (int)sn;
+            if (t + 1 < TAPS) fetch(t + 1, wn, sn);                                 // the next tap's record is in flight during this tap's counting
+            // dwords of plane word i: lo = xs[2 i], hi = xs[2 i + 1]
+            const unsigned xs[28] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w, w[2].x, w[2].y, w[2].z, w[2].w,
+                                     w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x, w[5].y, w[5].z, w[5].w,
+                                     w[6].x, w[6].y, w[6].z, w[6].w};
+            // this tap's masks of the 8 output channels: wave-uniform addresses in the CONSTANT address space (nothing in this kernel writes
+            // the mask region) -- scalar loads, the words live in SGPRs and enter v_and as scalar operands
+            uint64_t Pm[2][TPX_OC], Zm[2][TPX_OC];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < TPX_OC; ++j) {
+                    // (unconditional loads -- a one-group conv re-reads group 0 and masks the result: no branch between the scalar loads)
+                    const size_t wi = ((size_t)t * G + (g < G ? g : 0)) * p.Opad + o0 + j;
+                    const uint64_t P = cpos[wi], N = cneg[wi];
+                    const uint64_t keep = g < G ? ~0ull : 0ull;
+                    Pm[g][j] = P & keep;
+                    Zm[g][j] = ~(P | N) & (g == 0 ? valid0 : valid1) & keep;
+                }
+#pragma unroll
+            for (int j = 0; j < TPX_OC; ++j) {
+                int c[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned Pl = (unsigned)Pm[g][j], Ph = (unsigned)(Pm[g][j] >> 32);
+#pragma unroll
+                    for (int b = 0; b < 7; ++b) c[b] = __popc(Ph & xs[2 * (7 * g + b) + 1]) + (__popc(Pl & xs[2 * (7 * g + b)]) + c[b]);
+                }
+                int a = 0;
+#pragma unroll
+                for (int b = 0; b < 7; ++b) a += c[b] << b;
+                A[j] += a;
+                if ((Zm[0][j] | Zm[1][j]) != 0) {                                   // (scalar branch: a weight word with zeros -- ternary weights)
+                    int z[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const unsigned Zl = (unsigned)Zm[g][j], Zh = (unsigned)(Zm[g][j] >> 32);
+#pragma unroll
+                        for (int b = 0; b < 7; ++b) z[b] = __popc(Zh & xs[2 * (7 * g + b) + 1]) + (__popc(Zl & xs[2 * (7 * g + b)]) + z[b]);
+                    }
+                    int zz = 0;
+#pragma unroll
+                    for (int b = 0; b < 7; ++b) zz += z[b] << b;
+                    Zt[j] += zz;
+                }
+            }
+        }
+        int yi[TPX_OC];
+#pragma unroll
+        for (int j = 0; j < TPX_OC; ++j) yi[j] = live ? 2 * A[j] - S + Zt[j] : 0;
+        // ---- store (8 consecutive channels per pixel)
+        if (live) {
+            float* yrow = p.y + (size_t)m * p.ldy + o0;
+            if (o0 + TPX_OC <= p.O && (p.ldy & 3) == 0) {
+                *reinterpret_cast<float4*>(yrow) = make_float4((float)yi[0] / qs, (float)yi[1] / qs, (float)yi[2] / qs, (float)yi[3] / qs);
+                *reinterpret_cast<float4*>(yrow + 4) = make_float4((float)yi[4] / qs, (float)yi[5] / qs, (float)yi[6] / qs, (float)yi[7] / qs);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TPX_OC; ++j)
+                    if (o0 + j < p.O) yrow[j] = (float)yi[j] / qs;
+            }
+        }
+        // ---- batch statistics of the output: sum y = sum yi / qs, sum y^2 = sum yi^2 / qs^2 (all exact)
+        if (p.ystats != nullptr) {
+            int v[TPX_OC];
+            double q[TPX_OC];
+#pragma unroll
+            for (int j = 0; j < TPX_OC; ++j) { v[j] = yi[j]; q[j] = (double)yi[j] * (double)yi[j]; }
+#pragma unroll
+            for (int step = 0; step < 3; ++step) {                                  // reduce-scatter: 8 -> 4 -> 2 -> 1 values per lane
+                const int mask = 32 >> step, half = 4 >> step;
+                const bool up = (lane & mask) != 0;
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    const int sendv = up ? v[j] : v[j + half], keepv = up ? v[j + half] : v[j];
+                    const double sendq = up ? q[j] : q[j + half], keepq = up ? q[j + half] : q[j];
+                    v[j] = keepv + __shfl_xor(sendv, mask, 64);
+                    q[j] = keepq + __shfl_xor(sendq, mask, 64);
+                }
+            }
+#pragma unroll
+            for (int mask = 4; mask > 0; mask >>= 1) {
+                v[0] += __shfl_xor(v[0], mask, 64);
+                q[0] += __shfl_xor(q[0], mask, 64);
+            }
+            const int jo = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);      // the channel this lane group summed
+            if ((lane & 7) == 0 && o0 + jo < p.O) {
+                atomicAdd(&s_red[0][oc * TPX_OC + jo], (double)v[0] / (double)qs);
+                atomicAdd(&s_red[1][oc * TPX_OC + jo], q[0] / ((double)qs * (double)qs));
+            }
+        }
+    }
+    if (p.ystats != nullptr) {
+        __syncthreads();
+        if (tid < 32 && ocol0 + tid < p.O) {
+            __hip_atomic_fetch_add(p.ystats + ocol0 + tid, s_red[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ystats + p.O + ocol0 + tid, s_red[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // every conv of a table in one launch: blockIdx.y = table entry (same packing as ternary_pack_kernel)
 __global__ __launch_bounds__(256) void ternary_pack_all_kernel(const TernPackEntry* __restrict__ tab, const float* __restrict__ params,
                                                                uint64_t* __restrict__ masks) {
@@ -492,10 +672,26 @@ hipError_t launch_ternary_pack_all(const TernPackEntry* tab, int n, const float*
 
 hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
     if ((a.taps != 1 && a.taps != 9) || a.bits_i < 2 || a.bits_i > 15) return hipErrorInvalidValue;
-    if (a.planes != nullptr && a.scale == nullptr && a.C <= 128 && a.bits_i <= 8) {      // plan path: bit-planes once per tensor
+    if (a.planes != nullptr && a.C <= 128 && a.bits_i <= 8) {      // plan path (and cunet_ternary_conv_ex): bit-planes once per tensor
         int gp = (a.M + 7) / 8;
         if (gp > 8 * num_cus) gp = 8 * num_cus;
         hipLaunchKernelGGL(ternary_planes_kernel, dim3(gp), dim3(256), 0, s, a);
+        if (a.variant != 0) {            // lane = pixel, masks as scalar operands (planner option popcount_pixels)
+            const int cols = (a.O + 31) / 32;
+            const int nch = ((a.O < 32 ? a.O : 32) + TPX_OC - 1) / TPX_OC;
+            const long items = (long)((a.M + 63) / 64) * nch;
+            long gxp = (items + TPX_THREADS / 64 - 1) / (TPX_THREADS / 64);
+            const long cap = 6L * num_cus;                                   // six 4-wave blocks per CU: the kernel's occupancy
+            if (gxp > cap) {
+                const long rounds = (gxp + cap - 1) / cap;                   // every wave walks the same number of items
+                gxp = (gxp + rounds - 1) / rounds;
+            }
+            if (gxp < 1) gxp = 1;
+            const dim3 gridp((unsigned)gxp, cols);
+            if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_pixels_kernel<9>), gridp, dim3(TPX_THREADS), 0, s, a);
+            else hipLaunchKernelGGL((ternary_conv_pixels_kernel<1>), gridp, dim3(TPX_THREADS), 0, s, a);
+            return hipGetLastError();
+        }
         int gx = (a.M + TCP_THREADS / 64 - 1) / (TCP_THREADS / 64);
         if (gx > num_cus) gx = num_cus;
         const dim3 grid(gx, (a.O + 31) / 32);

@@ -171,6 +171,8 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "fuse_wgrad") return &o.fuse_wgrad;
     if (n == "dgrad_prefetch") return &o.dgrad_prefetch;
     if (n == "dgrad_rows") return &o.dgrad_rows;
+    if (n == "dgrad_rows_v") return &o.dgrad_rows_v;
+    if (n == "popcount_pixels") return &o.popcount_pixels;
     if (n == "f32_split") return &o.f32_split;
     if (n == "dgrad3_nt") return &o.dgrad3_nt;
     if (n == "dgrad3_ring") return &o.dgrad3_ring;
@@ -578,6 +580,7 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     // (default -1: with the split contraction the 64 x 64 launches -- 3072 row tiles at batch 24 -- take the row-tile kernel, which cuts dY
     // into its bf16 pieces once per workgroup instead of once per column slice: +0.7 ... 1.7 % on the CU-Net-2 step; on the fp32 pipe never)
     a.dgrad_rows = P.opts.dgrad_rows >= 0 ? P.opts.dgrad_rows : (P.opts.f32_split ? 3072 : 0);
+    a.dgrad_rows_v = P.opts.dgrad_rows_v;
     a.split = P.opts.f32_split;
     // fp32 gradient tensors: this launch also computes the node's weight gradient (partial tiles; the bucket's reduce sums them)
     a.wg_part = (E.xmode == 0 && !h->fused_S.empty() && h->fused_S[node_index] > 0) ? E.wsf + n.wg3_part : nullptr;
@@ -931,6 +934,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
                 t.gamma = a.gamma; t.beta = a.beta; t.rmean = a.rmean; t.rvar = a.rvar; t.training = training ? 1 : 0;
                 t.ystats = a.ystats;
                 t.planes = reinterpret_cast<uint64_t*>(h->ws + P.off_planes);
+                t.variant = P.opts.popcount_pixels;
                 PROF(PC_TERN, 0.0, 4.0 * (double)a.M * (a.K + a.Nout), launch_ternary_conv(t, cus, s));
                 if (fuse_mse)       // (the AND-popcount kernel has no loss epilogue: this head's MSE is its own launch)
                     HIPCHK(launch_mse(E.act(n.out), E.wsf + P.target_off, E.grad(n.out), E.zero + P.loss_acc, (long)o.rows(), o.C, o.ld, o.ld, 0, cus, s));
@@ -1404,6 +1408,21 @@ int cunet_ternary_conv(const float* x, const float* scale, const float* shift, c
     a.x = x; a.scale = scale; a.shift = shift; a.wpos = wpos; a.wneg = wneg; a.y = y;
     a.M = n * hh * w; a.H = hh; a.W = w; a.C = c; a.O = o; a.Opad = round_up(o, 64); a.taps = taps; a.bits_i = bits_i;
     a.ldx = c; a.ldy = o;
+    hipError_t e = launch_ternary_conv(a, device_cus(), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? CUNET_ERR_INVALID : CUNET_ERR_HIP, std::string("ternary conv: ") + hipGetErrorString(e));
+    return CUNET_OK;
+}
+
+int cunet_ternary_conv_ex(const float* x, const float* scale, const float* shift, const uint64_t* wpos, const uint64_t* wneg,
+                          uint64_t* planes, float* y, double* ystats, int n, int hh, int w, int c, int o, int taps, int bits_i,
+                          int variant, void* stream) {
+    if (!x || !scale || !shift || !wpos || !wneg || !planes || !y || n < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
+    if (c > 128 || bits_i > 8 || bits_i < 2) return fail(CUNET_ERR_INVALID, "ternary conv on bit-plane records: C <= 128, 2 <= bits_i <= 8");
+    TernArgs a{};
+    a.x = x; a.scale = scale; a.shift = shift; a.wpos = wpos; a.wneg = wneg; a.y = y;
+    a.M = n * hh * w; a.H = hh; a.W = w; a.C = c; a.O = o; a.Opad = round_up(o, 64); a.taps = taps; a.bits_i = bits_i;
+    a.ldx = c; a.ldy = o;
+    a.planes = planes; a.ystats = ystats; a.variant = variant;
     hipError_t e = launch_ternary_conv(a, device_cus(), (hipStream_t)stream);
     if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? CUNET_ERR_INVALID : CUNET_ERR_HIP, std::string("ternary conv: ") + hipGetErrorString(e));
     return CUNET_OK;

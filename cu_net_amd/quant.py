@@ -97,6 +97,35 @@ class BinOp(QuanOp):
     updateBinaryGradWeight = QuanOp.updateQuanGradWeight
 
 
+def ternary_conv_planes(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, weight: torch.Tensor, bits_i: int = 8, variant: int = 1):
+    """The same operator as `ternary_conv` through the network's own two-kernel path (include/cunet.h cunet_ternary_conv_ex): bit-plane
+    records once per tensor, then AND + popcount -- variant 1: lane = pixel, weight masks as scalar operands; 0: wave = pixel.
+    Returns (y NCHW, per-channel [2][O] fp64 sums of y and y^2 as the consumer BatchNorms receive them)."""
+    if not x.is_cuda:
+        raise CUNetError('ternary_conv_planes: GPU tensor required (the CPU oracle is oracle/quant_ref.py)')
+    n, c, h, w = x.shape
+    o, ci, kh, kw = weight.shape
+    assert ci == c and kh == kw and kh in (1, 3)
+    taps = kh * kw
+    dev = x.device
+    xn = x.permute(0, 2, 3, 1).contiguous().float()
+    wt = weight.contiguous().float().to(dev)
+    opad = (o + 63) // 64 * 64
+    words = taps * ((c + 63) // 64) * opad
+    wpos = torch.zeros(words, dtype=torch.int64, device=dev)
+    wneg = torch.zeros(words, dtype=torch.int64, device=dev)
+    st = _stream_ptr(dev)
+    check(lib().cunet_ternary_pack(_ptr(wt), _ptr(wpos), _ptr(wneg), o, c, taps, st), 'cunet_ternary_pack')
+    planes = torch.empty((n * h * w + 1) * 16, dtype=torch.int64, device=dev)
+    y = torch.empty((n, h, w, o), dtype=torch.float32, device=dev)
+    stats = torch.zeros((2, o), dtype=torch.float64, device=dev)
+    sc = scale.contiguous().float().to(dev)
+    sh = shift.contiguous().float().to(dev)
+    check(lib().cunet_ternary_conv_ex(_ptr(xn), _ptr(sc), _ptr(sh), _ptr(wpos), _ptr(wneg), _ptr(planes), _ptr(y), _ptr(stats),
+                                      n, h, w, c, o, taps, int(bits_i), int(variant), st), 'cunet_ternary_conv_ex')
+    return y.permute(0, 3, 1, 2).contiguous(), stats
+
+
 def ternary_conv(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, weight: torch.Tensor, bits_i: int = 8):
     """y = conv2d(QuanInput_bits_i(relu(x * scale + shift)), weight) for weight in {-1,0,+1}, kernel 1x1 or 3x3 (pad 1),
     computed with AND + popcount over activation bit-planes (no multiplier, no MFMA).  x: N x C x H x W (NCHW, GPU)."""

@@ -197,6 +197,13 @@ int cunet_ternary_pack(const float* w, uint64_t* wpos, uint64_t* wneg, int o, in
 int cunet_ternary_conv(const float* x, const float* scale, const float* shift, const uint64_t* wpos,
                        const uint64_t* wneg, float* y, int n, int h, int w, int c, int o, int taps,
                        int bits_i, void* stream);
+/* the same operator through the two-kernel path the network's forward uses: the activation is quantised and cut into bit-plane records
+ * once (`planes`: (n*h*w + 1) * 16 uint64 of scratch, device), then counted by `variant` 1 = lane-per-pixel kernel with scalar masks
+ * (round 5), 0 = wave-per-pixel kernel (round 3).  c <= 128, bits_i <= 8.  ystats (nullable): [2][o] fp64, zeroed by the caller --
+ * receives sum(y), sum(y^2) per output channel, exact (integers / 2^(bits_i-1)). */
+int cunet_ternary_conv_ex(const float* x, const float* scale, const float* shift, const uint64_t* wpos, const uint64_t* wneg,
+                          uint64_t* planes, float* y, double* ystats, int n, int h, int w, int c, int o, int taps, int bits_i,
+                          int variant, void* stream);
 
 /* ---- per-kernel-class timing (bench.py roofline) ------------------------------------------------
  * HIP events are recorded on the launch stream around every launch of the selected class(es):
@@ -291,6 +298,14 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        its bf16 operand planes once per workgroup instead of once per column slice: +0.7 ... 1.7 % on the CU-Net-2 step when
  *                        only the 64 x 64 launches of batch 24 take it), 0 on the fp32 matrix pipe (measured equal alone, 1.60 vs 1.57 ms per
  *                        CU-Net-2 step, and 2.3 % slower in the step, where its nodes cannot share a launch as adapter pairs do)
+ *   "dgrad_rows_v"       which row-tile kernel "dgrad_rows" selects on the split contraction: 2 (default, round 5) = the kernel owns its
+ *                        vector-memory queue -- x by asm requests, ONE counted wait per tile that leaves the previous tile's dz stores in
+ *                        flight, operand planes read one step ahead, BatchNorm sums in registers; 1 = the round-4 kernel (two vmcnt(0)
+ *                        per tile).  Same arithmetic per element; the fp64 BatchNorm sums are added in another order
+ *   "popcount_pixels"    AND-popcount forward of the quantised-input mode (cunet_set_quant_input + cunet_set_popcount_live): 1 (default, round 5)
+ *                        = ternary_conv_pixels_kernel, lane = pixel with the weight masks as scalar operands and one mask per weight word
+ *                        (2 popc(P & x) - popc(x) + popc(Z & x)); 0 = ternary_conv_planes_kernel of round 3 (wave = pixel, v_readlane per plane
+ *                        word).  Integer arithmetic either way: bit-identical outputs and statistics
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
  *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
  *                        measured equal (3504 vs 3491 img/s)

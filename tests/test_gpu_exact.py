@@ -557,7 +557,10 @@ def test_row_tile_data_gradient_agrees_with_the_sliced_kernel(split):
     shapes, whole backward: the same k-ordered MFMA chain per element, so dz is bit-identical and everything downstream agrees to the
     order of the fp64 BatchNorm reductions.  dgrad_rows = 1 sends EVERY eligible launch to the new kernel (grids smaller than the chip,
     one tile per workgroup), 512 only the 64 x 64 and 32 x 32 levels (the ring wraps, several tiles per workgroup).  The shipped default
-    is 0: the kernel measured equal alone and slower in the step."""
+    is 0: the kernel measured equal alone and slower in the step.
+    Round 5: with f32_split the row-tile kernel is dgrad1x1_rows_split2_kernel (planner option dgrad_rows_v = 2: counted waits that leave
+    the previous tile's stores in flight, x by asm requests, plane reads one step ahead, BatchNorm sums in registers); the round-4 kernel
+    (dgrad_rows_v = 1) runs here as a fourth arm.  All arms: same products in the same order per element."""
     from cu_net_amd._lib import set_planner_option
     from oracle import cunet_ref as O
     cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=2, order=1, loss_num=2)
@@ -568,8 +571,9 @@ def test_row_tile_data_gradient_agrees_with_the_sliced_kernel(split):
     res = {}
     try:
         set_planner_option('f32_split', split)
-        for opt in (0, 1, 512):
-            set_planner_option('dgrad_rows', opt)
+        for opt in (0, 1, 512) + ((1001,) if split else ()):      # 1001: every launch on the ROUND-4 row-tile kernel (dgrad_rows_v = 1)
+            set_planner_option('dgrad_rows', opt % 1000)
+            set_planner_option('dgrad_rows_v', 1 if opt >= 1000 else 2)
             net = cu_net_amd.create_cu_net(**cfg)
             net.load_state_dict(st)
             net = net.cuda().train()
@@ -587,7 +591,7 @@ def test_row_tile_data_gradient_agrees_with_the_sliced_kernel(split):
         set_planner_option('f32_split', 1)      # (the default)
     l0, g0, t0 = res[0]
     assert torch.isfinite(g0).all() and float(g0.norm()) > 0
-    for opt in (1, 512):
+    for opt in [k for k in res if k]:
         l1, g1, t1 = res[opt]
         assert abs(l1 - l0) <= 1e-6 * abs(l0), (opt, l1, l0)
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-5, (opt, float((g1 - g0).norm() / g0.norm()))

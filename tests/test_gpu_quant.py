@@ -137,6 +137,40 @@ def test_ternary_popcount_conv_is_bit_exact(shape):
         assert torch.equal(ref.double(), ref64)
 
 
+@pytest.mark.parametrize('binary', [False, True])
+@pytest.mark.parametrize('shape', [(2, 128, 16, 16, 32, 3), (1, 128, 8, 8, 16, 1), (3, 72, 5, 7, 68, 1), (1, 128, 64, 64, 32, 3),
+                                   (24, 128, 4, 4, 32, 3), (2, 32, 32, 32, 8, 3), (1, 100, 3, 3, 20, 3)])
+def test_ternary_popcount_on_bit_plane_records_is_bit_exact(shape, binary):
+    """The two-kernel AND-popcount path of the network's forward (bit-plane records once per tensor, then the counting kernel;
+    utils/quantize.py:125-149 weights x QuanInput activations :47-63), both counting kernels: `variant` 1 = lane per pixel with the weight
+    masks as scalar operands and ONE mask per weight word, 2 popc(P & x) - popc(x) + popc(Z & x) (round 5: planner option popcount_pixels),
+    0 = wave per pixel (round 3).  Against the oracle's exact convolution: outputs bit for bit, and the per-channel sums of y and y^2 the
+    consumer BatchNorms get -- exact integers / 128, so the fp64 sums must EQUAL the sums of the oracle's output.  Shapes: the network's own
+    (128 -> 32 3x3, 128 -> 16 heads), pixel counts that are not multiples of 64 (ragged last group), channel counts that are not
+    multiples of 64 or 8 (partial mask words, partial chunks of output channels), one-group inputs, 3x3 images (every tap of every pixel
+    reads the zero record somewhere); truly ternary weights (zeros: the Z term) and binary ones (no zero: the scalar branch skips it)."""
+    from cu_net_amd.quant import ternary_conv_planes
+    n, c, h, w, o, k = shape
+    g = torch.Generator().manual_seed(c + o + k + (1000 if binary else 0))
+    x = torch.randn(n, c, h, w, generator=g)
+    # (power-of-two scales: x * scale is exact, so the plane kernel's fused multiply-add -- the BatchNorm arithmetic of every loader of
+    # the network -- and the oracle's multiply-then-add round identically; with arbitrary scales an activation on a quantiser tie differs)
+    scale = torch.pow(2.0, -torch.randint(1, 4, (c,), generator=g).float())
+    shift = torch.randn(c, generator=g) * 0.2
+    if binary:
+        wt = (torch.randint(0, 2, (o, c, k, k), generator=g) * 2 - 1).float()
+    else:
+        wt = torch.randint(-1, 2, (o, c, k, k), generator=g).float()
+    ref = QR.ternary_conv_reference(x, scale, shift, wt, bits_i=8, pad=k // 2)
+    ref_s1 = ref.double().sum((0, 2, 3))
+    ref_s2 = (ref.double() ** 2).sum((0, 2, 3))
+    for variant in (1, 0):
+        got, stats = ternary_conv_planes(x.cuda(), scale, shift, wt, bits_i=8, variant=variant)
+        assert torch.equal(got.cpu(), ref), (variant, float((got.cpu() - ref).abs().max()))
+        assert torch.equal(stats[0].cpu(), ref_s1), variant
+        assert torch.equal(stats[1].cpu(), ref_s2), variant
+
+
 @pytest.mark.parametrize('bits_w', [1, 2])
 def test_quantised_train_step_matches_oracle(bits_w):
     """cu-net-prev-version-wig.py:163-190 as one fused step: quantise, forward/backward on the quantised weights,

@@ -3,6 +3,7 @@
 
     CUNET_LIB_PATH=.../libcunet_hip_tuning.so python tools/ring_phase_clocks.py [--fwd] [--serial]
 
+--rows: dgrad1x1_rows_split2_kernel (the 1x1 data gradient at 64 x 64: counted wait, barrier, requests, cut, MFMAs, epilogue).
 Default: dgrad3x3_ring_split_kernel (the 3x3 data gradient); --fwd: conv3x3_ring_split_kernel (the 3x3 forward: requests, MFMAs, partial
 tiles to LDS + barrier, sum of the eight partial tiles + store + statistics, barrier, ring commit + barrier).
 
@@ -20,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('CUNET_LIB_PATH', os.path.join(ROOT, 'cu_net_amd', 'libcunet_hip_tuning.so'))
 FWD = '--fwd' in sys.argv
-os.environ['CUNET_CONV_DBG'] = '8192' if FWD else '4096'
+ROWS = '--rows' in sys.argv      # dgrad1x1_rows_split2_kernel (round 5)
+os.environ['CUNET_CONV_DBG'] = '16384' if ROWS else ('8192' if FWD else '4096')
 if '--serial' in sys.argv:
     os.environ['CUNET_NO_SIDE_STREAM'] = '1'
 import torch  # noqa: E402
@@ -50,6 +52,15 @@ torch.cuda.synchronize()
 assert fn(buf, 1) == 0
 v = [int(b) for b in buf]
 tiles = max(v[0], 1)
+if ROWS:
+    names = ['counted wait (all but the previous dz stores)', 'barrier', 'x -> LDS tile, LDS-DMA + x requests', 'cut of the next tile (3 bf16 planes)',
+             'MFMAs (plane reads + chain of 48)', 'epilogue + dz stores']
+    print(f'{steps} steps, {v[0]} wave-tiles of the 1x1 row-tile data gradient ({v[0] // steps} per step)')
+    tot = sum(v[1:7])
+    for n, c in zip(names, v[1:7]):
+        print(f'  {n:48s} {c / tiles:9.0f} cycles per wave and tile  {100.0 * c / max(tot, 1):5.1f} %')
+    print(f'  {"sum of the phases":48s} {tot / tiles:9.0f} cycles per wave and tile; whole kernel {v[7] / tiles:.0f} (set-up: weights cut, tables, first tiles)')
+    sys.exit(0)
 names = (['requests (row g + 3)', 'MFMAs (fragment reads + chain)', 'partial tiles to LDS + barrier 1', 'sum of partials + store + statistics', 'barrier 2',
           'ring commit + barrier 3'] if FWD else
          ['requests (dY row g + 3, next x pieces)', 'MFMAs (fragment reads + chain)', 'partial hand-over + barrier 1', 'ring commit (+ partial add)',
