@@ -505,6 +505,10 @@ def main():
         if mode == 'fp32':
             out['contraction'] = SPLIT_NOTE if split else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32), planner option f32_split=0'
             out['config']['contraction'] = 'split-bf16, 6 products, fp32 accumulate (f32_split=1)' if split else 'fp32 MFMA (f32_split=0)'
+        if not args.forward_only:
+            # (FusedTrainer.step: the MSE and its gradient are computed in the heads' epilogues from the staged target, so the timed step never
+            # converts the heat maps to NCHW -- they stay NHWC in the workspace; tr.last_outputs() makes the NCHW copies on request)
+            out['config']['heat_maps'] = 'NHWC in the workspace; loss fused into the head epilogues; no NCHW copy inside the timed step'
         for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
             if k in r:
                 out[k] = r[k]
