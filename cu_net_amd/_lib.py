@@ -51,6 +51,7 @@ def lib():
         'cunet_set_planner_option': (i32, [C.c_char_p, i32]),
         'cunet_get_planner_option': (i32, [C.c_char_p, C.POINTER(i32)]),
         'cunet_debug_set_plan_option': (i32, [vp, C.c_char_p, i32]),
+        'cunet_debug_materialise': (i32, [vp, vp]),
         'cunet_plan_destroy': (None, [vp]),
         'cunet_state_count': (i32, [vp]),
         'cunet_state_entry': (i32, [vp, i32, C.POINTER(StateDesc)]),
@@ -107,7 +108,7 @@ def lib():
     return L
 
 
-EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set_planner_option', 'cunet_get_planner_option', 'cunet_debug_set_plan_option', 'cunet_plan_destroy', 'cunet_state_count',
+EXPORTED = ['cunet_last_error', 'cunet_version', 'cunet_plan_create', 'cunet_set_planner_option', 'cunet_get_planner_option', 'cunet_debug_set_plan_option', 'cunet_debug_materialise', 'cunet_plan_destroy', 'cunet_state_count',
             'cunet_state_entry', 'cunet_param_numel', 'cunet_buffer_numel', 'cunet_counter_numel',
             'cunet_workspace_bytes', 'cunet_num_heads', 'cunet_loss_anchors', 'cunet_plan_describe', 'cunet_bind', 'cunet_set_quant_input', 'cunet_set_popcount_live',
             'cunet_forward', 'cunet_loss_mse', 'cunet_loss_mse_fused', 'cunet_backward', 'cunet_backward_ex', 'cunet_side_stream_join', 'cunet_forward_bf16', 'cunet_bucket_order', 'cunet_num_buckets',
@@ -127,7 +128,7 @@ def check(rc: int, what: str = ''):
 PLANNER_OPTIONS = ('wgrad3_min_rows', 'wgrad3_min_chunks', 'wgrad3_max_splits', 'wgrad3_min_chunks_bf16', 'wgrad3_max_splits_bf16',
                    'wgrad3_stem', 'conv3x3_ring_min_rows', 'wgrad_fork_group', 'wgrad_fork_group_bf16', 'fwd_fork_min_w', 'pair_adapters',
                    'heads_on_side', 'dgrad_nt', 'wgrad_bf16_dma', 'fuse_wgrad', 'dgrad_prefetch', 'dgrad_rows', 'f32_split', 'dgrad3_nt',
-                   'dgrad3_ring', 'stem_split', 'dgrad_rows_v', 'popcount_pixels')
+                   'dgrad3_ring', 'stem_split', 'dgrad_rows_v', 'popcount_pixels', 'stem_fuse_dz')
 
 
 def set_planner_option(name: str, value: int):

@@ -149,6 +149,14 @@ struct WgradArgs {
     int split;             // fp32 storage: 1 = contract on the bf16 matrix pipe, operands cut into three bf16 pieces (planner option f32_split)
     int bf16_dma;          // xbf16 == 2, 1x1: 1 = the LDS-DMA ring kernel where its preconditions hold (the plan's snapshot of planner option
                            // wgrad_bf16_dma), 0 = always the register-staged kernel
+    // stem only (planner option stem_fuse_dz): sx != null = dy is NOT read; the kernel derives d(loss)/d(conv0 output) itself from the conv's
+    // own output sx [M][128], the gradient of the POOLED features sgy [M / 4][128], conv0's batch statistics and the reductions of
+    // stem_bwd_kernel<0> -- the second pass of the stem's BatchNorm-ReLU-pool backward and its 200 MB tensor never exist
+    const float* sx;
+    const float* sgy;
+    const double* sstats;  // [2][128] sum, sum of squares of sx
+    const double* sred;    // [2][128] sum(dz), sum(dz * xhat) (stem_bwd_kernel<0>)
+    double scount;         // rows behind sstats (= M)
 };
 
 // third-generation 1x1 weight gradient (wgrad3_kernels.hip): one workgroup owns the whole [128][CW] output for a range

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const PoolArgs p) {
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        o[k][e] = fmaf(S[e], (k == am) ? dz : 0.f, E[e]) - D[e] * v[k][e];
+                        o[k][e] = fmaf(-D[e], v[k][e], fmaf(S[e], (k == am) ? dz : 0.f, E[e]));      // (explicit: wgrad3_stem_kernel<true> computes the same two operations)
                 }
             }
             if (PASS == 1) {
@@ -638,9 +638,13 @@ hipError_t launch_stem_bwd(const PoolArgs& a, int pass, float* dgamma, float* db
     if (pass == 0) {
         if (a.xbf16 == 2) hipLaunchKernelGGL((stem_bwd_kernel<0, 1>), dim3((unsigned)gx), dim3(256), smem, s, a);
         else hipLaunchKernelGGL((stem_bwd_kernel<0, 0>), dim3((unsigned)gx), dim3(256), smem, s, a);
+    } else if (pass == 2) {      // the BatchNorm parameter gradients only: the dz pass is fused into the stem's weight gradient (stem_fuse_dz)
+        hipLaunchKernelGGL(stem_bn_param_grad_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s,
+                           (const double*)a.red, dgamma, dbeta, a.C);
     } else {
         if (a.xbf16 == 2) hipLaunchKernelGGL((stem_bwd_kernel<1, 1>), dim3((unsigned)gx), dim3(256), smem, s, a);
         else hipLaunchKernelGGL((stem_bwd_kernel<1, 0>), dim3((unsigned)gx), dim3(256), smem, s, a);
+        if (pass == 3) return hipGetLastError();      // (the dz pass alone: cunet_debug_materialise)
         hipLaunchKernelGGL(stem_bn_param_grad_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s,
                            (const double*)a.red, dgamma, dbeta, a.C);
     }

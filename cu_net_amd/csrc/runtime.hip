@@ -38,6 +38,7 @@ struct cunet_plan {
     int ternpack_dirty = 0;
     float* fused_loss_out = nullptr;  // cunet_loss_mse_fused: the next training forward computes the loss in its head epilogues
     int tern_live = 0;               // cunet_set_popcount_live: the caller vouches that those convs' weights ARE ternary right now
+    bool stem_fused_now = false;     // this backward pass: the stem's weight gradient computes d(loss)/d(conv0 output) itself (planner option stem_fuse_dz)
     // call-order state
     int fwd_training_done = 0;
     int loss_done = 0;
@@ -173,6 +174,7 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "dgrad_rows") return &o.dgrad_rows;
     if (n == "dgrad_rows_v") return &o.dgrad_rows_v;
     if (n == "popcount_pixels") return &o.popcount_pixels;
+    if (n == "stem_fuse_dz") return &o.stem_fuse_dz;
     if (n == "f32_split") return &o.f32_split;
     if (n == "dgrad3_nt") return &o.dgrad3_nt;
     if (n == "dgrad3_ring") return &o.dgrad3_ring;
@@ -742,7 +744,10 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
         a.red = E.zero + n.red;
         a.xbf16 = E.xmode == 2 ? 2 : 0;          // x (the stem conv output) is fp32 in every mode; gy follows the gradient storage
         PROF(PC_STEMBPB, 0.0, 4.0 * 1.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 0, nullptr, nullptr, cus, s));
-        PROF(PC_STEMBPB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
+        if (h->stem_fused_now)      // (planner option stem_fuse_dz: the stem's weight gradient derives dz itself; only dgamma / dbeta are left to do here)
+            HIPCHK(launch_stem_bwd(a, 2, h->grads + b.gamma, h->grads + b.beta, cus, s));
+        else
+            PROF(PC_STEMBPB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_stem_bwd(a, 1, h->grads + b.gamma, h->grads + b.beta, cus, s));
     } else {  // N_STEM_CONV: weight gradient only (the image needs no gradient)
         if (!(parts & BWD_WGRAD)) return CUNET_OK;
         const ConvInfo& c = P.convs[n.conv];
@@ -753,6 +758,12 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
         w.dw = h->grads + c.w;
         w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
         if (wg3_active(P, n, E.xmode)) {      // (an unsupported shape is an error here: the reduce table already expects partial tiles)
+            if (h->stem_fused_now) {           // d(loss)/d(conv0 output) is computed inside the kernel (WgradArgs::sx ...)
+                const Node& nb = P.nodes[node_index + 1];       // the stem's BatchNorm-ReLU-pool node
+                const BnInfo& sb = P.bns[nb.bn];
+                w.sx = E.act(n.out); w.sgy = E.grad(nb.out); w.sstats = E.stats(n.out); w.sred = E.zero + nb.red; w.scount = (double)o.rows();
+                w.gamma = h->params + sb.gamma; w.beta = h->params + sb.beta;
+            }
             PROF_ON(ws, PC_STEMW, 2.0 * w.M * w.Cout * w.Ccat, 4.0 * (double)w.M * w.Cout,
                     launch_wgrad3_stem(w, E.wsf + n.wg3_part, n.wg3_wpi, n.wg3_rows, ws));
         } else {
@@ -832,6 +843,7 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
     if (!h->ws) return fail(CUNET_ERR_STATE, "cunet_bind has not been called");
     hipStream_t s = (hipStream_t)stream;
     h->fwd_training_done = 0;        // (an earlier bf16 forward must not redirect this pass's activation pointers)
+    h->stem_fused_now = false;       // (cunet_debug_materialise: the reductions it would read are about to be cleared)
     Exec E(h);
     Plan& P = h->plan;
     const int cus = h->num_cus;
@@ -981,6 +993,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
     const int64_t off16 = h->bound_training ? P.off_bf16_train : P.off_bf16;
     if (h->ws_bytes < off16 + P.n_floats_infer * 2) return fail(CUNET_ERR_STATE, "workspace has no bf16 arena: size it with cunet_workspace_bytes(plan, 2 or 3)");
     hipStream_t s = (hipStream_t)stream;
+    h->stem_fused_now = false;
     Exec E(h);
     const int cus = h->num_cus;
     unsigned short* a16 = reinterpret_cast<unsigned short*>(h->ws + off16);      // bf16 arena, element offsets as the fp32 layout
@@ -1177,6 +1190,8 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         }
     }
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
+    h->stem_fused_now = P.opts.stem_fuse_dz && E.xmode != 2 && P.nodes.size() >= 2 && P.nodes[0].type == N_STEM_CONV &&
+                        P.nodes[1].type == N_STEM_BNPOOL && wg3_active(P, P.nodes[0], E.xmode) && (P.tensors[P.nodes[0].out].H & 1) == 0;
     // The heads' backward depends on nothing but the loss gradient: all of it (data and weight gradient) goes to the side stream
     // up front, last U-Net first (the order the caller's stream will want the results in), one hand-over for all of them; the
     // caller's stream waits for head k's completion where head k's turn would have been.
@@ -1428,6 +1443,30 @@ int cunet_ternary_conv_ex(const float* x, const float* scale, const float* shift
     return CUNET_OK;
 }
 
+int cunet_debug_materialise(cunet_plan_t* h, void* stream) {
+    // planner option stem_fuse_dz: the last backward never wrote d(loss)/d(conv0 output) -- the stem's weight gradient derived it on the
+    // fly.  A debugger that wants to LOOK at that tensor gets it written now by the second stem pass, from the same inputs (the first pass's
+    // reductions and the pooled features' gradient are still in the workspace until the next forward): the values the fused kernel used.
+    if (!h) return fail(CUNET_ERR_INVALID, "null argument");
+    if (!h->stem_fused_now || !h->ws || !h->bound_training) return CUNET_OK;      // (a forward since then clears the flag: its inputs are gone)
+    hipStream_t s = (hipStream_t)stream;
+    Plan& P = h->plan;
+    Exec E(h);
+    const Node& n = P.nodes[1];
+    const int tin = n.segs[0].tensor;
+    const TensorInfo& ti = P.tensors[tin];
+    const BnInfo& b = P.bns[n.bn];
+    PoolArgs a{};
+    a.x = E.act(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+    a.xstats = E.stats(tin); a.count = (double)ti.rows();
+    a.gamma = h->params + b.gamma; a.beta = h->params + b.beta;
+    a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.training = 1;
+    a.red = E.zero + n.red;
+    a.xbf16 = 0;
+    HIPCHK(launch_stem_bwd(a, 3, nullptr, nullptr, h->num_cus, s));      // (3: the dz pass alone -- dgamma / dbeta are in the arena already)
+    return CUNET_OK;
+}
+
 int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (!h || node < 0 || node >= (int)h->plan.nodes.size()) return fail(CUNET_ERR_INVALID, "bad node index");
     if (!h->ws || !h->bound_training) return fail(CUNET_ERR_STATE, "plan is not bound for training");
@@ -1437,6 +1476,7 @@ int cunet_debug_run_node_backward(cunet_plan_t* h, int node, void* stream) {
     if (n.red >= 0)
         HIPCHK(hipMemsetAsync(h->ws + P.off_zero + 8 * n.red, 0, (size_t)16 * n.Ccat, s));
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
+    h->stem_fused_now = false;                                      // (a single node: every tensor it reads and writes is a real tensor)
     const bool fused = wgrad_is_fused(h, node, Exec(h).xmode);      // (its weight gradient comes with the data gradient launched below)
     {
         std::vector<int> one;

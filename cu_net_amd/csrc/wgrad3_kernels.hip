@@ -1382,6 +1382,14 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad3_3x3_bf16_kernel(const W
 // stem_rp in common.h).  Partial tiles part[split][n][147], summed by the stem bucket's reduce: no atomics.
 template <int HF> struct StemTiles { static constexpr int N = HF == 0 ? 3 : 2; static constexpr int K0 = HF == 0 ? 0 : 3; };
 
+// FUSE (round 5, planner option stem_fuse_dz): dY -- the gradient of conv0's output behind BatchNorm, ReLU and the 2 x 2 max-pool -- is not
+// read from a tensor but computed while the chunk is staged: a thread owns one 4-channel piece and, per chunk, two horizontally adjacent
+// output pixels twice (the two columns of one pooling window of row oy): it requests the window's four x pieces and the pooled gradient's
+// piece (10 requests of 16 bytes instead of 4), finds the window's first arg-max of relu(bn(x)) as the pool did, and writes
+//     dz = A * (own the max and it is positive ? g : 0) + E - D * x        (the arithmetic of stem_bwd_kernel<1>, operation for operation)
+// into the LDS chunk.  The 200 MB dz tensor is neither written nor read, stem_bwd_kernel<1> (the last kernel of the step on the caller's
+// stream but one) is not launched; bit-identical weight gradient.
+template <bool FUSE>
 __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
@@ -1441,17 +1449,77 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Ar
     // ---- dY chunks: 64 pixels x 128 channels = 2048 float4, 4 per thread
     const int cpr = OW / STEM_CHUNK;                       // chunks per output row
     const int nchunks = (r1 - r0) * cpr;
-    f32x4n dv[4];
+    f32x4n dv[FUSE ? 10 : 4];
+    // FUSE: this thread's channel piece is 4 * (tid & 31) in every item (512 = 16 x 32 threads); its BatchNorm tables in registers
+    f32x4n tS = {0.f, 0.f, 0.f, 0.f}, tH = tS, tE = tS, tD = tS;
+    int f_row = 0;                                         // parity of the chunk's output row inside its pooling window
+    if (FUSE) {
+        const double invM = 1.0 / p.scount;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (tid & 31) + e;
+            const double mean = p.sstats[c] / p.scount;
+            double var = p.sstats[128 + c] / p.scount - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+            const double scale = (double)p.gamma[c] * istd;
+            const double c1 = p.sred[c] * invM, c2 = p.sred[128 + c] * invM;
+            const double D = scale * c2 * istd;
+            tS[e] = (float)scale;
+            tH[e] = (float)((double)p.beta[c] - mean * scale);
+            tD[e] = (float)D;
+            tE[e] = (float)(D * mean - scale * c1);
+        }
+    }
     auto issue = [&](int ci) {
         const int oy = r0 + ci / cpr;
         const int x0 = STEM_CHUNK * (ci - (ci / cpr) * cpr);
-        const float* src = p.dy + (((size_t)img * OH + oy) * OW + x0) * 128;
+        if (FUSE) {
+            f_row = oy & 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dv[j] = *reinterpret_cast<const f32x4n*>(src + 4 * (tid + WG3_THREADS * j));
+            for (int jj = 0; jj < 2; ++jj) {               // window jj: output columns x0 + 2 pw, + 1 with pw = (tid >> 5) + 16 jj
+                const int pw = (tid >> 5) + 16 * jj;
+                const size_t w00 = (((size_t)img * OH + (oy & ~1)) * OW + x0 + 2 * pw) * 128 + 4 * (tid & 31);
+                dv[5 * jj + 0] = *reinterpret_cast<const f32x4n*>(p.sx + w00);
+                dv[5 * jj + 1] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + 128);
+                dv[5 * jj + 2] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + (size_t)OW * 128);
+                dv[5 * jj + 3] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + (size_t)OW * 128 + 128);
+                dv[5 * jj + 4] = *reinterpret_cast<const f32x4n*>(p.sgy + (((size_t)img * (OH >> 1) + (oy >> 1)) * (OW >> 1) + (x0 >> 1) + pw) * 128 + 4 * (tid & 31));
+            }
+        } else {
+            const float* src = p.dy + (((size_t)img * OH + oy) * OW + x0) * 128;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dv[j] = *reinterpret_cast<const f32x4n*>(src + 4 * (tid + WG3_THREADS * j));
+        }
     };
     auto commit = [&]() {
+        if (FUSE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4n*>(lds + dyoff + 4 * (tid + WG3_THREADS * j)) = dv[j];
+            for (int jj = 0; jj < 2; ++jj) {
+                const int pw = (tid >> 5) + 16 * jj;
+                f32x4n o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int am = 0;                            // first arg-max of the window, as the forward's pool and stem_bwd_kernel take it
+                    float best = fmaxf(fmaf(dv[5 * jj + 0][e], tS[e], tH[e]), 0.f);
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const float a = fmaxf(fmaf(dv[5 * jj + k][e], tS[e], tH[e]), 0.f);
+                        if (a > best) { best = a; am = k; }
+                    }
+                    const float g = best > 0.f ? dv[5 * jj + 4][e] : 0.f;
+                    const float xa = f_row ? dv[5 * jj + 2][e] : dv[5 * jj + 0][e];      // this row's two pixels of the window
+                    const float xb = f_row ? dv[5 * jj + 3][e] : dv[5 * jj + 1][e];
+                    o0[e] = fmaf(-tD[e], xa, fmaf(tS[e], (am == 2 * f_row) ? g : 0.f, tE[e]));
+                    o1[e] = fmaf(-tD[e], xb, fmaf(tS[e], (am == 2 * f_row + 1) ? g : 0.f, tE[e]));
+                }
+                *reinterpret_cast<f32x4n*>(lds + dyoff + (2 * pw) * 128 + 4 * (tid & 31)) = o0;
+                *reinterpret_cast<f32x4n*>(lds + dyoff + (2 * pw + 1) * 128 + 4 * (tid & 31)) = o1;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4n*>(lds + dyoff + 4 * (tid + WG3_THREADS * j)) = dv[j];
+        }
     };
 
     const int nt = wave & 3;
@@ -1540,7 +1608,9 @@ hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows
     if (!wgrad3_stem_supported(a, rows) || wpi < 1 || (long)wpi * rows < a.H) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)&wgrad3_stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -1550,7 +1620,12 @@ hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows
     q.rows_per_split = rows;
     q.c0 = wpi;
     const int N = a.M / (a.H * a.W);
-    hipLaunchKernelGGL(wgrad3_stem_kernel, dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+    if (a.sx != nullptr) {
+        if (a.sgy == nullptr || a.sstats == nullptr || a.sred == nullptr || a.gamma == nullptr || a.beta == nullptr || (a.H & 1)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(wgrad3_stem_kernel<true>, dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+    } else {
+        hipLaunchKernelGGL(wgrad3_stem_kernel<false>, dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+    }
     return hipGetLastError();
 }
 

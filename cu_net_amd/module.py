@@ -172,6 +172,8 @@ class _BoundPlan:
 
     def debug_tensor(self, name: str, grad: bool = False) -> torch.Tensor:
         """NCHW copy of an internal NHWC tensor (tests only)."""
+        if grad:      # a gradient tensor the last backward did not materialise (planner option stem_fuse_dz) is written now
+            check(lib().cunet_debug_materialise(self.handle.h, _stream_ptr(self.workspace.device)), 'cunet_debug_materialise')
         d = self.handle.describe()
         t = [t for t in d['tensors'] if t['name'] == name][0]
         rows = t['N'] * t['H'] * t['W']

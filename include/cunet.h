@@ -306,6 +306,11 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        = ternary_conv_pixels_kernel, lane = pixel with the weight masks as scalar operands and one mask per weight word
  *                        (2 popc(P & x) - popc(x) + popc(Z & x)); 0 = ternary_conv_planes_kernel of round 3 (wave = pixel, v_readlane per plane
  *                        word).  Integer arithmetic either way: bit-identical outputs and statistics
+ *   "stem_fuse_dz"       1 (default, round 5): the stem's weight gradient computes d(loss)/d(conv0 output) itself while it stages its chunks --
+ *                        from conv0's output, the gradient of the pooled features and the reductions of the first stem pass -- so the second pass
+ *                        of the stem's BatchNorm-ReLU-pool backward and its 200 MB gradient tensor (24 x 128 x 128 x 128 fp32) never exist in a
+ *                        training step; 0: two stem passes + the weight gradient reading that tensor (rounds 1-4).  Bit-identical dW.
+ *                        (cunet_debug_run_node_backward always runs the unfused kernels: its tensors are real)
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
  *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
  *                        measured equal (3504 vs 3491 img/s)
@@ -334,6 +339,10 @@ int cunet_get_planner_option(const char* name, int* value);
 /* debugging aid of the test-suite: changes "wgrad_bf16_dma" -- the one option that only picks between bit-identical kernels at
  * launch time -- in the snapshot of a LIVE plan.  Any other name: CUNET_ERR_INVALID (those options shaped the plan's layout). */
 int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value);
+/* debugging aid: tensors that a training step no longer materialises are written now, from the state the last cunet_backward left in the
+ * workspace (today: d(loss)/d(conv0 output) under planner option "stem_fuse_dz").  The Python binding calls it before it reads a gradient
+ * tensor for the test-suite; a no-op when nothing is missing. */
+int cunet_debug_materialise(cunet_plan_t* plan, void* stream);
 
 /* training-sample preparation on the device: replaces the per-sample CPU work of data/mpii_for_mpii_22.py:127-141 between the
  * decoded image and the network input -- horizontal flip (pylib/HumanAug.py:267-271), per-channel colour gain with clamp to

@@ -642,3 +642,59 @@ def test_heads_on_the_side_stream_equal_heads_in_node_order(mode):
             assert float((a - b).abs().max()) <= (1e-5 if mode == 'fp32' else 2 ** -7) * float(b.abs().max())
         rel = float((got[2] - ref[2]).norm() / ref[2].norm())
         assert rel <= (1e-3 if mode == 'fp32' else 3e-2), rel
+
+
+@pytest.mark.parametrize('n,h,w', [(24, 256, 256), (3, 128, 256), (1, 256, 128)])
+def test_stem_weight_gradient_with_the_dz_pass_fused(n, h, w):
+    """Planner option stem_fuse_dz = 1 (default): wgrad3_stem_kernel<true> computes d(loss)/d(conv0 output) -- BatchNorm, ReLU and the 2 x 2
+    max-pool backward of models/cu_net.py:300-303 -- while it stages its chunks, from conv0's output, the pooled features' gradient and
+    the first stem pass's reductions; stem_bwd_kernel<1> and its N x 128 x H/2 x W/2 tensor drop out of the step.
+    (1) Inside ONE run, bit for bit: after the fused backward the debug reader materialises that tensor (cunet_debug_materialise: the
+    second stem pass on the state the backward left behind) and the UNFUSED weight-gradient kernel, run on it as a single node, must
+    reproduce conv0's weight gradient exactly -- same values, same partial tiles, same reduce.
+    (2) Against a second run with stem_fuse_dz = 0 (two stem passes, the weight gradient reads the tensor): conv0's weight gradient, the
+    stem BatchNorm's parameter gradients and the tensor agree to fp32 rounding (the U-Nets in front of the stem ran on identical kernels,
+    but their fp64 statistics atomics land in another order from run to run, so the stem's INPUT agrees to the last bits only).
+    The bench batch, a rectangular batch (output rows of 64 / 128 pixels: one / two chunks per row) and a single image."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=101)
+    gen = torch.Generator().manual_seed(102)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    target = torch.rand(n, 16, h // 4, w // 4, generator=gen)
+    xd, td = x.cuda(), target.cuda()
+    names = ('features.conv0.weight', 'features.norm0.weight', 'features.norm0.bias')
+    res = {}
+    for fuse in (1, 0):
+        set_planner_option('stem_fuse_dz', fuse)
+        net = cu_net_amd.create_cu_net(**cfg)
+        net.load_state_dict(st)
+        net = net.cuda().train()
+        plan = net._get_plan(n, h, w, True)
+        plan.stage_target(td)
+        plan.forward(xd, True, want_outputs=False)
+        plan.backward(None)
+        torch.cuda.synchronize()
+        d = plan.handle.describe()
+        assert d['nodes'][0]['op'] == 'stem_conv' and d['nodes'][0]['wg3'] > 0
+        conv0_out = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][0]['out']][0]
+        off = {name: (o, nmel) for name, kind, shape, o, nmel in net._entries if kind == 0}
+        grads = {k: net._grad_arena[off[k][0]:off[k][0] + off[k][1]].clone() for k in names}
+        dz = plan.debug_tensor(conv0_out, grad=True).clone()          # (fuse = 1: written now, by the second stem pass)
+        if fuse:
+            plan.debug_run_node_backward(0)                           # the unfused kernel on the materialised tensor (zeroes the arena first)
+            torch.cuda.synchronize()
+            o, nmel = off['features.conv0.weight']
+            again = net._grad_arena[o:o + nmel]
+            assert float(again.abs().max()) > 0
+            assert torch.equal(again, grads['features.conv0.weight']), float((again - grads['features.conv0.weight']).abs().max())
+        res[fuse] = (grads, dz)
+        del plan, net
+    for k in names:
+        a, b = res[1][0][k], res[0][0][k]
+        assert float(b.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
+    a, b = res[1][1], res[0][1]
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
