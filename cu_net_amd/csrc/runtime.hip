@@ -1255,7 +1255,11 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         return bn_param_grads(h, k_lo, k_hi, cur_bucket, s);
     };
     // (bf16 gradient tensors: shorter kernels, the hand-over bubble weighs more -- 8 per group measured best there, 4 in fp32)
-    const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, E.xmode == 2 ? P.opts.wgrad_fork_group_bf16 : P.opts.wgrad_fork_group) : 1;
+    // (fp32 gradients, round 5: 0 = by depth -- 2 for up to four U-Nets, where starting the side stream's work sooner shortens the tail of the
+    // step by more than the extra hand-overs cost (CU-Net-2: 4243-4298 img/s at 2 against 4188-4206 at 4, 4177-4199 at 1, 4190-4198 at 3 on
+    // one box), 4 for deeper networks, where the tail is a small part of the step and the hand-overs add up (CU-Net-16: 578 vs 581))
+    const int group_f32 = P.opts.wgrad_fork_group > 0 ? P.opts.wgrad_fork_group : (P.cfg.layer_num <= 4 ? 2 : 4);
+    const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, E.xmode == 2 ? P.opts.wgrad_fork_group_bf16 : group_f32) : 1;
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued

@@ -264,7 +264,8 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        allows (128 output channels, output width a multiple of 64); 0: per-wave atomic kernel
  *   "conv3x3_ring_min_rows"  the 3x3 forward of 64-pixel-wide levels runs on the LDS row ring when the batch has at least this many
  *                        image rows N*H (default 512 = two per CU; tests lower it to cover the kernel at small batches)
- *   "wgrad_fork_group"   backward hands the weight gradients to the internal side stream in groups of this many nodes (default 4):
+ *   "wgrad_fork_group"   backward hands the weight gradients to the internal side stream in groups of this many nodes (default 0 = by depth:
+ *                        2 for layer_num <= 4, 4 beyond -- round 5: CU-Net-2 4243-4298 img/s at 2 vs 4188-4206 at 4; CU-Net-16 578 vs 581):
  *                        every hand-over is an event record on the caller's stream, i.e. a marker packet the next kernel waits
  *                        behind (6-7 us of bubble on the critical path each); 1 = one hand-over per node
  *   "wgrad_fork_group_bf16"  the same when the gradient tensors are stored as bf16 (default 8)
