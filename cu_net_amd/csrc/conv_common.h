@@ -38,6 +38,10 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 // Eight fp32 values -> three operand registers of v_mfma_f32_32x32x16_bf16: x = h + m + l, each piece rounded to nearest even from
 // what the pieces before it left (8 + 8 + 8 significand bits: h + m + l == x exactly unless l underflows).  Elements 2 j, 2 j + 1 of
 // the input are the low / high half of dword j, the operand order of the instruction.
+// Non-finite inputs: x = +-Inf (or finite above the bf16 maximum, 3.39e38) gives h = +-Inf and x - h = NaN, so such an operand contributes
+// NaN where the fp32 MFMA would contribute +-Inf (NaN, not 0, against a zero-padded column too); a diverged run shows as a NaN loss
+// instead of an Inf one.  A select per element would restore Inf at one more VALU operation in loops that are VALU-bound already (DESIGN
+// section 4a); include/cunet.h documents the limitation next to the option, f32_split = 0 keeps the fp32 instruction.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_op __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_op __attribute__((ext_vector_type(2)));

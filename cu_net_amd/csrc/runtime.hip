@@ -175,6 +175,7 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "dgrad_rows_v") return &o.dgrad_rows_v;
     if (n == "popcount_pixels") return &o.popcount_pixels;
     if (n == "stem_fuse_dz") return &o.stem_fuse_dz;
+    if (n == "stem_wgrad_split") return &o.stem_wgrad_split;
     if (n == "f32_split") return &o.f32_split;
     if (n == "dgrad3_nt") return &o.dgrad3_nt;
     if (n == "dgrad3_ring") return &o.dgrad3_ring;
@@ -757,6 +758,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
         w.M = (int)o.rows(); w.H = o.H; w.W = o.W;
         w.dw = h->grads + c.w;
         w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
+        w.split = (P.opts.f32_split && P.opts.stem_wgrad_split) ? 1 : 0;      // (fp32 image and fp32 dY in every storage mode)
         if (wg3_active(P, n, E.xmode)) {      // (an unsupported shape is an error here: the reduce table already expects partial tiles)
             if (h->stem_fused_now) {           // d(loss)/d(conv0 output) is computed inside the kernel (WgradArgs::sx ...)
                 const Node& nb = P.nodes[node_index + 1];       // the stem's BatchNorm-ReLU-pool node

@@ -1389,7 +1389,11 @@ template <int HF> struct StemTiles { static constexpr int N = HF == 0 ? 3 : 2; s
 //     dz = A * (own the max and it is positive ? g : 0) + E - D * x        (the arithmetic of stem_bwd_kernel<1>, operation for operation)
 // into the LDS chunk.  The 200 MB dz tensor is neither written nor read, stem_bwd_kernel<1> (the last kernel of the step on the caller's
 // stream but one) is not launched; bit-identical weight gradient.
-template <bool FUSE>
+// EMU (round 5, planner option stem_wgrad_split with f32_split): the contraction on the bf16 matrix pipe as in wgrad3_kernel -- a lane takes
+// its operands as 8 consecutive output pixels (dY: eight ds_read_b32 a pixel row apart; im2col: eight ds_read_b32 two input pixels apart --
+// as many LDS reads as the fp32 k-steps they replace), cuts each into three bf16 pieces and issues six v_mfma_f32_32x32x16_bf16 per k-tile:
+// 4 x CT x 6 x 32 = 2304 matrix-pipe cycles per chunk instead of 32 x CT x 64 = 6144 (CT = 3).
+template <bool FUSE, bool EMU>
 __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
@@ -1571,11 +1575,43 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Ar
             for (int t = 0; t < CT; ++t) b_cur[t] = b_nxt[t];
         }
     };
+    auto chunk_mma_emu = [&](auto HF, int ci) {
+        constexpr int CT = StemTiles<decltype(HF)::value>::N;
+        const int oy = r0 + ci / cpr;
+        const int x0 = STEM_CHUNK * (ci - (ci / cpr) * cpr);
+#pragma unroll
+        for (int ks = 0; ks < STEM_CHUNK / 16; ++ks) {
+            const int p0 = 16 * ks + 8 * hi;                    // this lane's 8 pixels of the 16-pixel k-step
+            const float* A = lds + dyoff + p0 * 128 + nt * 32 + li;
+            float af[8], bf[CT][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = A[j * 128];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const float* B = lds + koff[t] + kmul[t] * (2 * (oy - r0)) * RP + 2 * (x0 + p0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bf[t][j] = B[2 * j];
+            }
+            u32x4 ah, am, al;
+            split_bf16x3(af, ah, am, al);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                u32x4 bh, bm, bl;
+                split_bf16x3(bf[t], bh, bm, bl);
+                acc[t] = mfma_split6(ah, am, al, bh, bm, bl, acc[t]);
+            }
+        }
+    };
     for (int ci = 0; ci < nchunks; ++ci) {
         const bool more = ci + 1 < nchunks;
         if (more) issue(ci + 1);
-        if (half == 0) chunk_mma(std::integral_constant<int, 0>{}, ci);
-        else chunk_mma(std::integral_constant<int, 1>{}, ci);
+        if constexpr (EMU) {
+            if (half == 0) chunk_mma_emu(std::integral_constant<int, 0>{}, ci);
+            else chunk_mma_emu(std::integral_constant<int, 1>{}, ci);
+        } else {
+            if (half == 0) chunk_mma(std::integral_constant<int, 0>{}, ci);
+            else chunk_mma(std::integral_constant<int, 1>{}, ci);
+        }
         __syncthreads();
         if (more) commit();
         __syncthreads();
@@ -1608,10 +1644,12 @@ hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows
     if (!wgrad3_stem_supported(a, rows) || wpi < 1 || (long)wpi * rows < a.H) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)&wgrad3_stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)&wgrad3_stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        const void* fns[4] = {(const void*)&wgrad3_stem_kernel<false, false>, (const void*)&wgrad3_stem_kernel<true, false>,
+                              (const void*)&wgrad3_stem_kernel<false, true>, (const void*)&wgrad3_stem_kernel<true, true>};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
     Wg3Args q{};
@@ -1622,9 +1660,11 @@ hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows
     const int N = a.M / (a.H * a.W);
     if (a.sx != nullptr) {
         if (a.sgy == nullptr || a.sstats == nullptr || a.sred == nullptr || a.gamma == nullptr || a.beta == nullptr || (a.H & 1)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(wgrad3_stem_kernel<true>, dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+        if (a.split) hipLaunchKernelGGL((wgrad3_stem_kernel<true, true>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+        else hipLaunchKernelGGL((wgrad3_stem_kernel<true, false>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
     } else {
-        hipLaunchKernelGGL(wgrad3_stem_kernel<false>, dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+        if (a.split) hipLaunchKernelGGL((wgrad3_stem_kernel<false, true>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
+        else hipLaunchKernelGGL((wgrad3_stem_kernel<false, false>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
     }
     return hipGetLastError();
 }

@@ -312,6 +312,9 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *                        of the stem's BatchNorm-ReLU-pool backward and its 200 MB gradient tensor (24 x 128 x 128 x 128 fp32) never exist in a
  *                        training step; 0: two stem passes + the weight gradient reading that tensor (rounds 1-4).  Bit-identical dW.
  *                        (cunet_debug_run_node_backward always runs the unfused kernels: its tensors are real)
+ *   "stem_wgrad_split"   1 (default, round 5; acts with f32_split): the stem's LDS-staged weight gradient contracts on the bf16 matrix pipe with
+ *                        three-piece operands like every other fp32 convolution (it was the last kernel on the fp32 pipe and the last long
+ *                        kernel of a step); 0: v_mfma_f32_32x32x2_f32
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
  *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
  *                        measured equal (3504 vs 3491 img/s)

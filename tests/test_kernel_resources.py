@@ -41,6 +41,7 @@ EXPECT = {
         'wgrad3_kernelILi5ELb0ELi0ELb1E': 256,             # 1x1 weight gradient, 320 channels, split contraction
         'wgrad3_kernelILi5ELb1ELi0ELb1E': 256,
         'wgrad3_3x3_kernelILi0ELb1E': 256,
+        'wgrad3_stem_kernelILb1ELb1E': 256,                # stem weight gradient: dz computed while staging, split contraction (round 5)
     },
     'bf16_kernels.hip': {
         'dgrad_bf16_kernelILi1ELi2ELi4E': 168,             # bf16 1x1 data gradient, two channel tiles, K = 128 (12 waves)

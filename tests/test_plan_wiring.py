@@ -1,5 +1,7 @@
 """CPU: the C++ plan builder (cu_net_amd/csrc/plan.cpp, reached through the C ABI) wires the network
 exactly like the reference: executing its node list with torch ops reproduces the golden outputs."""
+import os
+
 import pytest
 import torch
 
@@ -177,3 +179,44 @@ def test_planner_options_through_the_abi():
     finally:
         set_planner_option('f32_split', 1)
     assert smax[1] == 192 and smax[0] == 256, smax
+
+
+def test_planner_options_read_back_and_are_restored_between_tests():
+    """cunet_get_planner_option (round 5): every option of cu_net_amd._lib.PLANNER_OPTIONS reads back what cunet_set_planner_option stored,
+    an unknown name is refused, and the defaults are the ones include/cunet.h documents for the shipped library (f32_split 1,
+    dgrad_rows_v 2, popcount_pixels 1, stem_fuse_dz 1, wgrad_fork_group 0 = by depth).  The autouse fixture of tests/conftest.py
+    restores whatever a test changes: this test leaves f32_split at 0 ON PURPOSE and the next one checks it came back."""
+    from cu_net_amd._lib import CUNetError, PLANNER_OPTIONS, get_planner_option, planner_options_snapshot, set_planner_option
+    snap = planner_options_snapshot()
+    assert set(snap) == set(PLANNER_OPTIONS)
+    if not os.environ.get('CUNET_TEST_PLANNER_OPTS'):
+        assert (snap['f32_split'], snap['dgrad_rows_v'], snap['popcount_pixels'], snap['stem_fuse_dz'], snap['wgrad_fork_group'], snap['dgrad_rows']) == (1, 2, 1, 1, 0, -1)
+    with pytest.raises(CUNetError):
+        get_planner_option('no_such_option')
+    for name in PLANNER_OPTIONS:
+        v = get_planner_option(name)
+        set_planner_option(name, 3)
+        assert get_planner_option(name) == 3
+        set_planner_option(name, v)
+        assert get_planner_option(name) == v
+    set_planner_option('f32_split', 0)          # (left behind deliberately)
+
+
+def test_planner_options_were_restored():
+    from cu_net_amd._lib import get_planner_option
+    if not os.environ.get('CUNET_TEST_PLANNER_OPTS'):
+        assert get_planner_option('f32_split') == 1
+
+
+def test_debug_plan_option_is_limited_to_launch_time_choices():
+    """cunet_debug_set_plan_option (round 5): only wgrad_bf16_dma -- a choice between bit-identical kernels made at launch time -- may
+    change in a live plan's snapshot; every option that shaped the plan's layout is refused."""
+    from cu_net_amd._lib import CUNetError, PlanHandle, check, lib
+    plan = PlanHandle(2, 8, 16, 5, 2, 1, 2, batch=2, height=128, width=128)
+    check(lib().cunet_debug_set_plan_option(plan.h, b'wgrad_bf16_dma', 0), 'set')
+    check(lib().cunet_debug_set_plan_option(plan.h, b'wgrad_bf16_dma', 1), 'set')
+    for name in (b'f32_split', b'wgrad3_max_splits', b'no_such_option'):
+        with pytest.raises(CUNetError):
+            check(lib().cunet_debug_set_plan_option(plan.h, name, 1), 'set')
+    with pytest.raises(CUNetError):
+        check(lib().cunet_debug_set_plan_option(plan.h, b'wgrad_bf16_dma', -1), 'set')
