@@ -279,6 +279,12 @@ struct TernArgs {
 // b < 7: C <= 128, bits_i <= 8), word 14 = the sum of the pixel's quantised activations, word 15 = 0; record M is all zero (what a
 // tap outside the image reads).
 constexpr int TERN_REC_WORDS = 16;
+// Bit order inside a 64-channel plane / mask word (round 5): within each 32-bit half, bit 8 i + k holds channel 4 k + i (i < 4, k < 8) --
+// the order in which ternary_planes_rows_kernel finds the channels when it shifts a dword of four quantised bytes (channels 4 k .. 4 k + 3)
+// by k and ORs it into the plane: (d >> b) & 0x01010101 leaves bit b of byte i at position 8 i.  Every producer of plane words and every
+// packer of weight masks uses the same map, so the AND pairs the right channels; nothing else depends on it.
+__host__ __device__ inline int tern_bit_of_chan(int c) { return (c & 32) + 8 * (c & 3) + ((c & 31) >> 2); }      // c in 0 .. 63
+__host__ __device__ inline int tern_chan_of_bit(int b) { return (b & 32) + 4 * (b & 7) + ((b & 31) >> 3); }      // b in 0 .. 63
 
 struct AugSample {           // one training sample of cunet_augment_batch (host-computed crop geometry, pylib/HumanAug.py:118-142); 192 bytes
     const float* src;        // 3 x sh x sw fp32 CHW image in [0, 1]

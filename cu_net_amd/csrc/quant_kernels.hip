@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void ternary_conv_kernel(const TernArgs p) {
 #pragma unroll
             for (int g = 0; g < MAXG; ++g) {
                 if (g >= G) break;
-                const int c = 64 * g + lane;
+                const int c = 64 * g + tern_chan_of_bit(lane);             // (ballot bit `lane` = this channel: the mask words' bit order)
                 int q = 0;
                 if (valid && c < p.C) {
                     float a = fmaxf(fmaf(p.x[(size_t)row * p.ldx + c], s_sc[c], s_sh[c]), 0.f);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int m = m0 + u < p.M ? m0 + u : m0;
-                const int c = 64 * g + lane;
+                const int c = 64 * g + tern_chan_of_bit(lane);             // (ballot bit `lane` = this channel)
                 xv[u][g] = (g < G && c < p.C) ? ldg1(p.x + (size_t)m * p.ldx + c) : 0.f;
             }
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
             long long ssum = 0;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const int c = 64 * g + lane;
+                const int c = 64 * g + tern_chan_of_bit(lane);
                 int q = 0;
                 if (g < G && c < p.C) {
                     float a = fmaxf(fmaf(xv[u][g], s_sc[c], s_sh[c]), 0.f);
@@ -326,6 +326,108 @@ __global__ __launch_bounds__(256) void ternary_planes_kernel(const TernArgs p) {
             if (lane == 14) mine = (uint64_t)ssum;
             if (lane < TERN_REC_WORDS) p.planes[(size_t)(m0 + u) * TERN_REC_WORDS + lane] = mine;
         }
+    }
+}
+
+// The plane records with LANE = PIXEL (round 5, with the lane-per-pixel counting kernel).  The ballot kernel above spends ~150 wave
+// instructions per pixel (a wave per pixel: 14 ballots, 14 scalar popcounts, the selects that route words to lanes 0..14) -- 22 us per launch
+// on average, 3.5 ms of a CU-Net-16 step, as much as the counting it serves.  Here a wave takes 64 pixels: phase 1, lanes along CHANNELS
+// (a 16-byte piece of 4 channels per lane, two pixels per load instruction: coalesced), BatchNorm + ReLU + QuanInput, the four quantised
+// bytes packed into a dword of a wave-private LDS tile [64 pixels][32 dwords + 1]; phase 2, lane = pixel: its 32 dwords come back by
+// conflict-free ds_read_b32, and bit b of the four channels of dword k lands in plane b by (d >> b) & 0x01010101 shifted left by k -- three
+// operations per dword and plane, the bit order of tern_bit_of_chan (common.h).  The pixel sum is v_sad_u8 over the same dwords.
+// ~23 instead of ~150 wave instructions per pixel; the records are bit-identical to the ballot kernel's.
+__global__ __launch_bounds__(256) void ternary_planes_rows_kernel(const TernArgs p) {
+    __shared__ float s_sc[128], s_sh[128];
+    __shared__ unsigned s_q[4][64 * 33];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int c = tid; c < 128; c += 256) {
+        float sc = 0.f, sh = 0.f;
+        if (c < p.C && p.scale != nullptr) {
+            sc = p.scale[c]; sh = p.shift[c];
+        } else if (c < p.C) {
+            double mean, istd;
+            if (p.training) {
+                mean = p.xstats[c] / p.count;
+                double var = p.xstats[p.C + c] / p.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                istd = 1.0 / sqrt(var + (double)BN_EPS);
+            } else {
+                mean = (double)p.rmean[c];
+                istd = 1.0 / sqrt((double)p.rvar[c] + (double)BN_EPS);
+            }
+            const double scale = (double)p.gamma[c] * istd;
+            sc = (float)scale;
+            sh = (float)((double)p.beta[c] - mean * scale);
+        }
+        s_sc[c] = sc; s_sh[c] = sh;
+    }
+    __syncthreads();
+    const int nb = p.bits_i - 1;
+    const float qs = exp2f((float)nb);
+    const float lim = 1.f - 1.f / qs;
+    if (blockIdx.x == 0 && tid < 2 * TERN_REC_WORDS) reinterpret_cast<unsigned*>(p.planes + (size_t)p.M * TERN_REC_WORDS)[tid] = 0u;      // the zero record
+    const int c4 = 4 * (lane & 31);                       // phase 1: this lane's four channels (the same in every load)
+    const bool chan_ok = c4 < p.C;                         // (C is a multiple of 4: a piece is inside or outside as a whole)
+    const float4 sc4 = *reinterpret_cast<const float4*>(s_sc + c4), sh4 = *reinterpret_cast<const float4*>(s_sh + c4);
+    unsigned* Q = s_q[wave];
+    const int groups = (p.M + 63) >> 6;
+    for (int grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
+        const int m0 = grp * 64;
+        // ---- phase 1: quantise, pack, LDS (eight loads in flight per lane)
+#pragma unroll
+        for (int j0 = 0; j0 < 32; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = m0 + 2 * (j0 + u) + (lane >> 5);
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (chan_ok && m < p.M) v[u] = ldg4(p.x + (size_t)m * p.ldx + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const float s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, h4[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                unsigned packed = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = fmaxf(fmaf(f[e], s4[e], h4[e]), 0.f);
+                    a = fminf(a, lim);                                     // C(x, bits_i); relu already >= 0
+                    packed |= (unsigned)(int)rintf(a * qs) << (8 * e);     // Q(x, bits_i) * 2^(bits_i-1): at most 127
+                }
+                Q[(2 * (j0 + u) + (lane >> 5)) * 33 + (lane & 31)] = packed;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: lane = pixel m0 + lane
+        unsigned rec[2 * TERN_REC_WORDS];
+#pragma unroll
+        for (int i = 0; i < 2 * TERN_REC_WORDS; ++i) rec[i] = 0u;
+        unsigned ssum = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {                       // 32-channel group h: word 7 (h >> 1) + b, half h & 1
+            unsigned A[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned d = Q[lane * 33 + 8 * h + k];
+                ssum = __builtin_amdgcn_sad_u8(d, 0u, ssum);
+#pragma unroll
+                for (int b = 0; b < 7; ++b) A[b] |= ((d >> b) & 0x01010101u) << k;
+            }
+#pragma unroll
+            for (int b = 0; b < 7; ++b) rec[2 * (7 * (h >> 1) + b) + (h & 1)] = A[b];
+        }
+        rec[28] = ssum;                                    // word 14: the pixel's sum of quantised activations
+        if (m0 + lane < p.M) {
+            uint4* dst = reinterpret_cast<uint4*>(p.planes + (size_t)(m0 + lane) * TERN_REC_WORDS);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = make_uint4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the next group's bytes overwrite the tile)
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -445,7 +547,6 @@ __global__ __launch_bounds__(TCP_THREADS) void ternary_conv_planes_kernel(const 
 // the MFMA forward of the same node.  The output's batch statistics: per item a reduce-scatter over the 64 lanes (8 values -> one per
 // lane group) in exact integer / fp64 arithmetic, two LDS atomics on 8 lanes, one pair of global atomics per channel and block.
 constexpr int TPX_THREADS = 256;
-constexpr int TPX_OC = 8;
 // popc(v) + acc in ONE instruction (v_bcnt_u32_b32's second operand): left to itself hipcc counts into a fresh register and adds
 // afterwards (v_bcnt ..., 0 + v_add3: 72 instead of 63 vector instructions per output channel and tap)
 __device__ __forceinline__ int tpx_count(unsigned v, int acc) {
@@ -458,7 +559,9 @@ __device__ __forceinline__ int tpx_count(unsigned v, int acc) {
 #endif
 }
 
-template <int TAPS>
+// TPX_OC output channels per work item: 8 where the launch has work items to spare (64 x 64), 4 / 2 below -- a 16 x 16 launch of batch 24 is
+// 96 pixel groups: with 8 channels per item 384 items sit on 1024 SIMDs and the launch lasts one item's latency (25 us for 10 us of work).
+template <int TAPS, int TPX_OC>
 __global__ __launch_bounds__(TPX_THREADS) void ternary_conv_pixels_kernel(const TernArgs p) {
     __shared__ double s_red[2][32];
     const int tid = threadIdx.x;
@@ -479,8 +582,11 @@ __global__ __launch_bounds__(TPX_THREADS) void ternary_conv_pixels_kernel(const 
     typedef const __attribute__((address_space(4))) uint64_t* cmask_t;
     const cmask_t cpos = (cmask_t)(uintptr_t)p.wpos, cneg = (cmask_t)(uintptr_t)p.wneg;
     // valid-channel masks per group (channels >= C carry zero planes; their "zero weights" must not trigger the Z term)
-    const uint64_t valid0 = p.C >= 64 ? ~0ull : ((1ull << p.C) - 1ull);
-    const uint64_t valid1 = p.C >= 128 ? ~0ull : (p.C > 64 ? ((1ull << (p.C - 64)) - 1ull) : 0ull);
+    uint64_t valid0 = 0, valid1 = 0;
+    for (int b = 0; b < 64; ++b) {                                      // (bit b of a word = channel tern_chan_of_bit(b) of its group)
+        if (tern_chan_of_bit(b) < p.C) valid0 |= 1ull << b;
+        if (64 + tern_chan_of_bit(b) < p.C) valid1 |= 1ull << b;
+    }
 
     for (int item = blockIdx.x * (TPX_THREADS / 64) + wave; item < items; item += stride) {
         const int grp = item / nch;
@@ -571,9 +677,12 @@ __global__ __launch_bounds__(TPX_THREADS) void ternary_conv_pixels_kernel(const 
         // ---- store (8 consecutive channels per pixel)
         if (live) {
             float* yrow = p.y + (size_t)m * p.ldy + o0;
-            if (o0 + TPX_OC <= p.O && (p.ldy & 3) == 0) {
-                *reinterpret_cast<float4*>(yrow) = make_float4((float)yi[0] / qs, (float)yi[1] / qs, (float)yi[2] / qs, (float)yi[3] / qs);
-                *reinterpret_cast<float4*>(yrow + 4) = make_float4((float)yi[4] / qs, (float)yi[5] / qs, (float)yi[6] / qs, (float)yi[7] / qs);
+            if (TPX_OC >= 4 && o0 + TPX_OC <= p.O && (p.ldy & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j + 3 < TPX_OC; j += 4)
+                    *reinterpret_cast<float4*>(yrow + j) = make_float4((float)yi[j] / qs, (float)yi[j + 1] / qs, (float)yi[j + 2] / qs, (float)yi[j + 3] / qs);
+            } else if (TPX_OC == 2 && o0 + 2 <= p.O && (p.ldy & 1) == 0) {
+                *reinterpret_cast<float2*>(yrow) = make_float2((float)yi[0] / qs, (float)yi[1] / qs);
             } else {
 #pragma unroll
                 for (int j = 0; j < TPX_OC; ++j)
@@ -586,10 +695,13 @@ __global__ __launch_bounds__(TPX_THREADS) void ternary_conv_pixels_kernel(const 
             double q[TPX_OC];
 #pragma unroll
             for (int j = 0; j < TPX_OC; ++j) { v[j] = yi[j]; q[j] = (double)yi[j] * (double)yi[j]; }
+            constexpr int LG = TPX_OC == 8 ? 3 : (TPX_OC == 4 ? 2 : 1);
+            int jo = 0;                                                             // the channel this lane group ends up summing
 #pragma unroll
-            for (int step = 0; step < 3; ++step) {                                  // reduce-scatter: 8 -> 4 -> 2 -> 1 values per lane
-                const int mask = 32 >> step, half = 4 >> step;
+            for (int step = 0; step < LG; ++step) {                                 // reduce-scatter: OC -> OC / 2 -> ... -> 1 values per lane
+                const int mask = 32 >> step, half = TPX_OC >> (step + 1);
                 const bool up = (lane & mask) != 0;
+                jo += up ? half : 0;
 #pragma unroll
                 for (int j = 0; j < half; ++j) {
                     const int sendv = up ? v[j] : v[j + half], keepv = up ? v[j + half] : v[j];
@@ -599,12 +711,11 @@ __global__ __launch_bounds__(TPX_THREADS) void ternary_conv_pixels_kernel(const 
                 }
             }
 #pragma unroll
-            for (int mask = 4; mask > 0; mask >>= 1) {
+            for (int mask = 32 >> LG; mask > 0; mask >>= 1) {
                 v[0] += __shfl_xor(v[0], mask, 64);
                 q[0] += __shfl_xor(q[0], mask, 64);
             }
-            const int jo = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);      // the channel this lane group summed
-            if ((lane & 7) == 0 && o0 + jo < p.O) {
+            if ((lane & ((64 >> LG) - 1)) == 0 && o0 + jo < p.O) {
                 atomicAdd(&s_red[0][oc * TPX_OC + jo], (double)v[0] / (double)qs);
                 atomicAdd(&s_red[1][oc * TPX_OC + jo], q[0] / ((double)qs * (double)qs));
             }
@@ -638,8 +749,8 @@ __global__ __launch_bounds__(256) void ternary_pack_all_kernel(const TernPackEnt
                 const int ch = 64 * g + c;
                 if (ch >= e.C) break;
                 const float v = w[((size_t)o * e.C + ch) * e.taps + t];
-                if (v > 0.f) pp |= (uint64_t)1 << c;
-                if (v < 0.f) nn |= (uint64_t)1 << c;
+                if (v > 0.f) pp |= (uint64_t)1 << tern_bit_of_chan(c);
+                if (v < 0.f) nn |= (uint64_t)1 << tern_bit_of_chan(c);
             }
         wpos[i] = pp;
         wneg[i] = nn;
@@ -661,8 +772,8 @@ __global__ __launch_bounds__(256) void ternary_pack_kernel(const float* __restri
                 const int ch = 64 * g + c;
                 if (ch >= C) break;
                 const float v = w[((size_t)o * C + ch) * taps + t];
-                if (v > 0.f) pp |= (uint64_t)1 << c;
-                if (v < 0.f) nn |= (uint64_t)1 << c;
+                if (v > 0.f) pp |= (uint64_t)1 << tern_bit_of_chan(c);
+                if (v < 0.f) nn |= (uint64_t)1 << tern_bit_of_chan(c);
             }
         wpos[i] = pp;
         wneg[i] = nn;
@@ -684,13 +795,27 @@ hipError_t launch_ternary_pack_all(const TernPackEntry* tab, int n, const float*
 hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
     if ((a.taps != 1 && a.taps != 9) || a.bits_i < 2 || a.bits_i > 15) return hipErrorInvalidValue;
     if (a.planes != nullptr && a.C <= 128 && a.bits_i <= 8) {      // plan path (and cunet_ternary_conv_ex): bit-planes once per tensor
-        int gp = (a.M + 7) / 8;
-        if (gp > 8 * num_cus) gp = 8 * num_cus;
-        hipLaunchKernelGGL(ternary_planes_kernel, dim3(gp), dim3(256), 0, s, a);
+        if (a.variant != 0 && a.C % 4 == 0 && a.ldx % 4 == 0 && ((uintptr_t)a.x & 15) == 0) {      // lane = pixel (16-byte pieces of 4 channels)
+            int gp = ((a.M + 63) / 64 + 3) / 4;
+            if (gp > 8 * num_cus) gp = 8 * num_cus;
+            hipLaunchKernelGGL(ternary_planes_rows_kernel, dim3(gp), dim3(256), 0, s, a);
+        } else {
+            int gp = (a.M + 7) / 8;
+            if (gp > 8 * num_cus) gp = 8 * num_cus;
+            hipLaunchKernelGGL(ternary_planes_kernel, dim3(gp), dim3(256), 0, s, a);
+        }
         if (a.variant != 0) {            // lane = pixel, masks as scalar operands (planner option popcount_pixels)
             const int cols = (a.O + 31) / 32;
-            const int nch = ((a.O < 32 ? a.O : 32) + TPX_OC - 1) / TPX_OC;
-            const long items = (long)((a.M + 63) / 64) * nch;
+            const int ocols = a.O < 32 ? a.O : 32;
+            const long groups = (a.M + 63) / 64;
+            // output channels per work item: the most that still leaves an item per SIMD (1024 SIMDs; 32 x 32 at 8 channels: 34.7 us, at 4: 40.9 -- the plane loads are amortised over fewer channels)
+#ifndef CUNET_TPX_MAX_OC
+#define CUNET_TPX_MAX_OC 8
+#endif
+            int oc = CUNET_TPX_MAX_OC;
+            while (oc > 2 && groups * ((ocols + oc - 1) / oc) * cols < 1024) oc >>= 1;
+            const int nch = (ocols + oc - 1) / oc;
+            const long items = groups * nch;
             long gxp = (items + TPX_THREADS / 64 - 1) / (TPX_THREADS / 64);
             const long cap = 6L * num_cus;                                   // six 4-wave blocks per CU: the kernel's occupancy
             if (gxp > cap) {
@@ -699,8 +824,10 @@ hipError_t launch_ternary_conv(const TernArgs& a, int num_cus, hipStream_t s) {
             }
             if (gxp < 1) gxp = 1;
             const dim3 gridp((unsigned)gxp, cols);
-            if (a.taps == 9) hipLaunchKernelGGL((ternary_conv_pixels_kernel<9>), gridp, dim3(TPX_THREADS), 0, s, a);
-            else hipLaunchKernelGGL((ternary_conv_pixels_kernel<1>), gridp, dim3(TPX_THREADS), 0, s, a);
+#define CUNET_TPX(T_, OC_) hipLaunchKernelGGL((ternary_conv_pixels_kernel<T_, OC_>), gridp, dim3(TPX_THREADS), 0, s, a)
+            if (a.taps == 9) { if (oc == 8) CUNET_TPX(9, 8); else if (oc == 4) CUNET_TPX(9, 4); else CUNET_TPX(9, 2); }
+            else { if (oc == 8) CUNET_TPX(1, 8); else if (oc == 4) CUNET_TPX(1, 4); else CUNET_TPX(1, 2); }
+#undef CUNET_TPX
             return hipGetLastError();
         }
         int gx = (a.M + TCP_THREADS / 64 - 1) / (TCP_THREADS / 64);
