@@ -348,11 +348,12 @@ def test_decode_with_rotation_matches_reference_vectors():
     rot == 0) against the EXECUTED reference (G8r): bit-exact integer coordinates."""
     import numpy as np
     from tests._golden import GOLDEN_DIR
-    z = np.load(os.path.join(GOLDEN_DIR, 'G8r_decode_rot.npz'))
-    hm = torch.from_numpy(z['heat']).cuda()
-    fp = cu_net_amd.final_preds(hm, torch.from_numpy(z['center']), torch.from_numpy(z['scale']), [64, 64], torch.from_numpy(z['rot']))
+    z = np.load(os.path.join(GOLDEN_DIR, 'G8r_decode_rot.npz'))      # (angles + result; maps, centres and scales are G8's)
+    z0 = np.load(os.path.join(GOLDEN_DIR, 'G8_decode.npz'))
+    hm = torch.from_numpy(z0['heat']).cuda()
+    fp = cu_net_amd.final_preds(hm, torch.from_numpy(z0['center']), torch.from_numpy(z0['scale']), [64, 64], torch.from_numpy(z['rot']))
     assert torch.equal(fp.cpu(), torch.from_numpy(z['final_preds']))
-    z0 = np.load(os.path.join(GOLDEN_DIR, 'G8_decode.npz'))      # and the affine entry point reproduces the rot == 0 vectors as well
+    # and the affine entry point reproduces the rot == 0 vectors as well
     from cu_net_amd.trainer import _inverse_crop_transforms, _ptr, _stream_ptr
     from cu_net_amd._lib import check, lib
     inv = torch.from_numpy(_inverse_crop_transforms(torch.from_numpy(z0['center']), torch.from_numpy(z0['scale']), torch.zeros(hm.shape[0]), 64)).cuda()

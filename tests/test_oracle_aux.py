@@ -44,8 +44,10 @@ def test_decode_with_rotation_oracle_and_host_transform_match_reference_vectors(
     rationals; truncation; + 1) to the oracle's refined coordinates."""
     from fractions import Fraction
     from cu_net_amd.trainer import _inverse_crop_transforms
-    z = np.load(os.path.join(GOLDEN_DIR, 'G8r_decode_rot.npz'))
-    hm, center, scale, rot = (torch.from_numpy(z[k]) for k in ('heat', 'center', 'scale', 'rot'))
+    z = np.load(os.path.join(GOLDEN_DIR, 'G8r_decode_rot.npz'))      # (angles + result; maps, centres and scales are G8's)
+    z0 = np.load(os.path.join(GOLDEN_DIR, 'G8_decode.npz'))
+    hm, center, scale = (torch.from_numpy(z0[k]) for k in ('heat', 'center', 'scale'))
+    rot = torch.from_numpy(z['rot'])
     want = torch.from_numpy(z['final_preds'])
     assert torch.equal(DR.final_preds(hm, center, scale, [64, 64], rot), want)
     inv = _inverse_crop_transforms(center, scale, rot, 64)

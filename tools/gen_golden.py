@@ -546,8 +546,8 @@ def decode_parity():
     ref_fr = ev.final_preds(hm, center, scale, [64, 64], rot)
     check('G8r/final_preds', ref_fr, DR.final_preds(hm, center, scale, [64, 64], rot))
     assert not torch.equal(ref_fr, ref_fp)
-    np.savez_compressed(os.path.join(OUT, 'G8r_decode_rot.npz'), heat=to_np(hm), center=to_np(center), scale=to_np(scale), rot=to_np(rot),
-                        final_preds=to_np(ref_fr))
+    # (heat maps, centres and scales are G8's: only the angles and the result are stored)
+    np.savez_compressed(os.path.join(OUT, 'G8r_decode_rot.npz'), rot=to_np(rot), final_preds=to_np(ref_fr))
     print('G8r: final_preds with rot != 0 on 4x16 maps: oracle == reference')
 
 
