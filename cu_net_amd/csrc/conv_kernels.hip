@@ -1355,6 +1355,9 @@ template <int N> __device__ __forceinline__ void drs_wait(f32x4a& a, f32x4a& b, 
 
 __global__ __launch_bounds__(DRS_MAX_WAVES * 64, 2) void dgrad1x1_rows_split2_kernel(const ConvArgs p, int cgroups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef CUNET_TUNING
+    const unsigned long long tk_entry = CUNET_DBG(p, 16384) ? __builtin_amdgcn_s_memtime() : 0ull;      // (the wave's first instruction: set-up = [7] - the phases)
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1522,9 +1525,10 @@ __global__ __launch_bounds__(DRS_MAX_WAVES * 64, 2) void dgrad1x1_rows_split2_ke
     }
 #ifdef CUNET_TUNING
     if (stamp && lane == 0 && active) {
+        const unsigned long long tk1 = now();      // (stamped BEFORE this wave queues its atomics: ~10 k same-address atomics per launch back up the memory path, which round 5's "whole kernel" column included)
         atomicAdd(&g_conv_phase[0], (unsigned long long)k);
         for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
-        atomicAdd(&g_conv_phase[7], now() - tk0);
+        atomicAdd(&g_conv_phase[7], tk1 - tk_entry);
     }
 #endif
     (void)tk0; (void)ph;
@@ -1960,9 +1964,10 @@ __global__ __launch_bounds__(512, 2) void dgrad3x3_ring_split_kernel(const ConvA
     }
 #ifdef CUNET_TUNING
     if (stamp && lane == 0) {
+        const unsigned long long tk1 = now();      // (stamped BEFORE this wave queues its atomics: ~10 k same-address atomics per launch back up the memory path, which round 5's "whole kernel" column included)
         atomicAdd(&g_conv_phase[0], (unsigned long long)(g_end > g_begin ? g_end - g_begin : 0));
         for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
-        atomicAdd(&g_conv_phase[7], now() - tk0);
+        atomicAdd(&g_conv_phase[7], tk1 - tk0);
     }
 #endif
     (void)tk0; (void)ph;
@@ -2547,9 +2552,10 @@ __global__ __launch_bounds__(R3_THREADS) void conv3x3_ring_split_kernel(const Co
     }
 #ifdef CUNET_TUNING
     if (stamp && lane == 0) {
+        const unsigned long long tk1 = now();      // (stamped BEFORE this wave queues its atomics: ~10 k same-address atomics per launch back up the memory path, which round 5's "whole kernel" column included)
         atomicAdd(&g_conv_phase[0], (unsigned long long)(g_end > g_begin ? g_end - g_begin : 0));
         for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[1 + i], ph[i]);
-        atomicAdd(&g_conv_phase[7], now() - tk0);
+        atomicAdd(&g_conv_phase[7], tk1 - tk0);
     }
 #endif
     (void)tk0; (void)ph;

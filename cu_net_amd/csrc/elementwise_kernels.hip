@@ -134,10 +134,19 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GradGatherArgs p
 // arithmetic is 32-bit, two rows are in flight per thread (R = 2, plain consumers), and the launcher sizes the grid so that every
 // block walks the same number of row groups (3072 groups on 2048 blocks was 2 rounds for half of them, 1 for the rest).  Element for
 // element the same operations in the same order as the kernel above: bit-identical results.
-template <int NSRC, int UPS, int XBG, int V = 4>
-__global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherArgs p, int gshift) {
+// (round 6: the body is a device function of (arguments, block index, block count) so that two problems can share a launch --
+// gather_pool_pair_kernel below.  POOL = 1: the gathered tensor is the output of a 2 x 2 max-pool; the same thread routes its piece of
+// the gradient to the window's first arg-max of the pre-pool tensor `px` (pool_bwd_kernel's operation) and writes zeros to the other three.)
+struct PoolRoute {
+    const float* px;       // pre-pool activations [N * 2H * 2W][pC]   (H, W: the gathered = pooled tensor's)
+    float* pgx;            // their gradient
+    int pC;
+};
+
+template <int NSRC, int UPS, int XBG, int V, bool POOL>
+__device__ __forceinline__ void gather_rows_body(const GradGatherArgs& p, int gshift, int bid, int nblocks, const PoolRoute& pr, char* smem) {
     constexpr int XB = XBG != 0, GB = XBG == 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!(POOL && UPS), "a pooled tensor is read at its own resolution");
     float* cE = reinterpret_cast<float*>(smem);
     float* cD = cE + p.C;
     float* cA = cD + p.C;
@@ -178,9 +187,11 @@ __global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherA
     const int HW = p.H * p.W;
     constexpr int U = UPS ? 4 : 1;
     constexpr int R = UPS ? 1 : 2;                     // rows in flight per thread
-    const int stride = (int)gridDim.x * rpb;
-    for (int row0 = (int)blockIdx.x * rpb + (tid >> gshift); row0 < p.rows; row0 += R * stride) {
+    const int stride = nblocks * rpb;
+    for (int row0 = bid * rpb + (tid >> gshift); row0 < p.rows; row0 += R * stride) {
         float d[R][NSRC][U][V], x[R][V], o[R][V];
+        float win[POOL ? R : 1][4][V];                 // POOL: the 2 x 2 window of the pre-pool tensor
+        size_t woff[POOL ? R : 1][4];
         bool live[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -208,6 +219,15 @@ __global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherA
 #pragma unroll
             for (int k = 0; k < V; ++k) o[q][k] = 0.f;
             if (p.accumulate) ldxv<GB, V>(p.gx, (size_t)rr * p.ld + c, o[q]);
+            if constexpr (POOL) {
+                const int ni = rr / HW;
+                const int rm = rr - ni * HW;
+                const int yo = rm / p.W, xo = rm - yo * p.W;
+                const size_t m00 = ((size_t)ni * (2 * p.H) + 2 * yo) * (2 * p.W) + 2 * xo;
+                woff[q][0] = m00; woff[q][1] = m00 + 1; woff[q][2] = m00 + 2 * p.W; woff[q][3] = m00 + 2 * p.W + 1;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ldxv<XB, V>(pr.px, woff[q][w] * pr.pC + c, win[q][w]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -226,7 +246,48 @@ __global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherA
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] += o[q][k];
             if (live[q]) stxv<GB, V>(p.gx, (size_t)(row0 + q * stride) * p.ld + c, r);
+            if constexpr (POOL) {
+                if (live[q]) {
+                    float outw[4][V];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        // what pool_bwd_kernel would read back from the pooled gradient tensor: the stored (bf16: rounded) value
+                        const float gv = GB ? bf16_bits_lo((unsigned)f32_to_bf16_rne(r[k])) : r[k];
+                        int am = 0;
+                        float best = win[q][0][k];
+#pragma unroll
+                        for (int w = 1; w < 4; ++w)
+                            if (win[q][w][k] > best) { best = win[q][w][k]; am = w; }
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) outw[w][k] = (w == am) ? gv : 0.f;
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) stxv<GB, V>(pr.pgx, woff[q][w] * pr.pC + c, outw[w]);
+                }
+            }
         }
+    }
+}
+
+template <int NSRC, int UPS, int XBG, int V = 4>
+__global__ __launch_bounds__(256) void grad_gather_rows_kernel(const GradGatherArgs p, int gshift) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gather_rows_body<NSRC, UPS, XBG, V, false>(p, gshift, (int)blockIdx.x, (int)gridDim.x, PoolRoute{}, smem);
+}
+
+// Round 6: the three element-wise launches in front of a down block's adapter pair in backward -- gather(pool output) -> pool backward
+// (dependent), gather(skip adapter output) (independent of both) -- as ONE launch: blockIdx.y = 0 gathers the pooled tensor's gradient and
+// routes it through the arg-max map in the same thread (the pooled gradient is still written: tests and debuggers read it), blockIdx.y = 1
+// gathers the skip adapter's.  At r <= 16 each of the three is a 4 - 7 us launch (8 of them per U-Net saved); at 64 x 64 the pooled
+// gradient's re-read goes away.  Same operations on the same values as the three launches: bit-identical (tests/test_gpu_exact.py).
+template <int NA, int NB, int XBG, int V>
+__global__ __launch_bounds__(256) void gather_pool_pair_kernel(const GradGatherArgs a, const GradGatherArgs b, const PoolRoute pr, int gshift_a,
+                                                               int gshift_b, int nblk_a, int nblk_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.y == 0) {
+        if ((int)blockIdx.x < nblk_a) gather_rows_body<NA, 0, XBG, V, true>(a, gshift_a, (int)blockIdx.x, nblk_a, pr, smem);
+    } else {
+        if ((int)blockIdx.x < nblk_b) gather_rows_body<NB, 0, XBG, V, false>(b, gshift_b, (int)blockIdx.x, nblk_b, PoolRoute{}, smem);
     }
 }
 
@@ -306,6 +367,68 @@ hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t 
     }
     if (a.xbf16) return a.src[0].ups ? launch_gather_n<1, 1>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 1>(a, dim3((unsigned)gx), smem, s);
     return a.src[0].ups ? launch_gather_n<1, 0>(a, dim3((unsigned)gx), smem, s) : launch_gather_n<0, 0>(a, dim3((unsigned)gx), smem, s);
+}
+
+// geometry of a gather on the fixed-channel-piece kernel (the one launch_grad_gather would pick): false when the tensor's shape keeps the
+// flat-index kernel
+static bool gather_rows_geometry(const GradGatherArgs& a, int num_cus, int& V, int& gshift, long& blocks) {
+    bool v8 = a.xbf16 == 2 && a.C % 8 == 0 && a.ld % 8 == 0;
+    for (int e = 0; e < a.nsrc; ++e) v8 = v8 && a.src[e].lddz % 8 == 0 && a.src[e].choff % 8 == 0;
+    V = v8 ? 8 : 4;
+    const int gv = a.C / V;
+    if (!((a.xbf16 != 2 || v8) && a.C % V == 0 && gv >= 1 && gv <= 256 && (gv & (gv - 1)) == 0 && (long)a.rows * a.ld < (1L << 31))) return false;
+    gshift = 0;
+    while ((1 << gshift) < gv) ++gshift;
+    const int rpb = 256 >> gshift;
+    const long groups = ((long)a.rows + rpb - 1) / rpb;
+    const int R = a.src[0].ups ? 1 : 2;
+    blocks = std::min(groups, 8L * num_cus);
+    const long rounds = (groups + blocks * R - 1) / (blocks * R);
+    blocks = std::max(1L, (groups + rounds * R - 1) / (rounds * R));
+    return true;
+}
+
+template <int NA, int XBG, int V>
+static hipError_t launch_gpp_b(const GradGatherArgs& a, const GradGatherArgs& b, const PoolRoute& pr, dim3 grid, size_t smem, int ga, int gb,
+                               int na, int nb, hipStream_t s) {
+    switch (b.nsrc) {
+#define CUNET_G(N) case N: hipLaunchKernelGGL((gather_pool_pair_kernel<NA, N, XBG, V>), grid, dim3(256), smem, s, a, b, pr, ga, gb, na, nb); break;
+        CUNET_G(1) CUNET_G(2) CUNET_G(3) CUNET_G(4)
+#undef CUNET_G
+        default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+template <int XBG, int V>
+static hipError_t launch_gpp_a(const GradGatherArgs& a, const GradGatherArgs& b, const PoolRoute& pr, dim3 grid, size_t smem, int ga, int gb,
+                               int na, int nb, hipStream_t s) {
+    switch (a.nsrc) {
+        case 1: return launch_gpp_b<1, XBG, V>(a, b, pr, grid, smem, ga, gb, na, nb, s);
+        case 2: return launch_gpp_b<2, XBG, V>(a, b, pr, grid, smem, ga, gb, na, nb, s);
+        case 3: return launch_gpp_b<3, XBG, V>(a, b, pr, grid, smem, ga, gb, na, nb, s);
+        case 4: return launch_gpp_b<4, XBG, V>(a, b, pr, grid, smem, ga, gb, na, nb, s);
+        default: return hipErrorNotSupported;
+    }
+}
+
+// `a`: the gather of a pooled tensor's gradient (its geometry = the pooled tensor's), routed on to `pool.gx` through the arg-max map of
+// `pool.x` [N][2H][2W][C]; `b`: an independent plain gather.  hipErrorNotSupported, nothing launched, when the pair does not fit this kernel
+// (up-sampled consumers, more than four consumers, an accumulating pass, mixed piece widths): the caller runs the three launches.
+hipError_t launch_gather_pool_pair(const GradGatherArgs& a, const GradGatherArgs& b, const PoolArgs& pool, int num_cus, hipStream_t s) {
+    if (a.nsrc < 1 || b.nsrc < 1 || a.accumulate || b.accumulate || a.xbf16 != b.xbf16 || a.xbf16 != pool.xbf16) return hipErrorNotSupported;
+    for (int e = 0; e < a.nsrc; ++e) if (a.src[e].ups) return hipErrorNotSupported;
+    for (int e = 0; e < b.nsrc; ++e) if (b.src[e].ups) return hipErrorNotSupported;
+    if (pool.C != a.C || a.ld != a.C || pool.H != 2 * a.H || pool.W != 2 * a.W || (long)pool.N * a.H * a.W != (long)a.rows) return hipErrorNotSupported;
+    int va, vb, ga, gb;
+    long na, nb;
+    if (!gather_rows_geometry(a, num_cus, va, ga, na) || !gather_rows_geometry(b, num_cus, vb, gb, nb) || va != vb) return hipErrorNotSupported;
+    if ((long)pool.N * pool.H * pool.W * pool.C >= (1L << 31)) return hipErrorNotSupported;
+    PoolRoute pr{pool.x, pool.gx, pool.C};
+    const size_t smem = std::max((size_t)a.C * 4 * (2 + a.nsrc), (size_t)b.C * 4 * (2 + b.nsrc));
+    const dim3 grid((unsigned)std::max(na, nb), 2);
+    if (a.xbf16 == 2) return va == 8 ? launch_gpp_a<2, 8>(a, b, pr, grid, smem, ga, gb, (int)na, (int)nb, s) : launch_gpp_a<2, 4>(a, b, pr, grid, smem, ga, gb, (int)na, (int)nb, s);
+    if (a.xbf16) return launch_gpp_a<1, 4>(a, b, pr, grid, smem, ga, gb, (int)na, (int)nb, s);
+    return launch_gpp_a<0, 4>(a, b, pr, grid, smem, ga, gb, (int)na, (int)nb, s);
 }
 
 // dgamma / dbeta of a batch of BatchNorms from their backward reductions (one block per BatchNorm)

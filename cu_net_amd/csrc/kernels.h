@@ -22,6 +22,7 @@ bool wgrad3_3x3_on_bf16_mfma(const WgradArgs& a);      // bf16 x and dY, W in {1
 hipError_t launch_wgrad3_3x3(const WgradArgs& a, float* part, int S, int rows_per_split, hipStream_t s);
 hipError_t launch_wgrad_reduce(const WgReduceEntry* tab, int n, int max_numel, const float* ws, float* grads, hipStream_t s);
 hipError_t launch_grad_gather(const GradGatherArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_gather_pool_pair(const GradGatherArgs& a, const GradGatherArgs& b, const PoolArgs& pool, int num_cus, hipStream_t s);      // hipErrorNotSupported: nothing launched
 hipError_t launch_bn_param_grad(const BnParamGradArgs& a, hipStream_t s);
 hipError_t launch_pool_fwd(const PoolArgs& a, int mode, int num_cus, hipStream_t s);
 hipError_t launch_pool_bwd(const PoolArgs& a, int num_cus, hipStream_t s);

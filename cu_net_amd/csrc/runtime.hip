@@ -180,6 +180,7 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "dgrad3_nt") return &o.dgrad3_nt;
     if (n == "dgrad3_ring") return &o.dgrad3_ring;
     if (n == "stem_split") return &o.stem_split;
+    if (n == "fuse_pool_gather") return &o.fuse_pool_gather;
     return nullptr;
 }
 
@@ -370,13 +371,19 @@ int cunet_bind(cunet_plan_t* h, float* params, float* grads, float* buffers, int
             else HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, mode == 1 ? least : greatest));
         }
         h->fork_ev.resize(P.nodes.size());
-        const unsigned fork_flags = hipEventDisableTiming | (tune_int("CUNET_FORK_FLAGS", 0) ? hipEventReleaseToDevice : 0);
+        // Hand-over events order two streams of ONE device and are never inspected by the host (the caller synchronises its own stream):
+        // CUNET_FORK_FLAGS bit 0 = device-scope release, bit 1 = no system-scope fence when the event completes, bit 2 = the same for the
+        // events the caller's stream waits on (done / join / reduce / bucket).
+        const int ff = tune_int("CUNET_FORK_FLAGS", 0);
+        const unsigned scope_flags = ((ff & 1) ? hipEventReleaseToDevice : 0) | ((ff & 2) ? hipEventDisableSystemFence : 0);
+        const unsigned fork_flags = hipEventDisableTiming | scope_flags;
+        const unsigned back_flags = hipEventDisableTiming | ((ff & 4) ? scope_flags : 0);
         for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, fork_flags));
         h->done_ev.resize(P.nodes.size());
-        for (auto& e : h->done_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
-        for (auto& e : h->red_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->bucket_ev, hipEventDisableTiming));
+        for (auto& e : h->done_ev) HIPCHK(hipEventCreateWithFlags(&e, back_flags));
+        HIPCHK(hipEventCreateWithFlags(&h->join_ev, back_flags));
+        for (auto& e : h->red_ev) HIPCHK(hipEventCreateWithFlags(&e, back_flags));
+        HIPCHK(hipEventCreateWithFlags(&h->bucket_ev, back_flags));
     }
     h->fwd_training_done = 0; h->loss_done = 0;
     return CUNET_OK;
@@ -488,23 +495,22 @@ static void set_fused_mse(cunet_plan* h, const Exec& E, const Node& n, ConvArgs&
 // Gradient of tensor `t`: one gather over the dz slices of the conv nodes that read it (all of them have
 // run their data-gradient kernel: they come later in the forward order).  `only_node` >= 0 restricts the
 // gather to one consumer (node-local debugging / tests).
-static int gather_tensor_grad(cunet_plan* h, int t, int only_node, hipStream_t s) {
+// the launches of that gather, in order: plain consumers first, then the consumers behind the up-sample map, at most MAXGSRC per launch,
+// every launch after the first accumulating
+static void gather_launches(cunet_plan* h, int t, int only_node, std::vector<GradGatherArgs>& out) {
     Exec E(h);
     Plan& P = h->plan;
     const TensorInfo& ti = P.tensors[t];
-    int accumulate = 0;
+    out.clear();
     for (int ups = 0; ups < 2; ++ups) {
         GradGatherArgs a{};
-        auto flush = [&]() -> int {
-            if (a.nsrc == 0) return CUNET_OK;
-            a.accumulate = accumulate;
+        auto flush = [&]() {
+            if (a.nsrc == 0) return;
+            a.accumulate = out.empty() ? 0 : 1;
             a.x = E.xact(t); a.xbf16 = E.xmode; a.gx = E.grad(t); a.stats = E.stats(t); a.count = (double)ti.rows();
             a.C = ti.C; a.ld = ti.ld; a.rows = (int)ti.rows(); a.H = ti.H; a.W = ti.W;
-            PROF(PC_APPLY, 0.0, 4.0 * (double)ti.rows() * ti.C * (2.0 + accumulate + a.nsrc * (ups ? 4.0 : 1.0)),
-                 launch_grad_gather(a, h->num_cus, s));
-            accumulate = 1;
+            out.push_back(a);
             a = GradGatherArgs{};
-            return CUNET_OK;
         };
         for (int i = 0; i < ti.ccount; ++i) {
             const Contrib& c = P.contribs[ti.cfirst + i];
@@ -516,12 +522,60 @@ static int gather_tensor_grad(cunet_plan* h, int t, int only_node, hipStream_t s
             GradSrc& g = a.src[a.nsrc++];
             g.dz = E.wsf + n.dz; g.red = E.zero + n.red; g.gamma = h->params + P.bns[n.bn].gamma;
             g.lddz = n.Ccat; g.choff = choff; g.ups = ups; g.pad_ = 0;
-            if (a.nsrc == MAXGSRC) { const int rc = flush(); if (rc != CUNET_OK) return rc; }
+            if (a.nsrc == MAXGSRC) flush();
         }
-        const int rc = flush();
-        if (rc != CUNET_OK) return rc;
+        flush();
     }
+}
+
+static double gather_bytes(const GradGatherArgs& a) {
+    return 4.0 * (double)a.rows * a.C * (2.0 + a.accumulate + a.nsrc * (a.src[0].ups ? 4.0 : 1.0));
+}
+
+static int gather_tensor_grad(cunet_plan* h, int t, int only_node, hipStream_t s) {
+    std::vector<GradGatherArgs> ls;
+    gather_launches(h, t, only_node, ls);
+    for (const GradGatherArgs& a : ls)
+        PROF(PC_APPLY, 0.0, gather_bytes(a), launch_grad_gather(a, h->num_cus, s));
     return CUNET_OK;
+}
+
+static PoolArgs pool_bwd_args(cunet_plan* h, Exec& E, const Node& n) {
+    Plan& P = h->plan;
+    const int tin = n.segs[0].tensor;
+    const TensorInfo& ti = P.tensors[tin];
+    PoolArgs a{};
+    a.x = E.xact(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
+    a.xbf16 = E.xmode;
+    a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
+    return a;
+}
+
+// Backward of pool node `kp` together with the gather of the skip adapter in front of it (node kp - 1; planner option fuse_pool_gather):
+// gather(pool output) -> pool backward and gather(skip adapter output) in ONE launch (gather_pool_pair_kernel).  1: launched (the caller
+// must not gather the skip adapter's output again); 0: the pattern or the shapes do not fit, nothing launched; < 0: error in rc_out.
+static int bwd_pool_with_skip_gather(cunet_plan* h, int kp, hipStream_t s, int& rc_out) {
+    rc_out = CUNET_OK;
+    Plan& P = h->plan;
+    if (!P.opts.fuse_pool_gather || kp < 1) return 0;
+    const Node& np = P.nodes[kp];
+    const Node& ns = P.nodes[kp - 1];
+    if (np.type != N_POOL || ns.type != N_CONV || ns.bucket != np.bucket || ns.name.find(".adapters_skip.") == std::string::npos) return 0;
+    if (P.tensors[np.out].ccount <= 0 || P.tensors[ns.out].ccount <= 0 || P.tensors[np.segs[0].tensor].ld != P.tensors[np.segs[0].tensor].C) return 0;
+    std::vector<GradGatherArgs> la, lb;
+    gather_launches(h, np.out, -1, la);
+    gather_launches(h, ns.out, -1, lb);
+    if (la.size() != 1 || lb.size() != 1) return 0;
+    Exec E(h);
+    const PoolArgs pa = pool_bwd_args(h, E, np);
+    int slot_;
+    hipError_t e = prof_begin(h, PC_APPLY, s, slot_);
+    if (e == hipSuccess) e = launch_gather_pool_pair(la[0], lb[0], pa, h->num_cus, s);
+    if (e == hipErrorNotSupported) { prof_cancel(h, slot_); return 0; }
+    const TensorInfo& ti = P.tensors[np.segs[0].tensor];
+    if (e == hipSuccess) e = prof_end(h, slot_, 0.0, gather_bytes(la[0]) + gather_bytes(lb[0]) + 4.0 * 2.0 * (double)ti.rows() * ti.C, s);
+    if (e != hipSuccess) { rc_out = fail(CUNET_ERR_HIP, std::string("gather + pool backward: ") + hipGetErrorString(e)); return -1; }
+    return 1;
 }
 
 // dgamma / dbeta of the conv nodes [k0, k1) with bucket == `bucket` (or every bucket if < 0)
@@ -725,12 +779,8 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
         }
     } else if (n.type == N_POOL) {
         if (!(parts & BWD_MAIN)) return CUNET_OK;
-        const int tin = n.segs[0].tensor;
-        const TensorInfo& ti = P.tensors[tin];
-        PoolArgs a{};
-        a.x = E.xact(tin); a.gy = E.grad(n.out); a.gx = E.grad(tin);
-        a.xbf16 = E.xmode;
-        a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C;
+        const TensorInfo& ti = P.tensors[n.segs[0].tensor];
+        const PoolArgs a = pool_bwd_args(h, E, n);
         PROF(PC_POOLB, 0.0, 4.0 * 2.25 * (double)ti.rows() * ti.C, launch_pool_bwd(a, cus, s));
     } else if (n.type == N_STEM_BNPOOL) {
         if (!(parts & BWD_MAIN)) return CUNET_OK;
@@ -896,8 +946,11 @@ int cunet_forward(cunet_plan_t* h, const float* x, float* const* heat, int train
         // after site in stream order -- a head on the side stream would still be reading its records while the next U-Net's 3x3
         // site rewrites them on the caller's stream)
         const bool popcount_node = n.type == N_CONV && h->qin_bits && h->tern_live && h->node_qin[ni] && h->node_tern[ni];
+        // (round 6: never the LAST node of the list -- the last U-Net's head: nothing is left to run beside it, and the hand-over and the
+        // join around it were ~20 us of idle GPU between the forward and the backward)
         const bool forked = fork_fwd && n.type == N_CONV && !popcount_node &&
-                            ((o.W >= P.opts.fwd_fork_min_w && n.name.find(".adapters_skip.") != std::string::npos) || (n.head >= 0 && P.opts.heads_on_side));
+                            ((o.W >= P.opts.fwd_fork_min_w && n.name.find(".adapters_skip.") != std::string::npos) ||
+                             (n.head >= 0 && P.opts.heads_on_side && ni + 1 < P.nodes.size()));
         if (forked) {
             HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
             HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[ni], 0));
@@ -1056,7 +1109,7 @@ int cunet_forward_bf16(cunet_plan_t* h, const float* x, float* const* heat, int 
             }
             ConvArgs a = conv_fwd_args_bf16(h, E, n, a16, training);
             const int is_head = n.head >= 0;
-            const bool forked = is_head && fork_heads;      // a training pass: the head runs on the side stream (see cunet_forward)
+            const bool forked = is_head && fork_heads && ni + 1 < P.nodes.size();      // a training pass: the head runs on the side stream (see cunet_forward; the last node stays)
             if (forked) {
                 HIPCHK(hipEventRecord(h->fork_ev[ni], s_main));
                 HIPCHK(hipStreamWaitEvent(h->side, h->fork_ev[ni], 0));
@@ -1254,7 +1307,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         if (side_on && any_fused) HIPCHK(hipEventRecord(h->red_ev[position & 1], h->side));
         ++position;
         if (side_on && any_fused && position >= 2) HIPCHK(hipStreamWaitEvent(s, h->red_ev[position & 1], 0));      // (recorded at position - 2)
-        return bn_param_grads(h, k_lo, k_hi, cur_bucket, s);
+        return bn_param_grads(h, k_lo, k_hi, cur_bucket, s);      // (on the side stream instead: -0.5 % on the CU-Net-2 step, round 6 -- the side stream is the critical path at the end of a step)
     };
     // (bf16 gradient tensors: shorter kernels, the hand-over bubble weighs more -- 8 per group measured best there, 4 in fp32)
     // (fp32 gradients, round 5: 0 = by depth -- 2 for up to four U-Nets, where starting the side stream's work sooner shortens the tail of the
@@ -1262,6 +1315,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     // one box), 4 for deeper networks, where the tail is a small part of the step and the hand-overs add up (CU-Net-16: 578 vs 581))
     const int group_f32 = P.opts.wgrad_fork_group > 0 ? P.opts.wgrad_fork_group : (P.cfg.layer_num <= 4 ? 2 : 4);
     const size_t group = (h->use_side && h->side) ? (size_t)std::max(1, E.xmode == 2 ? P.opts.wgrad_fork_group_bf16 : group_f32) : 1;
+    int gathered_early = -1;                                   // node whose output gradient the fused pool launch has gathered already
     for (int k = (int)P.nodes.size() - 1; k >= 0; --k) {
         const Node& n = P.nodes[k];
         if (n.bucket != cur_bucket) {      // everything that writes bucket `cur_bucket` has been enqueued
@@ -1279,12 +1333,18 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             if (head_done[k] == 1) HIPCHK(hipStreamWaitEvent(s, h->done_ev[k], 0));
             continue;
         }
+        if (n.type == N_POOL) {            // gather + pool backward + the skip adapter's gather in one launch where the pattern fits
+            int rcp = CUNET_OK;
+            const int fused = bwd_pool_with_skip_gather(h, k, s, rcp);
+            if (fused < 0) return rcp;
+            if (fused) { gathered_early = k - 1; continue; }
+        }
         // the skip adapter of a pair (Node::pair on the node in front of it): both adapters' gradients are gathered first, then
         // their data gradients share a launch
         const bool paired = k >= 1 && P.nodes[k - 1].pair && P.nodes[k - 1].bucket == n.bucket;
         for (int q = k; q >= (paired ? k - 1 : k); --q) {
             const Node& nq = P.nodes[q];
-            if (P.tensors[nq.out].ccount > 0) {  // d(loss)/d(out): gather from the consumers (heads get theirs from the loss)
+            if (P.tensors[nq.out].ccount > 0 && q != gathered_early) {  // d(loss)/d(out): gather from the consumers (heads get theirs from the loss)
                 const int rcg = gather_tensor_grad(h, nq.out, -1, s);
                 if (rcg != CUNET_OK) return rcg;
             }

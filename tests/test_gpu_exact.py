@@ -698,3 +698,60 @@ def test_stem_weight_gradient_with_the_dz_pass_fused(n, h, w):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
     a, b = res[1][1], res[0][1]
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16_grads'])
+def test_pool_backward_fused_with_the_gathers_around_it(mode):
+    """Round 6, planner option fuse_pool_gather (default 1): in front of a down block's adapter pair backward runs gather(pool output) ->
+    pool backward and gather(skip adapter output) as ONE launch (gather_pool_pair_kernel) instead of three.  After a real backward pass:
+    the pre-pool tensor's gradient must be EXACTLY the pooled tensor's (stored) gradient routed to the first arg-max of every 2 x 2 window
+    (models/cu_net.py:260, torch's max_pool2d backward; torch.equal), the pool class must have no launch left and the gather class 8 per
+    U-Net fewer than with the option off, and loss / parameter gradients of the two selections agree to the order of the fp64 atomics."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    L = 2
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=L, order=1, loss_num=L)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=73)
+    x, target = O.synthetic_batch(4, 16, 256, seed=74)
+    res = {}
+    try:
+        for fuse in (1, 0):
+            set_planner_option('fuse_pool_gather', fuse)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(4, 256, 256, True, bf16=mode != 'fp32')
+            desc = plan.handle.describe()
+            plan.handle.profile_begin(1)
+            plan.handle.profile_reset()
+            loss = plan.stage_target(target.cuda())
+            if mode == 'fp32':
+                plan.forward(x.cuda(), True, want_outputs=False)
+            else:
+                plan.forward_bf16(x.cuda(), 2 if mode == 'bf16_grads' else 1, want_outputs=False)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            counts = {k: v[0] for k, v in plan.handle.profile_collect().items()}
+            plan.handle.profile_begin(0)
+            T = desc['tensors']
+            npool = 0
+            for nd in desc['nodes']:
+                if nd['op'] != 'pool':
+                    continue
+                npool += 1
+                xin = plan.debug_tensor(T[nd['segs'][0]['t']]['name']).float()
+                gy = plan.debug_tensor(T[nd['out']]['name'], grad=True).float()
+                gx = plan.debug_tensor(T[nd['segs'][0]['t']]['name'], grad=True).float()
+                leaf = xin.clone().requires_grad_(True)
+                torch.nn.functional.max_pool2d(leaf, 2, 2).backward(gy)
+                assert torch.equal(gx, leaf.grad), (fuse, nd['name'])
+            assert npool == 4 * L
+            res[fuse] = (float(loss), net._grad_arena.clone().cpu(), counts)
+    finally:
+        set_planner_option('fuse_pool_gather', 1)
+    assert res[1][2].get('pool_bwd', 0) == 0 and res[0][2]['pool_bwd'] == 4 * L, (res[1][2], res[0][2])
+    assert res[0][2]['bn_bwd_apply'] - res[1][2]['bn_bwd_apply'] == 4 * L, (res[0][2]['bn_bwd_apply'], res[1][2]['bn_bwd_apply'])
+    assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+    ga, gb = res[1][1], res[0][1]
+    assert float((ga - gb).norm() / gb.norm()) <= (1e-5 if mode == 'fp32' else 2e-2)

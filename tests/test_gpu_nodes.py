@@ -251,8 +251,10 @@ def _quantiser_tie_slack_forward(pre_q, w, bits, taps):
         return F.conv2d(_quantiser_tie_mask(pre_q, bits), w.abs(), None, 1, 1 if taps == 9 else 0) / 2.0 ** (bits - 1)
 
 
-def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0, only_ops=None, check_forward=False):
-    """wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
+def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0, only_ops=None, check_forward=False, node_filter=None):
+    """node_filter(k, node, desc) -> bool: check only the nodes it accepts (deep plans at the bench batch: every node of the first and the
+    last U-Nets, the nodes whose tensors straddle a 4 GB boundary of the workspace and a sample of the rest).
+    wgrad3_all = True: every eligible 1x1 weight gradient on the LDS-staged atomics-free kernel (the planner's default);
     False: the planner is told to keep them on the per-wave atomic kernel (wgrad2), which stays the path of narrow heads,
     non-32-multiple concats and the stem and must remain covered at production widths.
     check_forward: every conv / pool node's FORWARD output is compared too, with torch's on the GPU's own inputs (bf16 storage: on
@@ -260,12 +262,12 @@ def _check_all_nodes(cfg, st, x, bf16=False, wgrad3_all=False, quan_input_bits=0
     from cu_net_amd._lib import set_planner_option
     set_planner_option('wgrad3_min_rows', 0 if wgrad3_all else 1 << 30)
     try:
-        return _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops, check_forward)
+        return _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits, only_ops, check_forward, node_filter)
     finally:
         set_planner_option('wgrad3_min_rows', 0)
 
 
-def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_ops=None, check_forward=False):
+def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_ops=None, check_forward=False, node_filter=None):
     net = cu_net_amd.create_cu_net(**cfg)
     net.load_state_dict(st)
     net = net.cuda().train()
@@ -289,7 +291,18 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
             assert desc['nodes'][0]['op'] == 'stem_conv' and desc['nodes'][0]['wg3'] > 0, 'the planner did not select the LDS-staged stem kernel'
     elif only_ops and 'stem_conv' in only_ops:
         assert desc['nodes'][0]['wg3'] == 0
-    acts = {t['name']: plan.debug_tensor(t['name']).cpu() for t in T}
+    if node_filter is not None:      # (only the tensors the selected nodes touch leave the GPU)
+        picked = [k for k, nd in enumerate(desc['nodes']) if node_filter(k, nd, desc)]
+        assert picked, 'node_filter selected nothing'
+        need = set()
+        for k in picked:
+            need.add(desc['nodes'][k]['out'])
+            need.update(sg['t'] for sg in desc['nodes'][k]['segs'])
+        acts = {T[i]['name']: plan.debug_tensor(T[i]['name']).cpu() for i in sorted(need)}
+        picked = set(picked)
+    else:
+        picked = None
+        acts = {t['name']: plan.debug_tensor(t['name']).cpu() for t in T}
     off = {name: (o, nmel, shape) for name, kind, shape, o, nmel in net._entries if kind == 0}
 
     def pgrad(name):
@@ -299,6 +312,8 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
     bad = []
     for k, nd in enumerate(desc['nodes']):
         if only_ops is not None and nd['op'] not in only_ops:
+            continue
+        if picked is not None and k not in picked:
             continue
         gen = torch.Generator().manual_seed(1000 + k)
         oname = T[nd['out']]['name']
@@ -592,3 +607,59 @@ def test_weight_gradient_steady_state_loops(mode):
     key = 'wg3_bf16' if mode == 2 else 'wg3'
     big = [nd for nd in desc['nodes'] if nd['op'] == 'conv' and nd.get(key, 0) > 0 and desc['tensors'][nd['out']]['W'] == 64]
     assert big and all(nd[key] <= 8 for nd in big), [nd[key] for nd in big]
+
+
+def _deep_plan_filter(layer_num, stride):
+    """Nodes of a deep plan worth a CPU autograd pass at N = 24: every node of U-Net 0 and of the last U-Net (whose tensors sit at the far
+    end of the workspace), every node one of whose tensors straddles a multiple of 2^30 floats (4 GB: the offsets that no longer fit 32
+    bits), and every `stride`-th node of the U-Nets in between (their shapes repeat U-Net 1's; what differs are the offsets and buckets)."""
+    def f(k, nd, desc):
+        T = desc['tensors']
+        b = nd.get('bucket', 0)
+        if b in (0, layer_num - 1, layer_num):
+            return True
+        for i in [nd['out']] + [sg['t'] for sg in nd['segs']]:
+            t = T[i]
+            n = t['N'] * t['H'] * t['W'] * t['ld']
+            for o in (t['act'], t['grad']):
+                if o >= 0 and (o >> 30) != ((o + n) >> 30):
+                    return True
+        return k % stride == 0
+    return f
+
+
+def test_every_node_bench_batch_cu_net8_bf16_grads():
+    """BASELINE config 3's PLAN at the batch bench.py times it at -- CU-Net-8, K = 68, N = 24, bf16 activations and gradient tensors: nine
+    gradient buckets, a 10 GB workspace whose float offsets pass 2^31.  Node by node against autograd on the GPU's own activations
+    (forward output, input gradients, weight and BatchNorm parameter gradients): U-Net 0, U-Net 7, the stem, every node next to a 4 GB
+    boundary and every 6th node in between (models/cu_net.py:11-17,43-48,115-144; cu-net.py:182)."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=68, layer_num=8, order=1, loss_num=8)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=91)
+    x, _ = O.synthetic_batch(24, 68, 256, seed=92)
+    _check_all_nodes(cfg, st, x, bf16=2, wgrad3_all=True, check_forward=True, node_filter=_deep_plan_filter(8, 6))
+
+
+def test_every_node_bench_batch_cu_net16_binary_weights():
+    """BASELINE config 5's plan at the bench batch -- CU-Net-16, K = 16, N = 24, fp32, with the weights QuanOp(bits_w = 1).quantization()
+    leaves in the arena (utils/quantize.py:125-149; the step bench.py times runs exactly these kernels on exactly such weights): 17
+    buckets, a 15 GB workspace.  The quantised weights are read back and the same node-by-node autograd check runs on them: U-Net 0,
+    U-Net 15, the stem, 4 GB-boundary nodes and every 12th node in between."""
+    from cu_net_amd.quant import QuanOp
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=16, order=1, loss_num=16)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=93)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    QuanOp(net, bits_w=1, bits_i=8, bits_g=8).quantization()
+    torch.cuda.synchronize()
+    stq = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    changed = sum(1 for k in st if k.endswith('conv2.weight') and not torch.equal(st[k], stq[k]))
+    assert changed >= 9 * 16, 'quantization() left the 3x3 weights untouched'
+    del net
+    torch.cuda.empty_cache()
+    x, _ = O.synthetic_batch(24, 16, 256, seed=94)
+    _check_all_nodes(cfg, stq, x, wgrad3_all=True, check_forward=True, node_filter=_deep_plan_filter(16, 12))
