@@ -96,8 +96,9 @@ def host_cpu():
 
 def cpu_baseline(layers, class_num, steps):
     """CPU oracle (kind 'port': restatement of the reference, bit-exact to it on the golden vectors) timed on this host:
-    CU-Net-L order 1, bs=4, 256x256 (BASELINE.json configs[0]), full train step -- with torch.set_num_threads(n) for
-    n = the host's physical cores, 32 and 8 (comparable with SURVEY 8d's 8-vCPU probe); `value` / `cores` = the fastest of them."""
+    CU-Net-L order 1, bs=4, 256x256 (BASELINE.json configs[0]), full train step.  A short sample (1 warm-up + 3 timed steps) at
+    torch.set_num_threads(n) for n = the host's physical cores, 32 and 8 finds the fastest thread count; BASELINE.md section 3's
+    protocol -- 5 warm-up steps, `steps` (default 20) timed steps, MEDIAN -- then runs at that count: `value` / `cores`."""
     from oracle import cunet_ref as O
     model, phys = host_cpu()
     usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -105,32 +106,30 @@ def cpu_baseline(layers, class_num, steps):
     x, t = O.synthetic_batch(4, class_num, 256, seed=0)
     saved = torch.get_num_threads()
 
-    def run(n):
+    def run(n, warm, timed):
         torch.set_num_threads(n)
         st = O.init_state(spec, seed=2)
         opt = {}
-        O.train_step(spec, st, x, t, opt)            # warm-up (first step is several times slower)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(warm):                        # (the first step is several times slower)
             O.train_step(spec, st, x, t, opt)
-        return round(4 * steps / (time.perf_counter() - t0), 3)
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            O.train_step(spec, st, x, t, opt)
+            ts.append(time.perf_counter() - t0)
+        return round(4.0 / statistics.median(ts), 3)
     try:
-        n_main = max(1, min(phys, usable))
-        v_main = run(n_main)
-        v8 = run(min(8, usable)) if n_main != min(8, usable) else v_main
-        n32 = min(32, usable)
-        v32 = run(n32) if n32 not in (n_main, min(8, usable)) else (v_main if n32 == n_main else v8)
+        counts = sorted({max(1, min(phys, usable)), min(32, usable), min(8, usable)}, reverse=True)
+        short = {n: run(n, 1, 3) for n in counts}
+        best_n = max(short, key=lambda n: short[n])
+        value = run(best_n, 5, steps)
     finally:
         torch.set_num_threads(saved)
-    # (at bs = 4 torch's CPU kernels do not scale to a whole two-socket host: `value` / `cores` is the FASTEST thread count tried -- the
-    # baseline a user of the reference would actually get on this host; the all-cores figure SURVEY 8d also asks for is next to it)
-    best = max((v_main, n_main), (v32, n32), (v8, min(8, usable)))
-    return {'value': best[0], 'unit': 'images/sec', 'cores': best[1], 'kind': 'port',
-            'cpu_model': model, 'physical_cores': phys, 'logical_cpus_usable': usable,
-            'at_all_physical_cores': {'value': v_main, 'cores': n_main},
-            'at_8_threads': {'value': v8, 'cores': min(8, usable)}, 'at_32_threads': {'value': v32, 'cores': n32},
-            'sample': f'CU-Net-{layers} order 1 K={class_num}, bs=4, 256x256 fp32, {steps} full train steps '
-                      f'(fwd+MSE+bwd+RMSprop) after 1 warm-up at each thread count, torch CPU {torch.__version__}'}
+    return {'value': value, 'unit': 'images/sec', 'cores': best_n, 'kind': 'port',
+            'protocol': f'5 warm-up + {steps} timed steps, median (BASELINE.md section 3)',
+            'cpu_model': model, 'physical_cores': phys,
+            'short_samples': {str(n): v for n, v in short.items()},      # threads -> img/s, 1 warm-up + 3 timed steps, median
+            'sample': f'CU-Net-{layers} o1 K={class_num} bs=4 256x256 fp32 train step (fwd+MSE+bwd+RMSprop), oracle/cunet_ref.py, torch CPU {torch.__version__}'}
 
 
 def load_mfma_busy(cls, workload_key):
@@ -147,7 +146,7 @@ def load_mfma_busy(cls, workload_key):
             continue
         ent = tj.get('classes', {}).get(cls)
         if ent:
-            return ent, f'{os.path.basename(path)} (separate rocprofv3 --pmc pass at commit {tj.get("commit", "?")}, side stream off; not this run)'
+            return ent, f'{os.path.basename(path)}@{tj.get("commit", "?")}'
     return None, None
 
 
@@ -165,8 +164,7 @@ def load_traffic(cls, workload_key):
             continue
         ent = tj.get('classes', {}).get(cls)
         if ent:
-            return ent['hbm_bytes_per_launch'], (f'{os.path.basename(path)} (FETCH_SIZE x2 + WRITE_SIZE per launch; '
-                                                 f'separate rocprofv3 --pmc passes at commit {tj.get("commit", "r01")}, not this run)')
+            return ent['hbm_bytes_per_launch'], f'{os.path.basename(path)}@{tj.get("commit", "r01")}'
     return None, None
 
 
@@ -246,8 +244,7 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
     side_top = max(prof_side.items(), key=lambda kv: kv[1][1])
     side_note = None
     if not serial and not force_class and side_top[1][1] > on_path[dominant][1]:
-        side_note = {'kernel': side_top[0], 'launches': side_top[1][0], 'sum_ms_in_profiled_step': round(side_top[1][1], 3),
-                     'note': 'side-stream class with the largest summed HIP-event time of the profiled step (overlapped, low priority)'}
+        side_note = {'kernel': side_top[0], 'launches': side_top[1][0], 'sum_ms_in_profiled_step': round(side_top[1][1], 3)}
     if rank == 0 and have_classes and not serial:
         tot = sum(v[1] for v in prof_all.values())
         lines = [f'per-class profile of one warm-up step, CU-Net-{L} K={K} {mode} bits_w={bits_w} (sum of kernel times {tot:.3f} ms):']
@@ -324,8 +321,7 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
                 roof['achieved_TFLOPs'] = round(fl / (ms * 1e-3) / 1e12, 2)
                 roof['arithmetic_intensity_flop_per_byte'] = round(ai, 1)
         if on_split:
-            roof['matrix_pipe'] = ('bf16 MFMA, 6 products per fp32 product (planner option f32_split): ceiling %.1f TFLOP/s of fp32-equivalent work, '
-                                   'ridge %.0f flop/B' % (peak_mfma, ridge))
+            roof['matrix_pipe'] = 'bf16 MFMA x6 (f32_split): ceiling %.1f TFLOP/s, ridge %.0f flop/B' % (peak_mfma, ridge)
             if fl > 0:
                 roof['frac_of_f32_mfma_peak'] = round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)      # (the denominator of rounds 1-3)
         wkey = f'{L},{K},{bs},{"f32" if not bf16 else mode}'
@@ -360,20 +356,27 @@ def measure(dev, pg, rank, world, L, K, bs, steps, warmup, mode='fp32', bits_w=0
 
 
 F32_SPLIT = 1      # planner option f32_split as this process has it (main() follows --planner-opt and the fp32-pipe `also` line)
-SPLIT_NOTE = ('fp32 operands and fp32 accumulation on the bf16 matrix pipe: every operand value cut into three bf16 pieces (8 + 8 + 8 significand '
-              'bits, exact), six v_mfma_f32_32x32x16_bf16 products per pair (planner option f32_split=1, the default); error against fp64 '
-              'equal to the fp32 MFMA path (profiles/r04_split_bf16_probe.txt, tests/test_gpu_exact.py::test_backward_error_vs_fp64_tracks_torch_fp32); '
-              'all tensors in HBM fp32; `also` carries the same workload on the fp32 matrix pipe')
+# (what the fields of the line mean -- the split contraction, `roofline.alone`, `traffic` / `mfma_busy` and their `*_source` tags
+# "<file under profiles/>@<commit>", `largest_side_stream_class`, the `also` entries -- is written down once; the line
+# itself stays under ~6 KB so that the driver's record of it is complete)
+SPLIT_NOTE = 'split-bf16: fp32 operands cut into 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (f32_split=1; DESIGN.md 4a)'
 
 
 def workload_name(L, K, bs, mode, bits_w, forward_only, world, popcount=False):
-    return (f'CU-Net layer_num={L} order=1 loss_num={L}, bs={bs}/GPU, 256x256, {K} landmarks, '
-            + (f'QuanOp bits_w={bits_w} bits_g=8 (quantise -> step -> restore -> grad rewrite), ' if bits_w > 0 else '')
-            + ('AND-popcount forward convs, ' if popcount else '')
-            + (('bf16-storage' if mode != 'fp32' else 'fp32') + ' eval-mode forward only' if forward_only else
-               {'fp32': 'fp32', 'bf16': 'bf16-activation', 'bf16_grads': 'bf16 activation + gradient tensors'}[mode]
-               + ' train step (fwd + MSE + bwd + RMSprop')
-            + ('' if forward_only else (' + RCCL bucketed grad all-reduce)' if world > 1 else ')')))
+    return (f'CU-Net L={L} order=1 loss_num={L} bs={bs}/GPU 256x256 K={K} '
+            + (f'QuanOp bits_w={bits_w} ' if bits_w > 0 else '')
+            + ('AND-popcount fwd ' if popcount else '')
+            + (('bf16-storage' if mode != 'fp32' else 'fp32') + ' eval forward' if forward_only else
+               {'fp32': 'fp32', 'bf16': 'bf16-act', 'bf16_grads': 'bf16 act+grad tensors'}[mode]
+               + ' train step (fwd+MSE+bwd+RMSprop' + ('+RCCL grad all-reduce)' if world > 1 else ')')))
+
+
+def compact_roofline(roof):
+    """The `also` entries carry the contract's roofline fields only (the headline entry keeps the detail)."""
+    if not roof:
+        return roof
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us', 'mfma_busy')
+    return {k: roof[k] for k in keep if k in roof}
 
 
 def main():
@@ -384,7 +387,7 @@ def main():
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--class-num', type=int, default=68)
     ap.add_argument('--bs', type=int, default=24, help='per-GPU batch')
-    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-steps', type=int, default=20, help='timed steps of the CPU baseline at its best thread count (5 warm-up steps in front)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the extra CU-Net-8 bf16 / CU-Net-16 binary-weight lines')
     ap.add_argument('--also-steps', type=int, default=20)
@@ -477,9 +480,7 @@ def main():
                         force_class=r['roofline']['kernel'])
             ar = a['roofline']
             alone = {'avg_launch_us': ar['avg_launch_us'], 'achieved': ar['achieved'], 'frac': ar['frac'], 'launches': ar['launches'],
-                     'ms_per_step_serial': round(a['ms_per_step_median'], 3),
-                     'note': 'same kernels with the weight-gradient side stream off: every kernel alone on the GPU; roofline.achieved above '
-                             'is measured in the overlapped step, where this class shares the CUs with the data-gradient stream'}
+                     'ms_per_step_serial': round(a['ms_per_step_median'], 3)}
         except Exception as ex:
             alone = {'error': repr(ex)}
     if rank == 0:
@@ -496,19 +497,17 @@ def main():
             'ms_per_step_median': round(r['ms_per_step_median'], 3),
             'value_at_median': round(bs * world / r['ms_per_step_median'] * 1e3, 2),
             'ranks_seen_by_rccl': ranks_seen,
-            'backend': 'rccl' if backend == 'nccl' else 'gloo (host-staged; de-risking run, not a measurement)',
-            'library': cu_net_amd._lib.lib().cunet_version().decode(),
+            'backend': 'rccl' if backend == 'nccl' else 'gloo (host-staged: not a measurement)',
             'library_path': os.path.relpath(cu_net_amd._lib.LIB_PATH, ROOT),
             'roofline': r['roofline'],
             'final_loss': r['final_loss'],
         }
         if mode == 'fp32':
-            out['contraction'] = SPLIT_NOTE if split else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32), planner option f32_split=0'
-            out['config']['contraction'] = 'split-bf16, 6 products, fp32 accumulate (f32_split=1)' if split else 'fp32 MFMA (f32_split=0)'
+            out['config']['contraction'] = SPLIT_NOTE if split else 'fp32 MFMA (f32_split=0)'
         if not args.forward_only:
             # (FusedTrainer.step: the MSE and its gradient are computed in the heads' epilogues from the staged target, so the timed step never
             # converts the heat maps to NCHW -- they stay NHWC in the workspace; tr.last_outputs() makes the NCHW copies on request)
-            out['config']['heat_maps'] = 'NHWC in the workspace; loss fused into the head epilogues; no NCHW copy inside the timed step'
+            out['config']['heat_maps'] = 'NHWC in the workspace, loss fused into the head epilogues'
         for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
             if k in r:
                 out[k] = r[k]
@@ -528,7 +527,7 @@ def main():
             extra.append((2, 68, 'fp32', 0, False, False, 0))
         for spec in extra:
             (l2, k2, m2, bw, pc, fwd), sp2 = spec[:6], (spec[6] if len(spec) > 6 else split)
-            name2 = workload_name(l2, k2, bs, m2, bw, fwd, world, pc) + ('' if sp2 == split else ' -- planner option f32_split=0: fp32 matrix pipe')
+            name2 = workload_name(l2, k2, bs, m2, bw, fwd, world, pc) + ('' if sp2 == split else ' [f32_split=0: fp32 MFMA]')
             try:
                 if sp2 != split:
                     cu_net_amd._lib.set_planner_option('f32_split', sp2)
@@ -539,10 +538,10 @@ def main():
                     if sp2 != split:
                         cu_net_amd._lib.set_planner_option('f32_split', split)
                         F32_SPLIT = split
-                ent = {'workload': name2, 'value': round(e['value'], 2), 'unit': 'images/sec', 'n_gpus': world,
-                       'steps': args.also_steps, 'ms_per_step': round(e['ms_per_step'], 3), 'ms_per_step_median': round(e['ms_per_step_median'], 3),
-                       'dtype': 'bf16' if m2 != 'fp32' else 'f32', 'roofline': e['roofline'], 'final_loss': e['final_loss']}
-                for k in ('step_tflops', 'step_frac_of_f32_mfma_peak', 'step_frac_of_bf16_mfma_peak', 'step_algorithmic_GBs', 'step_frac_of_hbm_peak'):
+                ent = {'workload': name2, 'value': round(e['value'], 2), 'unit': 'images/sec', 'steps': args.also_steps,
+                       'ms_per_step': round(e['ms_per_step'], 3), 'dtype': 'bf16' if m2 != 'fp32' else 'f32',
+                       'roofline': compact_roofline(e['roofline']), 'final_loss': round(e['final_loss'], 6)}
+                for k in ('step_tflops', 'step_frac_of_hbm_peak'):
                     if k in e:
                         ent[k] = e[k]
                 also.append(ent)

@@ -1456,8 +1456,12 @@ __global__ __launch_bounds__(DRS_MAX_WAVES * 64, 2) void dgrad1x1_rows_split2_ke
         // Everything this wave has requested has landed -- its DMA pieces of the next tiles, this tile's x -- except the previous tile's
         // dz stores (the youngest four entries of the in-order queue), which finish under this tile.
         const unsigned long long t0 = now();
-        if (active && k > 0) drs_wait<4>(xq[0], xq[1], xq[2], xq[3]);
-        else drs_wait<0>(xq[0], xq[1], xq[2], xq[3]);
+        // (round 6: ONE register-tied wait.  With a second arm -- `else drs_wait<0>(xq ...)` -- hipcc merged the two arms' register
+        // assignments with v_mov copies of xq placed IN FRONT of that arm's s_waitcnt: harmless only because the arm was taken when nothing
+        // was in flight (k == 0) or by idle waves; tests/test_kernel_resources.py reads the ISA for exactly this.  k == 0: the requests
+        // were waited for in front of the loop.  Idle waves never read xq: an untied wait for their DMA pieces.)
+        if (active) { if (k > 0) drs_wait<4>(xq[0], xq[1], xq[2], xq[3]); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t1 = now();
         __syncthreads();                               // everyone's pieces have; planes k & 1 are complete; ring slot k % 3 (cut one tile ago) is free
         const unsigned long long t2 = now();

@@ -1247,6 +1247,9 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)P.n_params * 4, s));
     h->stem_fused_now = P.opts.stem_fuse_dz && E.xmode != 2 && P.nodes.size() >= 2 && P.nodes[0].type == N_STEM_CONV &&
                         P.nodes[1].type == N_STEM_BNPOOL && wg3_active(P, P.nodes[0], E.xmode) && (P.tensors[P.nodes[0].out].H & 1) == 0;
+    // (every error / abort return below leaves the pass incomplete: cunet_debug_materialise must not run on reductions that were never
+    // finished -- the guard clears the flag unless the pass reaches its end)
+    struct FusedGuard { cunet_plan* p; bool keep = false; ~FusedGuard() { if (!keep) p->stem_fused_now = false; } } fused_guard{h};
     // The heads' backward depends on nothing but the loss gradient: all of it (data and weight gradient) goes to the side stream
     // up front, last U-Net first (the order the caller's stream will want the results in), one hand-over for all of them; the
     // caller's stream waits for head k's completion where head k's turn would have been.
@@ -1388,6 +1391,7 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     HIPCHK(launch_running_update(reinterpret_cast<const RunStatEntry*>(h->ws + P.off_runstat_tab), P.n_runstat,
                                  E.zero, h->buffers, h->counters, 1, s));
     h->fwd_training_done = 0;
+    fused_guard.keep = true;
     return CUNET_OK;
 }
 
@@ -1499,6 +1503,8 @@ int cunet_ternary_conv_ex(const float* x, const float* scale, const float* shift
                           int variant, void* stream) {
     if (!x || !scale || !shift || !wpos || !wneg || !planes || !y || n < 1 || hh < 1 || w < 1) return fail(CUNET_ERR_INVALID, "bad argument");
     if (c > 128 || bits_i > 8 || bits_i < 2) return fail(CUNET_ERR_INVALID, "ternary conv on bit-plane records: C <= 128, 2 <= bits_i <= 8");
+    if (o < 1 || c < 1 || (taps != 1 && taps != 9)) return fail(CUNET_ERR_INVALID, "ternary conv: O >= 1, C >= 1, taps 1 or 9");
+    if ((uintptr_t)y & 15) return fail(CUNET_ERR_INVALID, "ternary conv: y must be 16-byte aligned (the pixel kernel stores 16-byte pieces)");
     TernArgs a{};
     a.x = x; a.scale = scale; a.shift = shift; a.wpos = wpos; a.wneg = wneg; a.y = y;
     a.M = n * hh * w; a.H = hh; a.W = w; a.C = c; a.O = o; a.Opad = round_up(o, 64); a.taps = taps; a.bits_i = bits_i;
@@ -1530,6 +1536,7 @@ int cunet_debug_materialise(cunet_plan_t* h, void* stream) {
     a.red = E.zero + n.red;
     a.xbf16 = 0;
     HIPCHK(launch_stem_bwd(a, 3, nullptr, nullptr, h->num_cus, s));      // (3: the dz pass alone -- dgamma / dbeta are in the arena already)
+    h->stem_fused_now = false;      // once: the tensor exists now (a later debug_poke of it must not be overwritten by a second materialise)
     return CUNET_OK;
 }
 

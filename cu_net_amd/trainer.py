@@ -149,14 +149,17 @@ def _inverse_crop_transforms(center: torch.Tensor, scale: torch.Tensor, rot: tor
     to_centre = np.array([[1.0, 0.0, -half], [0.0, 1.0, -half], [0.0, 0.0, 1.0]])
     back = np.array([[1.0, 0.0, half], [0.0, 1.0, half], [0.0, 0.0, 1.0]])
     for i in range(c.shape[0]):
-        h = size * s[i]                                    # float32
-        zoom = float(res) / h                              # float32
-        t = np.array([[zoom, 0.0, res * (-float(c[i, 0]) / h + .5)],
-                      [0.0, zoom, res * (-float(c[i, 1]) / h + .5)],
+        # (every float32 step spelled out: under NumPy >= 2 (NEP 50) a python scalar next to a float32 0-d array stays float32 -- what the
+        # G8 / G8r fixtures and the device path of the rot == 0 case pin; NumPy 1.x would promote the same expressions to float64)
+        f32 = np.float32
+        h = f32(size) * s[i]
+        zoom = f32(res) / h
+        t = np.array([[zoom, 0.0, f32(res) * (-c[i, 0] / h + f32(.5))],
+                      [0.0, zoom, f32(res) * (-c[i, 1] / h + f32(.5))],
                       [0.0, 0.0, 1.0]], dtype=np.float64)
         if r[i] != 0:
-            rad = -r[i] * np.pi / 180                      # float32 (to match the direction of the crop's rotation, :164)
-            sn, cs = np.sin(rad), np.cos(rad)              # float32
+            rad = -r[i] * f32(np.pi) / f32(180)            # (to match the direction of the crop's rotation, :164)
+            sn, cs = np.sin(rad), np.cos(rad)              # float32 in, float32 out
             turn = np.array([[cs, -sn, 0.0], [sn, cs, 0.0], [0.0, 0.0, 1.0]], dtype=np.float64)
             t = np.dot(back, np.dot(turn, np.dot(to_centre, t)))          # rotate about the centre of the crop (:171-177)
         out[i] = np.linalg.inv(t)[:2].reshape(6)

@@ -207,7 +207,8 @@ def test_bench_two_ranks_end_to_end():
     assert out['value'] > 0 and abs(out['value'] - 48 * 3 / (out['ms_per_step'] * 3e-3)) <= 1e-2 * out['value']
     also = out['also']
     assert len(also) == 2 and all('error' not in e for e in also), also
-    assert all('layer_num=8' in e['workload'] and '16 landmarks' in e['workload'] and e['n_gpus'] == 2 and e['value'] > 0 for e in also)
+    assert all('L=8' in e['workload'] and 'K=16' in e['workload'] and 'RCCL grad all-reduce' in e['workload'] and e['value'] > 0 for e in also)
+    assert len(lines[0]) < 6144, len(lines[0])            # (the driver keeps a bounded tail of stdout: the whole line has to fit)
     assert 'cpu_baseline' not in out
     for key in ('roofline', 'final_loss', 'library_path'):
         assert key in out

@@ -139,7 +139,7 @@ def test_ternary_popcount_conv_is_bit_exact(shape):
 
 @pytest.mark.parametrize('binary', [False, True])
 @pytest.mark.parametrize('shape', [(2, 128, 16, 16, 32, 3), (1, 128, 8, 8, 16, 1), (3, 72, 5, 7, 68, 1), (1, 128, 64, 64, 32, 3),
-                                   (24, 128, 4, 4, 32, 3), (2, 32, 32, 32, 8, 3), (1, 100, 3, 3, 20, 3)])
+                                   (24, 128, 4, 4, 32, 3), (2, 32, 32, 32, 8, 3), (1, 100, 3, 3, 20, 3), (2, 30, 6, 6, 12, 3)])
 def test_ternary_popcount_on_bit_plane_records_is_bit_exact(shape, binary):
     """The two-kernel AND-popcount path of the network's forward (bit-plane records once per tensor, then the counting kernel;
     utils/quantize.py:125-149 weights x QuanInput activations :47-63), both counting kernels: `variant` 1 = lane per pixel with the weight
@@ -148,7 +148,8 @@ def test_ternary_popcount_on_bit_plane_records_is_bit_exact(shape, binary):
     consumer BatchNorms get -- exact integers / 128, so the fp64 sums must EQUAL the sums of the oracle's output.  Shapes: the network's own
     (128 -> 32 3x3, 128 -> 16 heads), pixel counts that are not multiples of 64 (ragged last group), channel counts that are not
     multiples of 64 or 8 (partial mask words, partial chunks of output channels), one-group inputs, 3x3 images (every tap of every pixel
-    reads the zero record somewhere); truly ternary weights (zeros: the Z term) and binary ones (no zero: the scalar branch skips it)."""
+    reads the zero record somewhere), a channel count that is not a multiple of 4 (C = 30: the lane-per-pixel plane kernel reads 16-byte pieces, so
+    `variant` 1 falls back to the ballot plane kernel for the records -- round-5 advice); truly ternary weights (zeros: the Z term) and binary ones (no zero: the scalar branch skips it)."""
     from cu_net_amd.quant import ternary_conv_planes
     n, c, h, w, o, k = shape
     g = torch.Generator().manual_seed(c + o + k + (1000 if binary else 0))

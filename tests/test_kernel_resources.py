@@ -75,3 +75,58 @@ def test_workhorse_kernels_do_not_spill(fname, tmp_path):
         for k, v in hits.items():
             assert v.get('VGPRs Spill', 0) <= max_spill and v.get('SGPRs Spill', 0) == 0, (k, v)
             assert v['VGPRs'] <= budget, (k, v, budget)
+
+
+def _vgprs(text):
+    """Indices of the VGPRs an operand string names: v7, v[22:25] ..."""
+    out = set()
+    for m in re.finditer(r'\bv\[(\d+):(\d+)\]', text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r'\bv(\d+)\b', text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def test_row_tile_data_gradient_keeps_its_uncounted_requests_untouched(tmp_path):
+    """dgrad1x1_rows_split2_kernel (the dominant kernel of the bench line) requests its x pieces by inline asm -- loads the compiler's
+    vmcnt bookkeeping does not see -- and waits for them at the top of the NEXT iteration with a hand-counted `s_waitcnt vmcnt(4)`
+    (everything but the previous tile's four dz stores).  That is only correct while (a) the four requested register quads are neither
+    read, written nor copied between the request and the wait, across the loop's back edge, (b) exactly four global stores follow the
+    last request of an iteration, and (c) nothing of the kernel lives in scratch.  A compiler or flag change that breaks any of them would
+    produce stale ReLU masks / BatchNorm sums silently (round-5 advice): this reads the gfx950 ISA and fails instead."""
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not on PATH')
+    asm = tmp_path / 'conv.s'
+    flags = [f for f in FLAGS if not f.startswith('-Rpass') and f != '-c']
+    r = subprocess.run(['hipcc'] + flags + ['-S', os.path.join(SRC, 'conv_kernels.hip'), '-o', str(asm)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = asm.read_text().splitlines()
+    start = next(i for i, l in enumerate(lines) if re.match(r'_ZN5cunet27dgrad1x1_rows_split2_kernel\w*:', l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
+    body = [l.split(';')[0].strip() for l in lines[start:end]]
+    assert not any(l.startswith('scratch_') for l in body), 'the kernel spills to scratch'
+    waits = [i for i, l in enumerate(body) if l == 's_waitcnt vmcnt(4)']
+    assert len(waits) == 1, waits
+    w = waits[0]
+    # the tile loop: the innermost label in front of the wait that something behind the wait branches back to
+    labels = {l[:-1]: i for i, l in enumerate(body) if re.match(r'\.LBB\d+_\d+:$', l)}
+    back = [(labels[m.group(1)], i) for i, l in enumerate(body) for m in [re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)$', l)]
+            if m and m.group(1) in labels and labels[m.group(1)] < w < i]
+    assert back, 'no loop around the counted wait'
+    top, bottom = max(back, key=lambda tb: tb[0])
+    loop = body[top:bottom + 1]
+    loads = [(i, l) for i, l in enumerate(loop) if l.startswith('global_load_dwordx4')]
+    stores = [i for i, l in enumerate(loop) if l.startswith('global_store_dwordx4')]
+    assert len(loads) == 4 and len(stores) == 4, (len(loads), len(stores))
+    assert min(stores) > max(i for i, _ in loads), 'a dz store in front of an x request: vmcnt(4) would no longer cover the requests'
+    assert not any(l.startswith(('global_load', 'global_atomic', 'buffer_load', 'buffer_store')) and not l.startswith('global_load_dwordx4')
+                   for l in loop if not l.startswith('global_load_lds')), 'another vector-memory operation inside the tile loop changes the count'
+    wrel = w - top
+    for i, l in loads:
+        dst = _vgprs(l.split(',')[0])
+        assert len(dst) == 4, l
+        window = loop[i + 1:] + loop[:wrel]          # request -> back edge -> the wait
+        for k in window:
+            ops = k.split(None, 1)
+            if len(ops) == 2 and dst & _vgprs(ops[1]):
+                raise AssertionError(f'{k!r} touches the destination of the in-flight request {l!r}')

@@ -47,6 +47,38 @@ def test_bucket_layout_is_bucket_major():
     assert order == list(range(L - 1, -1, -1)) + [L]
 
 
+def _free_port():
+    """A port the kernel just handed out (bound to port 0 and released): no collision between concurrent test sessions."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _run_ranks(target, world, timeout):
+    """Spawn `world` ranks of `target(rank, world, port, queue)`, collect one result per rank, and ALWAYS terminate and join the children:
+    a rank that dies hard leaves the others in init_process_group / all_reduce for ever otherwise (round-5 advice)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=timeout))
+    finally:
+        for p in procs:
+            p.join(5 if len(res) < len(procs) else 30)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+    return res
+
+
+
 def _worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -88,15 +120,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_bucket_allreduce_gloo():
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(30)
+    res = _run_ranks(_worker, 2, 120)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
 
 
@@ -160,15 +184,7 @@ def _dp_worker(rank, world, port, q):
 
 
 def test_two_rank_step_equals_dataparallel_semantics():
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(30)
+    res = _run_ranks(_dp_worker, 2, 300)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
 
 
@@ -229,13 +245,5 @@ def _worker8(rank, world, port, q):
 
 def test_eight_rank_config4_bucket_table_gloo():
     """The first time 8 ranks meet must not be the first hardware run (cu-net.py:59 on the 8 GPUs of a node)."""
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(30)
+    res = _run_ranks(_worker8, 8, 300)
     assert sorted(res) == [(r, 'ok') for r in range(8)], res
