@@ -510,8 +510,13 @@ __global__ __launch_bounds__(b16_max_waves(NT) * 64) void conv_bf16_pair_kernel(
 // (= d beta, d gamma) in fp64.  Requirements: K (= Cout) and every segment multiples of 32, M of 32, W of 4.
 struct Grp16 { const u16* ptr; int ld; int ups; };
 
-template <int TAPS, int NT, int NCK = 0>       // NCK: 1x1 only, K / 32 as a compile-time constant (1 ... 4)
+// FZ (round 6, 1x1 over K = 128 only): the A operand is assembled on the load from the ONE consumer's dz slice and the tensor itself
+// (ConvArgs::fz_*: the BatchNorm-backward gather of a single-consumer tensor folded into the data gradient that reads it) -- the
+// coefficients come from a table built in the prologue, the result is rounded to bf16 exactly where grad_gather_rows_kernel<1, 0, 2, 8>
+// would have stored it, and the blocks of column slice 0 write it to the gradient tensor as they go.
+template <int TAPS, int NT, int NCK = 0, bool FZ = false>       // NCK: 1x1 only, K / 32 as a compile-time constant (1 ... 4)
 __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bidx, const int bidy, const int gdimx) {
+    static_assert(!FZ || (TAPS == 1 && NCK == 4), "the fused gather exists for the 1x1 data gradient over K = 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NB = NT * 32;
     const int kq8 = p.Kpad >> 3;
@@ -524,7 +529,8 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
     Grp16* grp = reinterpret_cast<Grp16*>(is + p.Ccat);               // [Ccat / 4]
     double* redbuf = reinterpret_cast<double*>(grp + (p.Ccat >> 2));  // [NB][2]
     constexpr int TP = NB + 8;                                        // element pitch of the epilogue tiles (16-byte aligned rows)
-    u16* tileT = reinterpret_cast<u16*>(redbuf + NB * 2);             // [waves][32][TP]
+    float* fzE = reinterpret_cast<float*>(redbuf + NB * 2);           // FZ: [3][128] coefficient tables E, D, A
+    u16* tileT = reinterpret_cast<u16*>(fzE + (FZ ? 3 * 128 : 0));    // [waves][32][TP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -588,6 +594,26 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
         }
     }
     for (int i = tid; i < NB * 2; i += blockDim.x) redbuf[i] = 0.0;
+    if constexpr (FZ) {      // the gather's coefficients, computed as grad_gather_rows_kernel<1, 0> computes them (one plain consumer)
+        const double invM = 1.0 / (double)p.M;
+        for (int c = tid; c < 128; c += blockDim.x) {
+            const double mean = p.fz_stats[c] / p.fz_count;
+            double var = p.fz_stats[128 + c] / p.fz_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+            const int cc = p.fz_choff + c;
+            const double scale = (double)p.fz_gamma[cc] * istd;
+            const double c1 = p.fz_red[cc] * invM;
+            const double c2 = p.fz_red[p.fz_lddz + cc] * invM;
+            const double D = scale * c2 * istd;
+            double Es = 0.0, Ds = 0.0;
+            Es += 1.0 * (D * mean - scale * c1);
+            Ds += 1.0 * D;
+            fzE[c] = (float)Es;
+            fzE[128 + c] = (float)Ds;
+            fzE[256 + c] = (float)scale;
+        }
+    }
     __syncthreads();
 
     const int HW = p.H * p.W;
@@ -649,6 +675,7 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
     static_assert(!FULLA || (NCK >= 1 && NCK <= 4), "1x1: K / 32 in 1 ... 4");
     constexpr int NA = FULLA ? 2 * NCK : 1;
     uint4 abuf[NA];
+    uint4 zbuf[FZ ? NA : 1];                          // FZ: the tensor's own pieces next to the consumer's dz pieces in abuf
     // the epilogue's x pieces (see below): this lane's piece column is the same for every tile
     constexpr int PPR = NB / 8;                       // pieces per tile row
     constexpr int NPJ = (32 * PPR) / 64;              // pieces per lane (4 for NB = 64, 2 for NB = 32)
@@ -688,13 +715,52 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
     // is the same on the loop's entry and back edge, so the waits are exact (vmcnt is one in-order counter of loads and stores).
     auto request_tile = [&](int t) {
         set_tile(t);
-        const u16* rp = dY + (size_t)m * p.lda + 8 * hi;
+        const u16* rp = FZ ? reinterpret_cast<const u16*>(p.fz_dz) + (size_t)m * p.fz_lddz + p.fz_choff + 8 * hi : dY + (size_t)m * p.lda + 8 * hi;
 #pragma unroll
         for (int c = 0; c < (FULLA ? NCK : 0); ++c) {
             abuf[(2 * c) % NA] = ldg16(rp + c * 32);
             abuf[(2 * c + 1) % NA] = ldg16(rp + c * 32 + 16);
         }
+        if constexpr (FZ) {
+            const u16* zp = reinterpret_cast<const u16*>(p.fz_x) + (size_t)m * p.fz_ldx + 8 * hi;
+#pragma unroll
+            for (int c = 0; c < NCK; ++c) {
+                zbuf[2 * c] = ldg16(zp + c * 32);
+                zbuf[2 * c + 1] = ldg16(zp + c * 32 + 16);
+            }
+        }
         request_x(t);
+    };
+    // FZ: pieces -> the gathered gradient, in place: r = fma(A, dz, E - D * x) (+ 0: the gather adds its zero "accumulate" operand),
+    // rounded to bf16 as the gather's store rounds; slice 0 keeps the tensor
+    auto assemble = [&](int t) {
+        if constexpr (FZ) {
+            u16* outp = reinterpret_cast<u16*>(const_cast<float*>(p.a)) + (size_t)(t * 32 + li) * p.lda + 8 * hi;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int k0 = (i >> 1) * 32 + (i & 1) * 16 + 8 * hi;
+                const unsigned dw[4] = {abuf[i].x, abuf[i].y, abuf[i].z, abuf[i].w};
+                const unsigned zw[4] = {zbuf[i].x, zbuf[i].y, zbuf[i].z, zbuf[i].w};
+                unsigned ow[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    float r[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = k0 + 2 * h + e;
+                        const float dzv = e ? bf16_bits_hi(dw[h]) : bf16_bits_lo(dw[h]);
+                        const float xv = e ? bf16_bits_hi(zw[h]) : bf16_bits_lo(zw[h]);
+                        float v = fzE[k] - fzE[128 + k] * xv;
+                        v = fmaf(fzE[256 + k], dzv, v);
+                        v += 0.f;
+                        r[e] = v;
+                    }
+                    ow[h] = (unsigned)f32_to_bf16_rne(r[0]) | ((unsigned)f32_to_bf16_rne(r[1]) << 16);
+                }
+                abuf[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if (by == 0) *reinterpret_cast<uint4*>(outp + (i >> 1) * 32 + (i & 1) * 16) = abuf[i];
+            }
+        }
     };
     const int tstride = gxd * nwaves;
     int tile = bx * nwaves + wave;
@@ -710,6 +776,7 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
         if constexpr (FULLA) {
+            assemble(tile);
 #pragma unroll
             for (int c = 0; c < NCK; ++c) {
                 const uint4* bb = Bs + (size_t)c * 4 * NB;
@@ -834,11 +901,12 @@ __device__ __forceinline__ void dgrad_bf16_body(const ConvArgs& p, const int bid
 }
 
 // waves per block: 16 (128 VGPRs) except the two-channel-tile 1x1 variant, whose whole-tile dY look-ahead needs the 168 of 12 waves
-constexpr int dg16_max_waves(int taps, int nt) { return (taps == 1 && nt == 2) ? 12 : B16_MAX_WAVES; }
+// (FZ, the gather folded into the load: 8 more 16-byte pieces per lane -- one wave per SIMD fewer)
+constexpr int dg16_max_waves(int taps, int nt, bool fz = false) { return fz ? (nt == 2 ? 8 : 12) : ((taps == 1 && nt == 2) ? 12 : B16_MAX_WAVES); }
 
-template <int TAPS, int NT, int NCK = 0>
-__global__ __launch_bounds__(dg16_max_waves(TAPS, NT) * 64) void dgrad_bf16_kernel(const ConvArgs p) {
-    dgrad_bf16_body<TAPS, NT, NCK>(p, blockIdx.x, blockIdx.y, gridDim.x);
+template <int TAPS, int NT, int NCK = 0, bool FZ = false>
+__global__ __launch_bounds__(dg16_max_waves(TAPS, NT, FZ) * 64) void dgrad_bf16_kernel(const ConvArgs p) {
+    dgrad_bf16_body<TAPS, NT, NCK, FZ>(p, blockIdx.x, blockIdx.y, gridDim.x);
 }
 template <int TAPS, int NT, int NCK = 0>
 __global__ __launch_bounds__(dg16_max_waves(TAPS, NT) * 64) void dgrad_bf16_pair_kernel(const ConvPair q) {
@@ -1205,17 +1273,20 @@ static hipError_t launch_dg16_pair_inst(const ConvArgs& a, const ConvArgs& b, di
     }
 }
 
-template <int TAPS, int NT, int NCK = 0>
+template <int TAPS, int NT, int NCK = 0, bool FZ = false>
 static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, size_t smem, hipStream_t s, const ConvArgs* pb = nullptr) {
-    if (pb) return launch_dg16_pair_inst<TAPS, NT, NCK>(a, *pb, grid, threads, smem, s);
+    if (pb) {
+        if constexpr (FZ) return hipErrorNotSupported;
+        else return launch_dg16_pair_inst<TAPS, NT, NCK>(a, *pb, grid, threads, smem, s);
+    }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_kernel<TAPS, NT, NCK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_bf16_kernel<TAPS, NT, NCK, FZ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((dgrad_bf16_kernel<TAPS, NT, NCK>), grid, dim3(threads), smem, s, a);
+    hipLaunchKernelGGL((dgrad_bf16_kernel<TAPS, NT, NCK, FZ>), grid, dim3(threads), smem, s, a);
     return hipGetLastError();
 }
 
@@ -1223,9 +1294,9 @@ static hipError_t launch_dg16_inst(const ConvArgs& a, dim3 grid, int threads, si
 // the shape is outside the kernel's requirements (the caller then uses conv_kernel's XB = 2 variant).
 // LDS of a block: operand + tables (dgrad_bf16_smem) + one epilogue tile of 32 x (32 NT + 8) bf16 per wave, for the largest wave
 // count the block may get at `bpc` blocks per CU.  Returns false when even one block per CU does not fit.
-static bool dgrad_bf16_plan(int NT, int taps, int Kpad, int Ccat, int& bpc, size_t& smem) {
-    const size_t base = dgrad_bf16_smem(NT, taps, Kpad, Ccat);
-    const int maxw = dg16_max_waves(taps, NT);
+static bool dgrad_bf16_plan(int NT, int taps, int Kpad, int Ccat, int& bpc, size_t& smem, bool fz = false) {
+    const size_t base = dgrad_bf16_smem(NT, taps, Kpad, Ccat) + (fz ? 3 * 128 * 4 : 0);
+    const int maxw = dg16_max_waves(taps, NT, fz);
     for (bpc = 3; bpc >= 1; --bpc) {
         const int wmax = maxw / bpc < 4 ? 4 : maxw / bpc;
         smem = base + (size_t)wmax * 32 * (NT * 32 + 8) * 2;
@@ -1255,9 +1326,11 @@ static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, 
     int NT = 0, blocks_per_cu = 1;
     size_t smem = 0;
     float best = 1e30f;
+    const bool fz = a.fz_dz != nullptr;
+    if (fz && (pb || a.taps != 1 || a.Kpad != 128 || a.fz_lddz % 8 || a.fz_choff % 8 || a.fz_ldx % 8)) return hipErrorNotSupported;
     for (int c = ntmax >= 2 ? 2 : 1; c >= 1; --c) {
         int bpc; size_t sm;
-        if (!dgrad_bf16_plan(c, a.taps, a.Kpad, a.Ccat, bpc, sm)) continue;
+        if (!dgrad_bf16_plan(c, a.taps, a.Kpad, a.Ccat, bpc, sm, fz)) continue;
         const int slices = (ncol32 + c - 1) / c;
         const float cost = slices * ((float)c + 0.3f);
         if (cost < best) { best = cost; NT = c; blocks_per_cu = bpc; smem = sm; }
@@ -1266,7 +1339,7 @@ static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, 
     const int gy = (ncol32 + NT - 1) / NT;
     const int max_blocks_x = (blocks_per_cu * num_cus + gy - 1) / gy;
     int waves = (ntiles + max_blocks_x - 1) / max_blocks_x;
-    const int maxw = dg16_max_waves(a.taps, NT);
+    const int maxw = dg16_max_waves(a.taps, NT, fz);
     if (waves > maxw / blocks_per_cu) waves = maxw / blocks_per_cu;
     if (waves < 1) waves = 1;
     int gx = (ntiles + waves - 1) / waves;
@@ -1279,6 +1352,9 @@ static hipError_t launch_dgrad_bf16_impl(const ConvArgs& a, const ConvArgs* pb, 
     dim3 grid1 = grid;
     b.xcd_gx = b.xcd_gy = 0;
     if (gy > 1) { b.xcd_gx = gx; b.xcd_gy = gy; grid1 = dim3(8 * ((gx + 7) / 8) * gy, 1); }
+    if (fz) {      // the single-consumer gather folded into the operand load (ConvArgs::fz_*)
+        return NT == 2 ? launch_dg16_inst<1, 2, 4, true>(b, grid1, threads, smem, s) : launch_dg16_inst<1, 1, 4, true>(b, grid1, threads, smem, s);
+    }
     if (a.taps == 1) {
         switch (a.Kpad / 32) {
 #define CUNET_DG1(C) case C: return NT == 2 ? launch_dg16_inst<1, 2, C>(b, grid1, threads, smem, s, pb) : launch_dg16_inst<1, 1, C>(b, grid1, threads, smem, s, pb);

@@ -101,6 +101,18 @@ struct ConvArgs {
                            // pieces, six products (conv_body's XBG = 6 / 7; the plan's snapshot of planner option f32_split)
     int ring_min_rows;     // 3x3 forward: LDS row ring when the batch has at least this many image rows (the plan's snapshot of
                            // planner option conv3x3_ring_min_rows; 0 = the default 512)
+    // ---- round 6, EP_BWD 1x1 over K = 128 (planner option fuse_z_gather): the A operand is NOT read from `a`.  `a` is the gradient of a tensor
+    //      with ONE plain consumer (the bottleneck output z of a dense layer, read by its 3x3 conv only), and this launch applies that
+    //      consumer's BatchNorm backward on the load -- a[m][k] = fz_A[k] * fz_dz[m][fz_choff + k] + fz_E[k] - fz_D[k] * fz_x[m][k], what
+    //      grad_gather_rows_kernel<1, 0> would have written -- from coefficient tables it derives in its prologue; the column slice 0
+    //      blocks store the operand into `a` as they go (the node's weight gradient and the tests read it afterwards).  fz_dz == null: off.
+    const float* fz_dz;    // the consumer's masked data gradient [M][fz_lddz] (bf16 behind the pointer when xbf16 == 2)
+    const double* fz_red;  // the consumer's reductions [2][fz_lddz]
+    const float* fz_gamma; // the consumer's BatchNorm weight [fz_lddz]
+    const float* fz_x;     // the tensor itself [M][fz_ldx] (bf16 when xbf16 != 0)
+    const double* fz_stats;// its batch statistics [2][K]
+    double fz_count;
+    int fz_lddz, fz_choff, fz_ldx, fz_pad_;
     int dbg;               // timing experiments only (CUNET_CONV_DBG; conv_bf16_kernel: CUNET_B16_DBG = 32 / 64 as below, 2048 no output
                            // stores -- switches inside its chunk loop made the tuning build's kernel 3x slower and were removed):
                            // 1 no stats atomics, 4 no MFMA, 32 no B preload,

@@ -38,6 +38,7 @@ struct cunet_plan {
     int ternpack_dirty = 0;
     float* fused_loss_out = nullptr;  // cunet_loss_mse_fused: the next training forward computes the loss in its head epilogues
     int tern_live = 0;               // cunet_set_popcount_live: the caller vouches that those convs' weights ARE ternary right now
+    int fz_node = -1;                // backward: the node whose data gradient is being launched with its output gradient's gather folded into the operand load (planner option fuse_z_gather)
     bool stem_fused_now = false;     // this backward pass: the stem's weight gradient computes d(loss)/d(conv0 output) itself (planner option stem_fuse_dz)
     // call-order state
     int fwd_training_done = 0;
@@ -181,6 +182,8 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "dgrad3_ring") return &o.dgrad3_ring;
     if (n == "stem_split") return &o.stem_split;
     if (n == "fuse_pool_gather") return &o.fuse_pool_gather;
+    if (n == "fuse_z_gather") return &o.fuse_z_gather;
+    if (n == "stem_wgrad_caller") return &o.stem_wgrad_caller;
     return nullptr;
 }
 
@@ -641,8 +644,32 @@ static ConvArgs dgrad_args(cunet_plan* h, Exec& E, const Node& n, int node_index
     a.split = P.opts.f32_split;
     // fp32 gradient tensors: this launch also computes the node's weight gradient (partial tiles; the bucket's reduce sums them)
     a.wg_part = (E.xmode == 0 && !h->fused_S.empty() && h->fused_S[node_index] > 0) ? E.wsf + n.wg3_part : nullptr;
+    if (h->fz_node == node_index) {      // the one consumer's BatchNorm backward applied on the operand load (see fz_eligible)
+        const Contrib& cb = P.contribs[o.cfirst];
+        const Node& nc = P.nodes[cb.node];
+        int choff = 0;
+        for (int j = 0; j < cb.seg; ++j) choff += P.tensors[nc.segs[j].tensor].C;
+        a.fz_dz = E.wsf + nc.dz; a.fz_red = E.zero + nc.red; a.fz_gamma = h->params + P.bns[nc.bn].gamma;
+        a.fz_lddz = nc.Ccat; a.fz_choff = choff;
+        a.fz_x = E.xact(n.out); a.fz_ldx = o.ld; a.fz_stats = E.stats(n.out); a.fz_count = (double)o.rows();
+    }
     return a;
 }
+
+// May node k's data gradient assemble d(loss)/d(out) itself (ConvArgs::fz_*) instead of reading the tensor a gather launch wrote?  A 1x1
+// conv over 128 output channels whose output has exactly ONE consumer, at the same resolution -- the bottleneck output of a dense layer
+// (models/cu_net.py:43-48: conv1 -> norm2 -> relu -> conv2) -- with bf16 gradient tensors (the kernels that implement it so far).
+static bool fz_eligible(const cunet_plan* h, int k, int xmode) {
+    const Plan& P = h->plan;
+    const Node& n = P.nodes[k];
+    if (!P.opts.fuse_z_gather || xmode != 2 || n.type != N_CONV || n.taps != 1 || n.head >= 0) return false;
+    const TensorInfo& o = P.tensors[n.out];
+    if (o.ccount != 1 || o.C != 128 || o.ld != 128 || P.convs[n.conv].Cout != 128 || o.stats < 0) return false;
+    const Contrib& cb = P.contribs[o.cfirst];
+    const Node& nc = P.nodes[cb.node];
+    return nc.type == N_CONV && nc.dz >= 0 && nc.segs[cb.seg].ups == 0 && nc.segs[cb.seg].tensor == n.out;
+}
+constexpr int CUNET_FZ_FALLBACK = 1;      // bwd_node: the fused launch does not exist for this shape -- nothing launched; gather, then launch plainly
 
 // Is node k's weight gradient computed by its data-gradient launch in the current pass?
 static bool wgrad_is_fused(const cunet_plan* h, int k, int xmode) { return xmode == 0 && !h->fused_S.empty() && h->fused_S[k] > 0; }
@@ -742,12 +769,16 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
                 if (e == hipSuccess) {
                     HIPCHK(prof_end(h, slot_, 2.0 * a.M * a.K * a.Nout * a.taps, 2.0 * (double)a.M * (a.K + 2.0 * a.Nout), s));
                     done = true;
+                } else if (a.fz_dz != nullptr && (e == hipErrorNotSupported || e == hipErrorInvalidValue)) {
+                    prof_cancel(h, slot_);
+                    return CUNET_FZ_FALLBACK;
                 } else if (e != hipErrorInvalidValue) {
                     HIPCHK(e);
                 } else {
                     HIPCHK(prof_end(h, slot_, 0.0, 0.0, s));
                 }
             }
+            if (!done && a.fz_dz != nullptr) return CUNET_FZ_FALLBACK;      // (the fp32 kernels read the gathered tensor)
             if (!done)
                 PROF(c.taps == 9 ? PC_C3D : PC_C1D, 2.0 * a.M * a.K * a.Nout * a.taps, 4.0 * (double)a.M * (a.K + 2.0 * a.Nout),
                      launch_conv(a, c.taps == 9 ? LD_PLAIN3 : LD_PLAIN, EP_BWD, cus, s));
@@ -1297,6 +1328,10 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
     bool any_fused = false;
     for (size_t k = 0; k < P.nodes.size() && !any_fused; ++k) any_fused = wgrad_is_fused(h, (int)k, E.xmode);
     int position = 0;
+    // round 6 (planner option stem_wgrad_caller): the stem's weight gradient -- the last long kernel of a step, 160 us with nothing left to
+    // run beside it -- is launched on the CALLER's stream behind the stem's BatchNorm pass instead of queueing behind the last bucket's
+    // weight gradients and reduce on the side stream (which are still running then), and its reduce follows it there.
+    const bool stem_on_caller = side_on && P.opts.stem_wgrad_caller && !P.nodes.empty() && P.nodes[0].type == N_STEM_CONV && P.nodes[0].wg3_S > 0;
     auto close_bucket = [&](int k_lo, int k_hi) -> int {     // everything that writes bucket `cur_bucket` (nodes [k_lo, k_hi)) has been enqueued
         const bool had_pending = !pending.empty();
         const int rcf = fork_wgrads(h, pending, s);
@@ -1305,9 +1340,11 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             HIPCHK(hipEventRecord(h->bucket_ev, s));
             HIPCHK(hipStreamWaitEvent(h->side, h->bucket_ev, 0));
         }
-        const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket], side_on ? h->side : s);
+        // (the stem's bucket with stem_on_caller: its one weight gradient ran on the caller's stream -- so does its reduce)
+        const bool red_on_side = side_on && !(stem_on_caller && cur_bucket == P.cfg.layer_num);
+        const int rcr = reduce_wgrad3(h, P.wgred_first[cur_bucket], P.wgred_count[cur_bucket], P.wgred_maxnumel[cur_bucket], red_on_side ? h->side : s);
         if (rcr != CUNET_OK) return rcr;
-        if (side_on && any_fused) HIPCHK(hipEventRecord(h->red_ev[position & 1], h->side));
+        if (red_on_side && (any_fused || stem_on_caller)) HIPCHK(hipEventRecord(h->red_ev[position & 1], h->side));
         ++position;
         if (side_on && any_fused && position >= 2) HIPCHK(hipStreamWaitEvent(s, h->red_ev[position & 1], 0));      // (recorded at position - 2)
         return bn_param_grads(h, k_lo, k_hi, cur_bucket, s);      // (on the side stream instead: -0.5 % on the CU-Net-2 step, round 6 -- the side stream is the critical path at the end of a step)
@@ -1345,11 +1382,24 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
         // the skip adapter of a pair (Node::pair on the node in front of it): both adapters' gradients are gathered first, then
         // their data gradients share a launch
         const bool paired = k >= 1 && P.nodes[k - 1].pair && P.nodes[k - 1].bucket == n.bucket;
+        // round 6: the gather of a single-consumer output folded into this node's data gradient (fz_eligible): no gather launch, the data
+        // gradient writes the tensor as it goes, and the node's weight gradient -- which reads it -- is handed over behind that launch
+        const bool fz_try = !paired && k != gathered_early && fz_eligible(h, k, E.xmode);
         for (int q = k; q >= (paired ? k - 1 : k); --q) {
             const Node& nq = P.nodes[q];
+            if (fz_try) break;
             if (P.tensors[nq.out].ccount > 0 && q != gathered_early) {  // d(loss)/d(out): gather from the consumers (heads get theirs from the loss)
                 const int rcg = gather_tensor_grad(h, nq.out, -1, s);
                 if (rcg != CUNET_OK) return rcg;
+            }
+            if (stem_on_caller && q == 0 && nq.type == N_STEM_CONV) {
+                const int rcf = fork_wgrads(h, pending, s);                     // (whatever is still waiting goes to the side stream first)
+                if (rcf != CUNET_OK) return rcf;
+                // its partial tiles go to the region the bucket two positions back used: that bucket's reduce (side stream) must be through
+                if (position >= 2) HIPCHK(hipStreamWaitEvent(s, h->red_ev[position & 1], 0));
+                const int rcw = bwd_node(h, nq, 0, s, s, BWD_WGRAD);
+                if (rcw != CUNET_OK) return rcw;
+                continue;
             }
             if (node_has_wgrad(nq) && !wgrad_is_fused(h, q, E.xmode)) {          // (its d(loss)/d(out) is enqueued: the weight gradient may start once that has run)
                 pending.push_back(q);
@@ -1364,6 +1414,25 @@ int cunet_backward_ex(cunet_plan_t* h, const float* const* grad_heat, void* stre
             int rcp = CUNET_OK;
             launched = bwd_dgrad_pair(h, k - 1, k, s, rcp);
             if (launched < 0) return rcp;
+        }
+        if (fz_try) {
+            h->fz_node = k;
+            int rc = bwd_node(h, n, k, s, s, BWD_MAIN);
+            h->fz_node = -1;
+            if (rc == CUNET_FZ_FALLBACK) {                       // no fused kernel for this shape: the two launches
+                const int rcg = gather_tensor_grad(h, n.out, -1, s);
+                if (rcg != CUNET_OK) return rcg;
+                rc = bwd_node(h, n, k, s, s, BWD_MAIN);
+            }
+            if (rc != CUNET_OK) return rc;
+            launched = 1;
+            if (!wgrad_is_fused(h, k, E.xmode)) {
+                pending.push_back(k);
+                if (pending.size() >= group || k == 0) {
+                    const int rcf = fork_wgrads(h, pending, s);
+                    if (rcf != CUNET_OK) return rcf;
+                }
+            }
         }
         for (int q = k; !launched && q >= (paired ? k - 1 : k); --q) {
             const int rc = bwd_node(h, P.nodes[q], q, s, s, BWD_MAIN);

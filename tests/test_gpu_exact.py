@@ -755,3 +755,57 @@ def test_pool_backward_fused_with_the_gathers_around_it(mode):
     assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
     ga, gb = res[1][1], res[0][1]
     assert float((ga - gb).norm() / gb.norm()) <= (1e-5 if mode == 'fp32' else 2e-2)
+
+
+@pytest.mark.parametrize('mode', ['bf16_grads'])
+def test_single_consumer_gather_folded_into_the_data_gradient(mode):
+    """Round 6, planner option fuse_z_gather (default 0: measured slower): the gradient of a dense layer's bottleneck output z (models/cu_net.py:43-48: read
+    by norm2 -> relu -> conv2 only) is not gathered by its own launch -- conv1's data gradient assembles A * dz + E - D * z on its operand
+    load from coefficient tables it derives itself, rounds it where the gather would have stored it and writes the tensor as it goes (the
+    weight gradient of conv1 and this test read it).  Against the same step with the option off: 9 gather launches per U-Net (+ 1) fewer, every
+    z gradient tensor and the parameter gradients equal to the rounding of the statistics atomics."""
+    from cu_net_amd._lib import set_planner_option
+    from oracle import cunet_ref as O
+    L = 2
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=L, order=1, loss_num=L)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=75)
+    x, target = O.synthetic_batch(4, 16, 256, seed=76)
+    res = {}
+    try:
+        for fuse in (1, 0):
+            set_planner_option('fuse_z_gather', fuse)
+            net = cu_net_amd.create_cu_net(**cfg)
+            net.load_state_dict(st)
+            net = net.cuda().train()
+            plan = net._get_plan(4, 256, 256, True, bf16=True)
+            desc = plan.handle.describe()
+            plan.handle.profile_begin(1)
+            plan.handle.profile_reset()
+            loss = plan.stage_target(target.cuda())
+            plan.forward_bf16(x.cuda(), 2, want_outputs=False)
+            plan.backward(None)
+            torch.cuda.synchronize()
+            counts = {k: v[0] for k, v in plan.handle.profile_collect().items()}
+            plan.handle.profile_begin(0)
+            zg = {}
+            for nd in desc['nodes']:
+                if nd['op'] == 'conv' and nd['name'].endswith('.conv1'):
+                    zg[nd['name']] = plan.debug_tensor(desc['tensors'][nd['out']]['name'], grad=True).float().cpu()
+            assert len(zg) == 9 * L
+            res[fuse] = (float(loss), net._grad_arena.clone().cpu(), counts, zg)
+    finally:
+        set_planner_option('fuse_z_gather', 0)
+    # (9 bottleneck outputs per U-Net + the last U-Net's output, whose only consumer is its head)
+    assert res[0][2]['bn_bwd_apply'] - res[1][2]['bn_bwd_apply'] == 9 * L + 1, (res[0][2]['bn_bwd_apply'], res[1][2]['bn_bwd_apply'])
+    assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+    worst = 0.0
+    for name, a in res[1][3].items():
+        b = res[0][3][name]
+        assert torch.isfinite(a).all(), name
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel <= 2e-2, (name, rel)                 # (bf16 tensors downstream of atomics-ordered fp64 sums: a few one-ulp flips)
+    ga, gb = res[1][1], res[0][1]
+    assert float((ga - gb).norm() / gb.norm()) <= 2e-2
+    print(f'worst relative difference of a z gradient tensor, fused vs gathered: {worst:.3e}')
