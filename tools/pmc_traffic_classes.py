@@ -23,6 +23,7 @@ CLASSES = [      # first match wins: the bf16-MFMA kernels carry bench.py's *_bf
     (r'conv(_pair)?_kernel<2, 1,|dgrad1x1_rows_kernel|dgrad1x1_rows_split2?_kernel', 'conv1x1_bwd_data'),
     (r'conv_kernel<3, 1,|dgrad3x3_ring_split_kernel', 'conv3x3_bwd_data'),
     (r'grad_gather(_rows)?_kernel', 'bn_bwd_apply'),
+    (r'gather_pool_pair_kernel', 'bn_bwd_apply'),      # round 6: gather + pool backward + the skip adapter's gather in one launch
     (r'pool_fwd_kernel<0>|pool_bf16_kernel', 'pool_fwd'),
     (r'pool_bwd_kernel', 'pool_bwd'),
     (r'ternary_conv_planes_kernel|ternary_conv_pixels_kernel|ternary_planes_kernel|ternary_conv_kernel', 'conv_fwd_popcount'),
