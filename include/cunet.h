@@ -315,6 +315,14 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "stem_wgrad_split"   1 (default, round 5; acts with f32_split): the stem's LDS-staged weight gradient contracts on the bf16 matrix pipe with
  *                        three-piece operands like every other fp32 convolution (it was the last kernel on the fp32 pipe and the last long
  *                        kernel of a step); 0: v_mfma_f32_32x32x2_f32
+ *   "fuse_pool_gather"   1 (default, round 6): in backward, gather(pool output) -> pool backward and the gather of the skip adapter's output --
+ *                        three element-wise launches in front of a down block's adapter pair, the last independent of the other two -- run as
+ *                        ONE launch (gather_pool_pair_kernel): +1.7 ... 2.4 % on the CU-Net-2 step.  Same operations on the same values
+ *   "fuse_z_gather"      0 (default; round 6, bf16 gradient tensors only): 1 = the gather of a tensor with ONE plain consumer (a dense layer's
+ *                        bottleneck output) is folded into the operand load of the 1x1 data gradient that reads it, which also writes the
+ *                        tensor.  Measured -2.5 % on config 3 (every column slice repeats the assembly): kept for re-measurement only
+ *   "stem_wgrad_caller"  0 (default; round 6): 1 = the stem's weight gradient and its reduce on the caller's stream behind the stem's BatchNorm
+ *                        pass instead of behind the last bucket's work on the side stream.  Measured +0.1 ... 0.2 %
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
  *                        32-channel chunks of dY on the way per wave, requested across the tile boundary; 1 (default) = one (rounds 1-3):
  *                        measured equal (3504 vs 3491 img/s)
