@@ -36,6 +36,7 @@ EXPECT = {
         'dgrad3x3_ring_split_kernel': 256,
         'stem_fwd_split_kernel': (256, 6),                 # (six registers spilled before the row loop, reloaded once per output row / at the end: none inside the tile loop)
         'dgrad1x1_rows_split_kernel': 256,
+        'dgrad1x1_rows_split2_kernel': 256,                # the dominant kernel of the bench line (round 5; round 6: tiles dealt from a counter)
     },
     'wgrad3_kernels.hip': {
         'wgrad3_kernelILi5ELb0ELi0ELb1E': 256,             # 1x1 weight gradient, 320 channels, split contraction
@@ -44,9 +45,11 @@ EXPECT = {
         'wgrad3_stem_kernelILb1ELb1E': 256,                # stem weight gradient: dz computed while staging, split contraction (round 5)
     },
     'bf16_kernels.hip': {
-        'dgrad_bf16_kernelILi1ELi2ELi4E': 168,             # bf16 1x1 data gradient, two channel tiles, K = 128 (12 waves)
+        'dgrad_bf16_kernelILi1ELi2ELi4ELb0E': 168,         # bf16 1x1 data gradient, two channel tiles, K = 128 (12 waves)
         'dgrad_bf16_pair_kernelILi1ELi2ELi4E': 168,
-        'dgrad_bf16_kernelILi1ELi1ELi4E': 128,
+        'dgrad_bf16_kernelILi1ELi1ELi4ELb0E': 128,
+        'dgrad_bf16_kernelILi1ELi2ELi4ELb1E': 256,         # round 6, planner option fuse_z_gather (off by default): the gather folded into the load, 8 / 12 waves
+        'dgrad_bf16_kernelILi1ELi1ELi4ELb1E': 168,
         'conv_bf16_kernelILi1ELi1ELi0E': 128,              # bf16 1x1 forward, one / two channel tiles
         'conv_bf16_kernelILi1ELi2ELi0E': 128,
     },
@@ -105,28 +108,69 @@ def test_row_tile_data_gradient_keeps_its_uncounted_requests_untouched(tmp_path)
     end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
     body = [l.split(';')[0].strip() for l in lines[start:end]]
     assert not any(l.startswith('scratch_') for l in body), 'the kernel spills to scratch'
-    waits = [i for i, l in enumerate(body) if l == 's_waitcnt vmcnt(4)']
-    assert len(waits) == 1, waits
-    w = waits[0]
-    # the tile loop: the innermost label in front of the wait that something behind the wait branches back to
+    # hipcc lays basic blocks out in any order: the checks walk the control flow (fall-through, s_branch, both arms of s_cbranch_*) instead
+    # of reading the listing top to bottom
     labels = {l[:-1]: i for i, l in enumerate(body) if re.match(r'\.LBB\d+_\d+:$', l)}
-    back = [(labels[m.group(1)], i) for i, l in enumerate(body) for m in [re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)$', l)]
-            if m and m.group(1) in labels and labels[m.group(1)] < w < i]
-    assert back, 'no loop around the counted wait'
-    top, bottom = max(back, key=lambda tb: tb[0])
-    loop = body[top:bottom + 1]
-    loads = [(i, l) for i, l in enumerate(loop) if l.startswith('global_load_dwordx4')]
-    stores = [i for i, l in enumerate(loop) if l.startswith('global_store_dwordx4')]
+    headers = [i for i in range(start, end) if re.match(r'\.LBB\d+_\d+:', lines[i]) and 'Loop Header: Depth=1' in lines[i]]
+    w4 = [i for i, l in enumerate(body) if l == 's_waitcnt vmcnt(4)']
+    assert 1 <= len(w4) <= 2, w4
+    # the x requests' wait is the first vmcnt(4) behind the header of the tile loop (the other one, round 6, is the tile ticket's: behind the stores)
+    tops = [h - start for h in headers if any(h - start < w for w in w4)]
+    assert tops, 'no loop header in front of the counted wait'
+    top = max(t for t in tops if t < min(w for w in w4 if w > min(tops)))
+    wx = min(w for w in w4 if w > top)
+    # (the loop's top has three arms -- the counted wait; idle waves, which wait for their DMA pieces with vmcnt(0) and never read the x
+    # registers; the workgroup's first tile, whose requests were waited for in front of the loop -- and they meet in front of the barrier: a walk
+    # ends there)
+    stops = {min(i for i in range(wx, len(body)) if body[i] == 's_barrier')}
+
+    def walk(frm):
+        """instructions executed after `frm` on any path, up to (not including) the barrier behind the x requests' wait"""
+        seen, todo = set(), [frm + 1]
+        while todo:
+            i = todo.pop()
+            while i < len(body) and i not in seen and i not in stops:
+                seen.add(i)
+                l = body[i]
+                m = re.match(r's_branch\s+(\.LBB\d+_\d+)$', l)
+                if m:
+                    i = labels[m.group(1)]
+                    continue
+                m = re.match(r's_cbranch\w*\s+(\.LBB\d+_\d+)$', l)
+                if m:
+                    todo.append(labels[m.group(1)])
+                if l.startswith('s_endpgm'):
+                    break
+                i += 1
+        return seen
+
+    # blocks of the tile loop, by hipcc's own annotation of every block ("in Loop: Header=BBn_m"; the header says "This Loop Header")
+    hdr = re.match(r'\.(LBB\d+_\d+):', lines[start + top]).group(1)
+    inloop, flag = [], False
+    for raw in lines[start:end]:
+        if re.match(r'\.LBB\d+_\d+:', raw) or re.match(r';\s*%bb\.\d+:', raw):
+            flag = f'Header={hdr[1:]}' in raw or raw.startswith(f'.{hdr}:')
+        inloop.append(flag)
+    after_wait = {i for i in walk(min(stops)) if inloop[i]}      # one iteration: from the barrier round to the barrier again
+    loads = [(i, body[i]) for i in sorted(after_wait) if body[i].startswith('global_load_dwordx4')]
+    stores = [i for i in sorted(after_wait) if body[i].startswith('global_store_dwordx4')]
     assert len(loads) == 4 and len(stores) == 4, (len(loads), len(stores))
-    assert min(stores) > max(i for i, _ in loads), 'a dz store in front of an x request: vmcnt(4) would no longer cover the requests'
-    assert not any(l.startswith(('global_load', 'global_atomic', 'buffer_load', 'buffer_store')) and not l.startswith('global_load_dwordx4')
-                   for l in loop if not l.startswith('global_load_lds')), 'another vector-memory operation inside the tile loop changes the count'
-    wrel = w - top
-    for i, l in loads:
+    for st in stores:
+        assert not any(body[j].startswith('global_load_dwordx4') for j in walk(st)), 'an x request behind a dz store: vmcnt(4) would no longer cover the requests'
+    others = [body[i] for i in after_wait if body[i].startswith(('global_load', 'global_atomic', 'buffer_load', 'buffer_store', 'global_store'))
+              and not body[i].startswith(('global_load_dwordx4', 'global_store_dwordx4', 'global_load_lds'))]
+    # (round 6: thread 0 takes the workgroup's next tile from a counter -- ONE returning atomic per iteration, issued in front of the x requests,
+    # i.e. older than the four dz stores the counted wait leaves in flight)
+    assert all(o.startswith('global_atomic_add ') for o in others) and len(others) <= 1, others
+    for i, l in enumerate(body):
+        if l.startswith('global_atomic_add ') and i in after_wait:
+            assert all(j in walk(i) for j, _ in loads), 'the tile ticket is not older than the x requests'
+    for i, l in loads + [(i, body[i]) for i in after_wait if body[i].startswith('global_atomic_add ')]:
         dst = _vgprs(l.split(',')[0])
-        assert len(dst) == 4, l
-        window = loop[i + 1:] + loop[:wrel]          # request -> back edge -> the wait
-        for k in window:
-            ops = k.split(None, 1)
+        assert len(dst) in (1, 4), l
+        if len(dst) == 1:
+            continue                                             # (the ticket's register is read behind ITS wait, checked by the stores' order above)
+        for j in walk(i):
+            ops = body[j].split(None, 1)
             if len(ops) == 2 and dst & _vgprs(ops[1]):
-                raise AssertionError(f'{k!r} touches the destination of the in-flight request {l!r}')
+                raise AssertionError(f'{body[j]!r} touches the destination of the in-flight request {l!r}')
