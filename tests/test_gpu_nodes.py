@@ -215,6 +215,25 @@ def test_every_node_backward_full_width_bf16_gradient_tensors():
 TIE_BAND = 2e-3      # in quantiser steps: an activation this close to a rounding boundary may land on either neighbouring level
 
 
+def _relu_tie_slack(x, z, gamma, beta, dact):
+    """Per-channel allowance (dbeta, dgamma) for ReLU decisions that may fall either way: elements with |z| within 8 * 2^-24 of the magnitudes
+    that cancel into it (|x * scale| + |mean * scale| + |beta|), i.e. z = 0 to the rounding of either evaluation order.  A flip changes dbeta[c] by |d(loss)/d(relu out)| and dgamma[c] by that times |xhat|."""
+    if dact is None:
+        zero = torch.zeros(z.shape[1])
+        return zero, zero
+    mean = x.mean((0, 2, 3), keepdim=True)
+    var = x.var((0, 2, 3), unbiased=False, keepdim=True)
+    xhat = (x - mean) / torch.sqrt(var + 1e-5)
+    # the magnitudes that cancel into z in EITHER evaluation: torch's (x - mean) * invstd * gamma + beta and the kernels' fma(x, scale, shift) with
+    # scale = gamma * invstd, shift = beta - mean * scale (a channel whose mean is many standard deviations from zero has |x * scale| and |shift|
+    # far above |z|: the rounding of scale and shift alone moves z by 2^-24 of THOSE)
+    g = (gamma.view(1, -1, 1, 1) / torch.sqrt(var + 1e-5)).abs()
+    terms = g * x.abs() + g * mean.abs() + beta.view(1, -1, 1, 1).abs()
+    tie = (z.abs() <= 8.0 * 2.0 ** -24 * terms).float()
+    w = tie * dact.abs()
+    return w.sum((0, 2, 3)), (w * xhat.abs()).sum((0, 2, 3))
+
+
 def _quantiser_tie_slack(pre_q, dy, bits, taps):
     """The weight gradient at a QuanInput2d site contracts dY with the QUANTISED activation round(a * 2^(bits-1)) / 2^(bits-1)
     (utils/quantize.py:33-42,47-63).  The reference side of this test recomputes `a` (BatchNorm + ReLU) on the CPU from the GPU's
@@ -334,7 +353,10 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
                 # the MFMA's K, i.e. whenever it fits the tensor's slot -- the operand their bf16 forward multiplied as well)
                 wt = wt.bfloat16().float()
             wt.requires_grad_(True)
-            act = F.relu(F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5))
+            pre = F.batch_norm(cat, None, None, gamma, beta, True, 0.1, 1e-5)
+            relu_out = F.relu(pre)
+            relu_out.retain_grad()                              # d(loss)/d(relu output): what a flipped ReLU mask adds to / removes from a sum
+            act = relu_out
             if quan_input_bits and (nd['taps'] == 9 or nd.get('head', -1) >= 0):
                 from oracle.cunet_ref import _QuanInputFn       # QuanInput2d site: quantised forward, straight-through backward
                 pre_q = act.detach()
@@ -368,8 +390,16 @@ def _check_all_nodes_impl(cfg, st, x, bf16, wgrad3_all, quan_input_bits=0, only_
                 nm = T[s['t']]['name']
                 _close(f'{nd["name"]} dX[{nm}]', plan.debug_tensor(nm, grad=True), l.grad, bad, **dx_tol)
             _close(f'{nd["name"]} dW', pgrad(nd['conv'] + '.weight'), wt.grad, bad, **dw_tol)
-            _close(f'{nd["name"]} dgamma', pgrad(nd['bn'] + '.weight'), gamma.grad, bad)
-            _close(f'{nd["name"]} dbeta', pgrad(nd['bn'] + '.bias'), beta.grad, bad)
+            # dgamma / dbeta are sums over ALL rows of a channel: ONE ReLU decision that falls the other way (z = gamma * xhat + beta within its own
+            # rounding error of 0: the kernel's fused multiply-add from fp64-derived scale / shift against torch's operation order) moves the
+            # whole channel by |d(loss)/d(relu out)| of that element -- at the bench batch (98 304 rows per channel at 64 x 64) about one channel
+            # per node has such an element, and with them the count of "elements off" is the count of ties, not a kernel property (round 6: a
+            # session on the fp32 matrix pipe found three in one node of the CU-Net-16 plan).  As for the quantiser ties of round 5 the
+            # allowance is derived from the inputs, per channel: the sum of |d(loss)/d(relu out)| (times |xhat| for dgamma) over the elements whose z
+            # is within 8 ulp of the magnitudes that cancel into it of zero.
+            bn_slack = _relu_tie_slack(cat.detach(), pre.detach(), gamma.detach(), beta.detach(), relu_out.grad)
+            _close(f'{nd["name"]} dgamma', pgrad(nd['bn'] + '.weight'), gamma.grad, bad, slack=bn_slack[1])
+            _close(f'{nd["name"]} dbeta', pgrad(nd['bn'] + '.bias'), beta.grad, bad, slack=bn_slack[0])
         elif op == 'pool':
             nm = T[nd['segs'][0]['t']]['name']
             leaf = acts[nm].clone().requires_grad_(True)
