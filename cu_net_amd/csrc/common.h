@@ -159,6 +159,8 @@ struct WgradArgs {
     int xbf16;             // 1 = the segments' x are bf16; 2 = x and dy are bf16 (dw stays fp32)
     int qin_bits;          // > 0: the conv's input is QuanInput(relu(bn(x))): the weight gradient contracts dY with the QUANTISED activation
     int split;             // fp32 storage: 1 = contract on the bf16 matrix pipe, operands cut into three bf16 pieces (planner option f32_split)
+    int split_planes;      // split contraction, 1x1 (round 6, planner option wgrad_split_planes): 1 = operands cut once on the way into LDS, three bf16
+                           // planes read back by ds_read_b64_tr_b16 (wgrad5_split_kernel) for slices of at most 9 channel tiles
     int bf16_dma;          // xbf16 == 2, 1x1: 1 = the LDS-DMA ring kernel where its preconditions hold (the plan's snapshot of planner option
                            // wgrad_bf16_dma), 0 = always the register-staged kernel
     // stem only (planner option stem_fuse_dz): sx != null = dy is NOT read; the kernel derives d(loss)/d(conv0 output) itself from the conv's

@@ -184,6 +184,7 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "fuse_pool_gather") return &o.fuse_pool_gather;
     if (n == "fuse_z_gather") return &o.fuse_z_gather;
     if (n == "stem_wgrad_caller") return &o.stem_wgrad_caller;
+    if (n == "wgrad_split_planes") return &o.wgrad_split_planes;
     return nullptr;
 }
 
@@ -208,8 +209,10 @@ int cunet_get_planner_option(const char* name, int* value) {
 int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value) {
     // only launch-time choices between bit-identical kernels may change under a live plan (everything else shaped its layout)
     if (!plan || !name || value < 0) return fail(CUNET_ERR_INVALID, "bad plan option");
-    if (std::string(name) != "wgrad_bf16_dma") return fail(CUNET_ERR_INVALID, std::string("not a launch-time option: ") + name);
-    plan->plan.opts.wgrad_bf16_dma = value;
+    const std::string n(name);
+    if (n == "wgrad_bf16_dma") plan->plan.opts.wgrad_bf16_dma = value;
+    else if (n == "wgrad_split_planes") plan->plan.opts.wgrad_split_planes = value;
+    else return fail(CUNET_ERR_INVALID, std::string("not a launch-time option: ") + name);
     return CUNET_OK;
 }
 
@@ -793,6 +796,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
             w.xbf16 = E.xmode;
             w.qin_bits = h->qin_bits ? h->node_qin[node_index] : 0;
             w.split = E.xmode == 0 ? P.opts.f32_split : 0;
+            w.split_planes = P.opts.wgrad_split_planes;
             w.bf16_dma = P.opts.wgrad_bf16_dma;      // (the plan's snapshot, like every other option; cunet_debug_set_plan_option flips it on a live plan for the bit-identity test)
             if (c.taps == 9 && wg3_active(P, n, E.xmode) && wgrad3_3x3_supported(w)) {
                 // LDS ring of activated image rows, partial tiles [split][tap][n][c] (reduced + transposed per bucket)

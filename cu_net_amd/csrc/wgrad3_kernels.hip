@@ -760,6 +760,266 @@ __global__ __launch_bounds__(WG3_THREADS, 2) void wgrad4_bf16_kernel(const Wg3Ar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6 (planner option wgrad_split_planes): the fp32 1x1 weight gradient on the split contraction with the operands cut ONCE.
+// wgrad3_kernel<..., EMU> stages fp32 tiles and every wave cuts the fragments it reads -- the dY fragment by the two waves that share an
+// output-channel tile's k-step, every X fragment by the four waves of the four output-channel tiles: 49 152 element cuts per 32-pixel
+// chunk for 14 336 elements (CW = 320), ~216 VALU instructions per wave and k-step next to 30 MFMAs: the two pipes of a SIMD are loaded
+// about equally, and whatever of the cutting does not hide behind the other wave's MFMAs is lost (38 us per 64 x 64 launch alone against
+// a matrix-pipe bound of 26 at 192 workgroups).  Here the element is cut on its way INTO LDS -- once, behind BatchNorm + ReLU -- into three
+// bf16 planes laid out as wgrad4_bf16_kernel's ring rows ([pixel][dY 128 | X CW] bf16, the same conflict-free pitch), and the MFMA
+// fragments come out of each plane by ds_read_b64_tr_b16 (two reads per fragment: lane = channel, 8 consecutive pixels), through the
+// compiler's own builtin (its waits are the compiler's).  Same pieces, same six products per pair in the same k order as the staging
+// kernel: bit-identical partial tiles (tests/test_gpu_exact.py).  Two 32-pixel buffers of 3 x 32 x pitch bytes: CW <= 288 (9 tiles) fit
+// 160 KB; a 320-channel slice keeps wgrad3_kernel.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 wg5_frag(const char* p, int step) {      // p: this lane's transpose-read address, step = 4 pixel rows
+    typedef __attribute__((address_space(3))) v4i16_t lds_v4;
+    const v4i16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
+    const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + step));
+    const u32x2w ua = __builtin_bit_cast(u32x2w, a), ub = __builtin_bit_cast(u32x2w, b);
+    return u32x4{ua.x, ua.y, ub.x, ub.y};
+}
+// four fp32 values (4 channels of one pixel) -> their three bf16 pieces, 8 bytes per plane
+__device__ __forceinline__ void wg5_cut4(const float4 v, u32x2w& h, u32x2w& m, u32x2w& l) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_bf16x3_pair(f32x2_op{v.x, v.y}, h0, m0, l0);
+    split_bf16x3_pair(f32x2_op{v.z, v.w}, h1, m1, l1);
+    h = u32x2w{h0, h1}; m = u32x2w{m0, m1}; l = u32x2w{l0, l1};
+}
+
+template <int CT>      // channel tiles of the slice: CW = 32 CT, 4 <= CT <= 9; CT <= 5: split-K over the two k-steps of a chunk
+__global__ __launch_bounds__(WG3_THREADS, 2) void wgrad5_split_kernel(const Wg3Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SPLITK = CT <= 5;
+    constexpr int CTW = SPLITK ? CT : (CT + 1) / 2;
+    static_assert(CTW >= 3 && CTW <= 5, "tile ownerships of 3 .. 5 channel tiles");
+    constexpr int CW = 32 * CT;
+    constexpr int PITCH = wg4_pitch(CT);                   // bytes per pixel row of a plane
+    constexpr int PLANE = WG3_P * PITCH;
+    constexpr int BUF = 3 * PLANE;
+    const WgradArgs& p = q.w;
+    float* sc = reinterpret_cast<float*>(smem);            // [CW]
+    float* sh = sc + WG3_MAXCW;
+    char* buf0 = smem + WG4_RING0;                         // 2 x { plane h, plane m, plane l }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int HW = p.H * p.W;
+
+    for (int c = tid; c < CW; c += WG3_THREADS) {
+        const int cc = q.c0 + c;
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cc >= p.seg[t].choff) s = t;
+        const Seg& sg = p.seg[s];
+        const int lc = cc - sg.choff;
+        const double sum = sg.stats[lc], sq = sg.stats[sg.C + lc];
+        const double mean = sum / sg.count;
+        double var = sq / sg.count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double scale = (double)p.gamma[cc] * istd;
+        sc[c] = (float)scale;
+        sh[c] = (float)((double)p.beta[cc] - mean * scale);
+    }
+
+    // ---- staging plan of this thread (chunk-invariant), as wgrad3_kernel: 2 float4 of dY, up to NX float4 of X
+    constexpr int NX = (CT + 1) / 2;                       // ceil(32 * CW / 4 / 512)
+    constexpr int cw4 = CW >> 2;
+    constexpr int nx4 = WG3_P * cw4;
+    int xp[NX], xc[NX];
+    const float* xbase[NX];
+    int xld[NX], xups[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        int idx = tid + WG3_THREADS * j;
+        if (idx >= nx4) idx = nx4 - 1;                     // duplicates of the last item: same value to the same LDS address
+        xp[j] = idx / cw4;
+        xc[j] = (idx - xp[j] * cw4) << 2;
+        const int cc = q.c0 + xc[j];
+        int s = 0;
+        for (int t = 1; t < p.nseg; ++t)
+            if (cc >= p.seg[t].choff) s = t;
+        const Seg& sg = p.seg[s];
+        xbase[j] = sg.x + (cc - sg.choff);
+        xld[j] = sg.ld;
+        xups[j] = sg.ups;
+    }
+    const int ap0 = tid >> 5, ac0 = (tid & 31) << 2;       // dY item 0: pixel tid/32, channels 4*(tid%32); item 1: pixel + 16
+
+    const int row_begin = blockIdx.x * q.rows_per_split;
+    int row_end = row_begin + q.rows_per_split;
+    if (row_end > p.M) row_end = p.M;
+    const int nchunks = (row_end - row_begin + WG3_P - 1) / WG3_P;
+
+    // (two chunks of raw loads in flight per thread -- stages by chunk parity, the loop unrolled by two, exact counted waits -- measured the same on
+    // the 64 x 64 launches, 27.9 vs 28.7 us, and slower on the small ones: a workgroup streams ~21 GB/s from its CU either way, which at 192
+    // workgroups IS the launch's share of the HBM rate; one chunk ahead it stays)
+    float4 av[2], xv[NX];
+    float4 s4[NX], h4[NX];
+    bool aok[2], xok[NX];
+    auto issue = [&](int chunk) {                          // raw global loads of one chunk into registers (clamped addresses)
+        const int m0 = row_begin + chunk * WG3_P;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ap0 + 16 * j;
+            aok[j] = m < row_end;
+            const int mc = aok[j] ? m : row_begin;
+            av[j] = ldg4(p.dy + (size_t)mc * p.lddy + ac0);
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int m = m0 + xp[j];
+            xok[j] = m < row_end;
+            const int mc = xok[j] ? m : row_begin;
+            int row = mc;
+            if (q.any_ups) {                               // nearest-upsample index map (models/cu_net.py:250,265): (y >> 1, x >> 1)
+                const int nimg = mc / HW;
+                const int rem = mc - nimg * HW;
+                const int py = rem / p.W;
+                const int px = rem - py * p.W;
+                const int rowU = nimg * (HW >> 2) + (py >> 1) * (p.W >> 1) + (px >> 1);
+                row = xups[j] ? rowU : mc;
+            }
+            xv[j] = ldg4(xbase[j] + (size_t)row * xld[j]);
+        }
+    };
+    auto commit = [&](char* buf) {                         // registers -> three bf16 planes, BatchNorm + ReLU on X, zeros beyond the range
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 v = aok[j] ? av[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            u32x2w h, m, l;
+            wg5_cut4(v, h, m, l);
+            char* d = buf + (ap0 + 16 * j) * PITCH + 2 * ac0;
+            *reinterpret_cast<u32x2w*>(d) = h;
+            *reinterpret_cast<u32x2w*>(d + PLANE) = m;
+            *reinterpret_cast<u32x2w*>(d + 2 * PLANE) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            float4 v;
+            v.x = fmaxf(fmaf(xv[j].x, s4[j].x, h4[j].x), 0.f);
+            v.y = fmaxf(fmaf(xv[j].y, s4[j].y, h4[j].y), 0.f);
+            v.z = fmaxf(fmaf(xv[j].z, s4[j].z, h4[j].z), 0.f);
+            v.w = fmaxf(fmaf(xv[j].w, s4[j].w, h4[j].w), 0.f);
+            if (!xok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            u32x2w h, m, l;
+            wg5_cut4(v, h, m, l);
+            char* d = buf + xp[j] * PITCH + 256 + 2 * xc[j];
+            *reinterpret_cast<u32x2w*>(d) = h;
+            *reinterpret_cast<u32x2w*>(d + PLANE) = m;
+            *reinterpret_cast<u32x2w*>(d + 2 * PLANE) = l;
+        }
+    };
+
+    // ---- tile ownership as wgrad4_bf16_kernel: output-channel tile wave & 3; split-K: every X tile, k-step (wave >> 2) of a chunk; otherwise
+    // half (wave >> 2) owns CTW consecutive X tiles -- the second half the LAST CTW (an odd CT: its first tile repeats the first half's
+    // last one and is not stored)
+    const int nt = wave & 3;
+    const int half = wave >> 2;
+    const int cb = SPLITK ? 0 : (half ? CT - CTW : 0);
+    const bool dup_first = !SPLITK && half && (CT & 1);
+    f32x16 acc[CTW];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // transpose-read address of this lane inside a plane: pixel 8 (l >> 5) + ((l & 15) >> 2) (+ 4 for the second read, + 16 for the second
+    // k-step), channel piece 16 ((l >> 4) & 1) + 4 (l & 3) of the tile
+    const int lane_off = (8 * hi + ((lane & 15) >> 2)) * PITCH + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    const int off_a = lane_off + nt * 64;
+    const int off_x = lane_off + 256 + cb * 64;
+
+    issue(0);
+    __syncthreads();                                       // sc / sh visible
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        s4[j] = *reinterpret_cast<const float4*>(sc + xc[j]);
+        h4[j] = *reinterpret_cast<const float4*>(sh + xc[j]);
+    }
+    commit(buf0);
+    __syncthreads();
+    auto contract = [&](const char* cur) {                 // the chunk in `cur`: this wave's k-step(s)
+        constexpr int NS = SPLITK ? 1 : 2;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const int kst = (SPLITK ? half : ks) * 16 * PITCH;
+            // every fragment of the k-step is requested before its first MFMA (left alone hipcc reads a tile's three X fragments and waits
+            // for them right in front of that tile's six MFMAs: one exposed LDS round trip per tile)
+            const u32x4 ah = wg5_frag(cur + off_a + kst, 4 * PITCH);
+            const u32x4 am = wg5_frag(cur + PLANE + off_a + kst, 4 * PITCH);
+            const u32x4 al = wg5_frag(cur + 2 * PLANE + off_a + kst, 4 * PITCH);
+            u32x4 xh[CTW], xm[CTW], xl[CTW];
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) {
+                xh[t] = wg5_frag(cur + off_x + kst + 64 * t, 4 * PITCH);
+                xm[t] = wg5_frag(cur + PLANE + off_x + kst + 64 * t, 4 * PITCH);
+                xl[t] = wg5_frag(cur + 2 * PLANE + off_x + kst + 64 * t, 4 * PITCH);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) acc[t] = mfma_split6(ah, am, al, xh[t], xm[t], xl[t], acc[t]);
+        }
+    };
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) issue(chunk + 1);                        // in flight across the MFMA loop
+        contract(buf0 + (chunk & 1) * BUF);
+        if (more) commit(buf0 + ((chunk + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    if (SPLITK) {                                          // the second k-step's half hands its tiles over through LDS
+        float* red = reinterpret_cast<float*>(smem + WG4_RING0);
+        if (half == 1) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((nt * CTW + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((nt * CTW + t) * 16 + r) * 64 + lane];
+        }
+        if (half == 1) return;
+    }
+    float* out = q.part + (size_t)blockIdx.x * WG3_NOUT * p.Ccat;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        if (t == 0 && dup_first) continue;                  // the tile both halves computed
+        const int c = q.c0 + (cb + t) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)n * p.Ccat + c] = acc[t][r];
+        }
+    }
+}
+
+static hipError_t launch_wg5_split(const Wg3Args& q, int ct, dim3 grid, hipStream_t s) {
+    const size_t smem = (size_t)WG4_RING0 + (size_t)2 * 3 * WG3_P * wg4_pitch(ct);
+#define CUNET_WG5(CT_) hipLaunchKernelGGL((wgrad5_split_kernel<CT_>), grid, dim3(WG3_THREADS), smem, s, q)
+    switch (ct) {
+        case 4: CUNET_WG5(4); break;
+        case 5: CUNET_WG5(5); break;
+        case 6: CUNET_WG5(6); break;
+        case 7: CUNET_WG5(7); break;
+        case 8: CUNET_WG5(8); break;
+        case 9: CUNET_WG5(9); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CUNET_WG5
+    return hipGetLastError();
+}
+
 // dst[i] = sum_s part[s][i]: fixed summation order (bitwise reproducible).  blockIdx.y = table entry.
 // A block covers 64 float4 of the output; its four 64-thread groups take every fourth split and meet in LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgReduceEntry* __restrict__ tab, const float* __restrict__ ws,
@@ -867,7 +1127,9 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
             (const void*)&wgrad3_bf16_kernel<4, true>, (const void*)&wgrad3_bf16_kernel<5, true>, (const void*)&wgrad3_bf16_kernel<3, false>,
             (const void*)&wgrad3_bf16_kernel<4, false>, (const void*)&wgrad3_bf16_kernel<5, false>,
             (const void*)&wgrad4_bf16_kernel<4>, (const void*)&wgrad4_bf16_kernel<5>, (const void*)&wgrad4_bf16_kernel<6>, (const void*)&wgrad4_bf16_kernel<7>,
-            (const void*)&wgrad4_bf16_kernel<8>, (const void*)&wgrad4_bf16_kernel<9>, (const void*)&wgrad4_bf16_kernel<10>};
+            (const void*)&wgrad4_bf16_kernel<8>, (const void*)&wgrad4_bf16_kernel<9>, (const void*)&wgrad4_bf16_kernel<10>,
+            (const void*)&wgrad5_split_kernel<4>, (const void*)&wgrad5_split_kernel<5>, (const void*)&wgrad5_split_kernel<6>, (const void*)&wgrad5_split_kernel<7>,
+            (const void*)&wgrad5_split_kernel<8>, (const void*)&wgrad5_split_kernel<9>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -901,7 +1163,11 @@ hipError_t launch_wgrad3(const WgradArgs& a, float* part, int S, int rows_per_sp
         size_t buf_bytes = a.xbf16 == 2 ? (size_t)2 * (WG3_NOUT + q.CW) * WG3B_LDP * 2 : (size_t)2 * WG3_P * (WG3_NOUT + ldx) * 4;
         if (ct <= 5 && buf_bytes < (size_t)4 * ct * 4096) buf_bytes = (size_t)4 * ct * 4096;      // split-K hand-over area
         const size_t smem = (size_t)2 * WG3_MAXCW * 4 + buf_bytes;
-        const hipError_t e = dma ? launch_wg4_bf16(q, ct, dim3(S), s) : a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)
+        // fp32 on the split contraction, operands cut once on the way into LDS (planner option wgrad_split_planes): slices of <= 8 tiles
+        const bool planes = a.split && a.xbf16 == 0 && a.split_planes && ct <= 8 &&      // (9 tiles: 256 VGPRs and 11 spilled)
+                            (size_t)WG4_RING0 + (size_t)2 * 3 * WG3_P * wg4_pitch(ct) <= (size_t)160 * 1024 && (ct > 5 || (size_t)4 * ct * 4096 <= (size_t)2 * 3 * WG3_P * wg4_pitch(ct));
+        const hipError_t e = planes ? launch_wg5_split(q, ct, dim3(S), s)
+                           : dma ? launch_wg4_bf16(q, ct, dim3(S), s) : a.xbf16 == 2 ? launch_wg3_bf16(q, ct, dim3(S), smem, s)
                            : a.xbf16 ? launch_wg3_x<1>(q, ct, dim3(S), smem, s)
                            : a.split ? launch_wg3_x<0, true>(q, ct, dim3(S), smem, s) : launch_wg3_x<0>(q, ct, dim3(S), smem, s);
         if (e != hipSuccess) return e;

@@ -321,6 +321,9 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "fuse_z_gather"      0 (default; round 6, bf16 gradient tensors only): 1 = the gather of a tensor with ONE plain consumer (a dense layer's
  *                        bottleneck output) is folded into the operand load of the 1x1 data gradient that reads it, which also writes the
  *                        tensor.  Measured -2.5 % on config 3 (every column slice repeats the assembly): kept for re-measurement only
+ *   "wgrad_split_planes" 0 (default; round 6, acts with f32_split): 1 = the fp32 1x1 weight gradient cuts its operands ONCE, on the way into LDS (three
+ *                        bf16 planes, fragments by ds_read_b64_tr_b16: wgrad5_split_kernel) for slices of at most 8 channel tiles.  Bit-identical
+ *                        partial tiles; 11-16 % less time for those launches alone, +-0.3 % on the CU-Net-2 step, +0.75 % on CU-Net-16
  *   "stem_wgrad_caller"  0 (default; round 6): 1 = the stem's weight gradient and its reduce on the caller's stream behind the stem's BatchNorm
  *                        pass instead of behind the last bucket's work on the side stream.  Measured +0.1 ... 0.2 %
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
@@ -348,8 +351,8 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
 int cunet_set_planner_option(const char* name, int value);
 /* reads the process-wide value back (tests save / restore the options they change).  0, or CUNET_ERR_INVALID for an unknown name. */
 int cunet_get_planner_option(const char* name, int* value);
-/* debugging aid of the test-suite: changes "wgrad_bf16_dma" -- the one option that only picks between bit-identical kernels at
- * launch time -- in the snapshot of a LIVE plan.  Any other name: CUNET_ERR_INVALID (those options shaped the plan's layout). */
+/* debugging aid of the test-suite: changes "wgrad_bf16_dma" or "wgrad_split_planes" -- the options that only pick between bit-identical
+ * kernels at launch time -- in the snapshot of a LIVE plan.  Any other name: CUNET_ERR_INVALID (those options shaped the plan's layout). */
 int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value);
 /* debugging aid: tensors that a training step no longer materialises are written now, from the state the last cunet_backward left in the
  * workspace (today: d(loss)/d(conv0 output) under planner option "stem_fuse_dz").  The Python binding calls it before it reads a gradient

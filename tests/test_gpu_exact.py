@@ -809,3 +809,51 @@ def test_single_consumer_gather_folded_into_the_data_gradient(mode):
     ga, gb = res[1][1], res[0][1]
     assert float((ga - gb).norm() / gb.norm()) <= 2e-2
     print(f'worst relative difference of a z gradient tensor, fused vs gathered: {worst:.3e}')
+
+
+@pytest.mark.parametrize('n', [4, 24])
+def test_split_weight_gradient_with_operands_cut_once_is_bit_identical(n):
+    """wgrad5_split_kernel (round 6, planner option wgrad_split_planes, default 0 -- 8 % less time for its class alone, nothing in the step: fp32 operands cut into their three bf16 pieces ONCE, on the way into
+    LDS behind BatchNorm + ReLU; MFMA fragments by ds_read_b64_tr_b16 from three bf16 planes) against wgrad3_kernel<..., EMU> (fp32 tiles in
+    LDS, every wave cuts the fragments it reads) on the SAME plan state, node by node: the same pieces enter the same six products per pair in
+    the same k order, so every 1x1 weight gradient of a slice of at most 8 channel tiles must agree bit for bit (288- and 320-channel slices
+    run wgrad3_kernel under either setting).  N = 4: few short splits; N = 24: the bench's geometry.  Up-sampled segments, split-K (<= 5 tiles) and
+    two-half ownerships incl. odd tile counts (7, 9) all occur in CU-Net-2.  Autograd wgrad of models/cu_net.py:24,43."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=95)
+    x, _ = O.synthetic_batch(n, 16, 256, seed=96)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    plan = net._get_plan(n, 256, 256, True)
+    plan.forward(x.cuda(), True, want_outputs=False)
+    torch.cuda.synchronize()
+    desc = plan.handle.describe()
+    T = desc['tensors']
+    off = {name: (o, nmel) for name, kind, shape, o, nmel in net._entries if kind == 0}
+    nodes = [(k, nd) for k, nd in enumerate(desc['nodes']) if nd['op'] == 'conv' and nd['taps'] == 1 and nd.get('wg3', 0) > 0]
+    assert len(nodes) >= 40
+    seen_ct, bad = set(), []
+    try:
+        for k, nd in nodes:
+            o, nmel = off[nd['conv'] + '.weight']
+            t = T[nd['out']]
+            gen = torch.Generator().manual_seed(3000 + k)
+            plan.debug_poke(t['name'], torch.randn((t['N'], t['C'], t['H'], t['W']), generator=gen), grad=True)      # this node's d(loss)/d(out)
+            got = {}
+            for planes in (1, 0):
+                plan.debug_set_option('wgrad_split_planes', planes)      # (the plan's own snapshot: nothing process-wide changes)
+                plan.debug_run_node_backward(k)
+                torch.cuda.synchronize()
+                got[planes] = net._grad_arena[o:o + nmel].clone()
+            seen_ct.add(nmel // (128 * 32))
+            if not torch.equal(got[1], got[0]):
+                d = (got[1] - got[0]).abs()
+                bad.append(f'{nd["name"]}: {int((d > 0).sum())}/{nmel} elements differ, max {float(d.max()):.3e} of {float(got[0].abs().max()):.3e}')
+            assert float(got[0].abs().max()) > 0
+    finally:
+        plan.debug_set_option('wgrad_split_planes', 0)
+    assert not bad, '\n'.join(bad[:20])
+    assert {4, 5, 6, 8, 9, 10} <= seen_ct, seen_ct

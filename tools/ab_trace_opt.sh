@@ -5,7 +5,7 @@ OPT=$1; V0=$2; V1=$3; FILT=$4; shift 4
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/abt; mkdir -p $OUT; export TMPDIR=/tmp
 for v in $V0 $V1; do
   cd /tmp
-  CUNET_BENCH_NO_CLASS_EVENTS=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_$v -o t -- python $ROOT/bench.py --no-cpu-baseline --no-also --no-alone --steps 6 --warmup 3 --planner-opt $OPT=$v "$@" > /dev/null 2> $OUT/$v.err
+  CUNET_BENCH_NO_CLASS_EVENTS=1 ${CUNET_ABT_ENV:-} timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_$v -o t -- python $ROOT/bench.py --no-cpu-baseline --no-also --no-alone --steps 6 --warmup 3 --planner-opt $OPT=$v "$@" > /dev/null 2> $OUT/$v.err
   cd $ROOT
   python tools/trace_summary.py "$(ls $OUT/tr_$v/*/*kernel_trace.csv $OUT/tr_$v/*kernel_trace.csv 2>/dev/null | head -1)" 400 > $OUT/sum_$v.txt
   rm -rf $OUT/tr_$v
