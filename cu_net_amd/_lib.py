@@ -129,7 +129,7 @@ PLANNER_OPTIONS = ('wgrad3_min_rows', 'wgrad3_min_chunks', 'wgrad3_max_splits', 
                    'wgrad3_stem', 'conv3x3_ring_min_rows', 'wgrad_fork_group', 'wgrad_fork_group_bf16', 'fwd_fork_min_w', 'pair_adapters',
                    'heads_on_side', 'dgrad_nt', 'wgrad_bf16_dma', 'fuse_wgrad', 'dgrad_prefetch', 'dgrad_rows', 'f32_split', 'dgrad3_nt',
                    'dgrad3_ring', 'stem_split', 'dgrad_rows_v', 'popcount_pixels', 'stem_fuse_dz', 'stem_wgrad_split',
-                   'fuse_pool_gather', 'fuse_z_gather', 'stem_wgrad_caller', 'wgrad_split_planes')
+                   'fuse_pool_gather', 'fuse_z_gather', 'stem_wgrad_caller', 'wgrad_split_planes', 'stem_wgrad_planes')
 
 
 def set_planner_option(name: str, value: int):

@@ -185,6 +185,7 @@ static int* planner_option_slot(PlannerOptions& o, const std::string& n) {
     if (n == "fuse_z_gather") return &o.fuse_z_gather;
     if (n == "stem_wgrad_caller") return &o.stem_wgrad_caller;
     if (n == "wgrad_split_planes") return &o.wgrad_split_planes;
+    if (n == "stem_wgrad_planes") return &o.stem_wgrad_planes;
     return nullptr;
 }
 
@@ -212,6 +213,7 @@ int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value)
     const std::string n(name);
     if (n == "wgrad_bf16_dma") plan->plan.opts.wgrad_bf16_dma = value;
     else if (n == "wgrad_split_planes") plan->plan.opts.wgrad_split_planes = value;
+    else if (n == "stem_wgrad_planes") plan->plan.opts.stem_wgrad_planes = value;
     else return fail(CUNET_ERR_INVALID, std::string("not a launch-time option: ") + name);
     return CUNET_OK;
 }
@@ -844,6 +846,7 @@ static int bwd_node(cunet_plan* h, const Node& n, int node_index, hipStream_t s,
         w.dw = h->grads + c.w;
         w.img = h->last_x; w.IH = P.cfg.height; w.IW = P.cfg.width;
         w.split = (P.opts.f32_split && P.opts.stem_wgrad_split) ? 1 : 0;      // (fp32 image and fp32 dY in every storage mode)
+        w.split_planes = P.opts.stem_wgrad_planes;                            // (round 6: both operands cut once on their way into LDS)
         if (wg3_active(P, n, E.xmode)) {      // (an unsupported shape is an error here: the reduce table already expects partial tiles)
             if (h->stem_fused_now) {           // d(loss)/d(conv0 output) is computed inside the kernel (WgradArgs::sx ...)
                 const Node& nb = P.nodes[node_index + 1];       // the stem's BatchNorm-ReLU-pool node

@@ -1896,6 +1896,290 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Ar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6 (planner option stem_wgrad_planes, acts with f32_split + stem_wgrad_split): the stem's weight gradient with BOTH operands cut once.
+// wgrad3_stem_kernel<*, EMU> keeps the image rows and the dY chunk as fp32 in LDS and every wave cuts the fragments it reads: an image element
+// ends up cut ~49 times (12 (tap, pixel) pairs x 4 output-channel waves), ~256 VALU instructions per wave and 16-pixel k-step next to 18 MFMAs
+// -- the kernel, the last of a step and alone on the GPU, is VALU-bound at 150 us against 42 us of matrix pipe.  Here
+//   * the image rows live in a RING of 16 row slots as three bf16 planes, de-interleaved by column parity (a stride-2 tap walks consecutive
+//     elements of one parity line): line (c, kx & 1) holds element idx = ox + (kx >> 1) of the 3 + IW + 3 padded row at byte 2 idx.  A lane's
+//     8 pixels of one plane are 5 dwords (ds_read2_b32 x 2 + ds_read_b32 at byte 2 (x0 + p0) + 4 (kx >> 2)) and four v_alignbyte_b32 by
+//     2 ((kx >> 1) & 1) bytes; line pitch IW + 8 bytes (= 2 mod 4 dwords: the 32 im2col columns of a tile fall into different banks);
+//     two rows are staged per output row (one float4 per thread, cut on its way in), zero rows / borders are zeros in the planes;
+//   * the dY chunk (32 pixels, two buffers: ONE barrier per chunk, the next chunk's cut runs beside the other waves' MFMAs) is cut on its way in,
+//     behind the fused BatchNorm / ReLU / pool backward, into three planes of wgrad4's row layout and read by ds_read_b64_tr_b16 (wg5_frag).
+// Same pieces, same six products, same pixel order and the same rows per workgroup as wgrad3_stem_kernel<*, true>: bit-identical partial tiles.
+constexpr int SPL_NS = 16;                                 // ring slots: 7 rows under contraction + 2 being staged, a power of two
+constexpr int SPL_P = 32;                                  // output pixels per dY chunk
+constexpr int SPL_APITCH = 320;                            // bytes per pixel row of a dY plane (128 bf16 + 64: an odd multiple of 64)
+constexpr int SPL_APLANE = SPL_P * SPL_APITCH;
+constexpr int SPL_ABUF = 3 * SPL_APLANE;
+typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+template <bool FUSE>
+__global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_planes_kernel(const Wg3Args q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    const WgradArgs& p = q.w;
+    const int OH = p.H, OW = p.W, IH = p.IH, IW = p.IW;
+    const int LP = IW + 8;                                 // bytes per (channel, parity) line of a plane
+    const int PL = 6 * LP;                                 // bytes per plane of a row slot
+    const int SLOT = 3 * PL;
+    char* abuf0 = smem + (SPL_NS + 1) * SLOT;              // slot SPL_NS stays all zeros (im2col columns >= 147)
+    const int rows = q.rows_per_split;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+    const int wpi = q.c0;
+    const int img = blockIdx.x / wpi;
+    const int r0 = (blockIdx.x - img * wpi) * rows;
+    int r1 = r0 + rows;
+    if (r1 > OH) r1 = OH;
+
+    for (int i = tid * 16; i < (SPL_NS + 1) * SLOT; i += WG3_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- image rows: a thread stages one float4 of a row PAIR (2 rows x 3 channels x IW / 4 <= 512 items)
+    const int per_row = 3 * (IW >> 2);
+    const bool stager = tid < 2 * per_row;
+    const int sj = tid / per_row;
+    const int sc = (tid - sj * per_row) / (IW >> 2);
+    const int sx4 = (tid - sj * per_row) - sc * (IW >> 2);
+    // pixel ix = 4 sx4 + e sits at element ix + 3 of the padded row: parity (ix + 3) & 1, idx (ix + 3) >> 1
+    const int so1 = (2 * sc + 1) * LP + 2 * (2 * sx4 + 1);  // e = 0, 2: parity 1, idx 2 sx4 + 1, + 2 (two 2-byte stores)
+    const int so0 = (2 * sc) * LP + 2 * (2 * sx4 + 2);      // e = 1, 3: parity 0, idx 2 sx4 + 2, + 3 (one 4-byte store)
+    auto img_issue = [&](f32x4n& v, int& row, int first) {
+        if (stager) {
+            const int iy = first + sj;
+            row = iy;
+            v = f32x4n{0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < IH) v = *reinterpret_cast<const f32x4n*>(p.img + (((size_t)img * 3 + sc) * IH + iy) * IW + 4 * sx4);
+        }
+    };
+    auto img_commit = [&](const f32x4n& v, int row) {
+        if (stager) {
+            char* d = smem + ((row + 4) & (SPL_NS - 1)) * SLOT;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_bf16x3_pair(f32x2_op{v[1], v[3]}, h0, m0, l0);
+            split_bf16x3_pair(f32x2_op{v[0], v[2]}, h1, m1, l1);
+            *reinterpret_cast<unsigned*>(d + so0) = h0;
+            *reinterpret_cast<unsigned*>(d + PL + so0) = m0;
+            *reinterpret_cast<unsigned*>(d + 2 * PL + so0) = l0;
+            *reinterpret_cast<unsigned short*>(d + so1) = (unsigned short)h1;
+            *reinterpret_cast<unsigned short*>(d + so1 + 2) = (unsigned short)(h1 >> 16);
+            *reinterpret_cast<unsigned short*>(d + PL + so1) = (unsigned short)m1;
+            *reinterpret_cast<unsigned short*>(d + PL + so1 + 2) = (unsigned short)(m1 >> 16);
+            *reinterpret_cast<unsigned short*>(d + 2 * PL + so1) = (unsigned short)l1;
+            *reinterpret_cast<unsigned short*>(d + 2 * PL + so1 + 2) = (unsigned short)(l1 >> 16);
+        }
+    };
+
+    // ---- dY chunks of 32 pixels x 128 channels; FUSE: the tables of this thread's channel piece 4 (tid & 31) (wgrad3_stem_kernel<true>)
+    const int cpr = OW / SPL_P;
+    const int nchunks = (r1 - r0) * cpr;
+    f32x4n tS = {0.f, 0.f, 0.f, 0.f}, tH = tS, tE = tS, tD = tS;
+    if (FUSE) {
+        const double invM = 1.0 / p.scount;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (tid & 31) + e;
+            const double mean = p.sstats[c] / p.scount;
+            double var = p.sstats[128 + c] / p.scount - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+            const double scale = (double)p.gamma[c] * istd;
+            const double c1 = p.sred[c] * invM, c2 = p.sred[128 + c] * invM;
+            const double D = scale * c2 * istd;
+            tS[e] = (float)scale;
+            tH[e] = (float)((double)p.beta[c] - mean * scale);
+            tD[e] = (float)D;
+            tE[e] = (float)(D * mean - scale * c1);
+        }
+    }
+    constexpr int NDV = FUSE ? 5 : 2;
+    f32x4n dv[2][NDV];                                     // two chunks of raw loads in flight, sets by chunk parity
+    const int pw = tid >> 5, pc = 4 * (tid & 31);          // FUSE: pooling window pw of the chunk (output columns x0 + 2 pw, + 1); else pixels pw, pw + 16
+    auto issue = [&](auto SET, int ci) {
+        constexpr int S = decltype(SET)::value;
+        const int oy = r0 + ci / cpr;
+        const int x0 = SPL_P * (ci - (ci / cpr) * cpr);
+#ifdef CUNET_SPL_NO_LOADS      // probe builds (timing only, wrong results)
+#pragma unroll
+        for (int u = 0; u < NDV; ++u) dv[S][u] = f32x4n{0.25f * (float)(ci + u), 1.f, -0.5f, 0.125f * (float)x0};
+        return;
+#endif
+        if (FUSE) {
+            const size_t w00 = (((size_t)img * OH + (oy & ~1)) * OW + x0 + 2 * pw) * 128 + pc;
+            dv[S][0] = *reinterpret_cast<const f32x4n*>(p.sx + w00);
+            dv[S][1] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + 128);
+            dv[S][2] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + (size_t)OW * 128);
+            dv[S][3] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + (size_t)OW * 128 + 128);
+            dv[S][NDV - 1] = *reinterpret_cast<const f32x4n*>(p.sgy + (((size_t)img * (OH >> 1) + (oy >> 1)) * (OW >> 1) + (x0 >> 1) + pw) * 128 + pc);
+        } else {
+            const float* src = p.dy + (((size_t)img * OH + oy) * OW + x0) * 128;
+            dv[S][0] = *reinterpret_cast<const f32x4n*>(src + (size_t)pw * 128 + pc);
+            dv[S][1] = *reinterpret_cast<const f32x4n*>(src + (size_t)(pw + 16) * 128 + pc);
+        }
+    };
+    auto put = [&](char* buf, int pixel, const f32x4n& o) {
+        u32x2w h, m, l;
+        wg5_cut4(make_float4(o[0], o[1], o[2], o[3]), h, m, l);
+        char* d = buf + pixel * SPL_APITCH + 2 * pc;
+        *reinterpret_cast<u32x2w*>(d) = h;
+        *reinterpret_cast<u32x2w*>(d + SPL_APLANE) = m;
+        *reinterpret_cast<u32x2w*>(d + 2 * SPL_APLANE) = l;
+    };
+    auto commit = [&](auto SET, int ci, char* buf) {
+        constexpr int S = decltype(SET)::value;
+#ifdef CUNET_SPL_NO_COMMIT     // probe builds (timing only, wrong results)
+        return;
+#endif
+        if (FUSE) {
+            const int f_row = (r0 + ci / cpr) & 1;         // parity of the chunk's output row inside its pooling window
+            f32x4n o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int am = 0;                                // first arg-max of the window, as the forward's pool and stem_bwd_kernel take it
+                float best = fmaxf(fmaf(dv[S][0][e], tS[e], tH[e]), 0.f);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float a = fmaxf(fmaf(dv[S][k][e], tS[e], tH[e]), 0.f);
+                    if (a > best) { best = a; am = k; }
+                }
+                const float g = best > 0.f ? dv[S][NDV - 1][e] : 0.f;
+                const float xa = f_row ? dv[S][2][e] : dv[S][0][e];
+                const float xb = f_row ? dv[S][3][e] : dv[S][1][e];
+                o0[e] = fmaf(-tD[e], xa, fmaf(tS[e], (am == 2 * f_row) ? g : 0.f, tE[e]));
+                o1[e] = fmaf(-tD[e], xb, fmaf(tS[e], (am == 2 * f_row + 1) ? g : 0.f, tE[e]));
+            }
+            put(buf, 2 * pw, o0);
+            put(buf, 2 * pw + 1, o1);
+        } else {
+            put(buf, pw, dv[S][0]);
+            put(buf, pw + 16, dv[S][1]);
+        }
+    };
+
+    const int nt = wave & 3;
+    const int half = wave >> 2;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // this lane's im2col column per k-tile: its line inside a plane (+ the dword the five-dword window starts at), its row offset ky and the byte
+    // shift of the window; columns >= 147 read the zero slot
+    int kline[3], kky[3], ksh[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = (half * 3 + t) * 32 + li;
+        const bool valid = k < STEM_K && (half == 0 || t < 2);
+        const int c = k / 49, rem = k - (k / 49) * 49;
+        const int ky = rem / 7, kx = rem - (rem / 7) * 7;
+        kline[t] = valid ? (2 * c + (kx & 1)) * LP + 4 * (kx >> 2) : 0;
+        kky[t] = valid ? ky : -1;
+        ksh[t] = valid ? 2 * ((kx >> 1) & 1) : 0;
+    }
+    // transpose-read address of this lane inside a dY plane (wgrad5_split_kernel): pixel 8 hi + ((l & 15) >> 2) (+ 4 for the second read),
+    // channel piece 16 ((l >> 4) & 1) + 4 (l & 3) of output-channel tile nt
+    const int off_a = (8 * hi + ((lane & 15) >> 2)) * SPL_APITCH + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + nt * 64;
+
+    // ---- prologue: the first two chunks' loads, rows 2 r0 - 3 ... 2 r0 + 4 (four pairs, all requested before the first is cut)
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if (nchunks > 0) issue(S0{}, 0);
+    if (nchunks > 1) issue(S1{}, 1);
+    {
+        f32x4n iv[4];
+        int ir[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) img_issue(iv[u], ir[u], 2 * r0 - 3 + 2 * u);
+        __syncthreads();                                   // the zeros are in place
+#pragma unroll
+        for (int u = 0; u < 4; ++u) img_commit(iv[u], ir[u]);
+    }
+    if (nchunks > 0) commit(S0{}, 0, abuf0);
+    __syncthreads();
+
+    f32x4n nv = {0.f, 0.f, 0.f, 0.f};                      // the row pair staged for the next output row
+    int nrow = 0;
+    auto contract = [&](auto HF, int ci, const char* cur) {
+        constexpr int CT = StemTiles<decltype(HF)::value>::N;
+        const int oy = r0 + ci / cpr;
+        const int x0 = SPL_P * (ci - (ci / cpr) * cpr);
+        const int rb = 2 * oy + 1;                         // input row 2 oy - 3 + ky lives in slot (2 oy + 1 + ky) & 15
+        const char* bp[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int sl = kky[t] >= 0 ? ((rb + kky[t]) & (SPL_NS - 1)) : SPL_NS;
+            bp[t] = smem + sl * SLOT + kline[t] + (kky[t] >= 0 ? 2 * (x0 + 8 * hi) : 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < SPL_P / 16; ++ks) {
+            const u32x4 ah = wg5_frag(cur + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
+            const u32x4 am = wg5_frag(cur + SPL_APLANE + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
+            const u32x4 al = wg5_frag(cur + 2 * SPL_APLANE + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
+            u32x4 b[CT][3];
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const char* s = bp[t] + pl * PL + 32 * ks;
+                    const u32x2_a4 d01 = *reinterpret_cast<const u32x2_a4*>(s);
+                    const u32x2_a4 d23 = *reinterpret_cast<const u32x2_a4*>(s + 8);
+                    const unsigned d4 = *reinterpret_cast<const unsigned*>(s + 16);
+                    b[t][pl] = u32x4{__builtin_amdgcn_alignbyte(d01.y, d01.x, ksh[t]), __builtin_amdgcn_alignbyte(d23.x, d01.y, ksh[t]),
+                                     __builtin_amdgcn_alignbyte(d23.y, d23.x, ksh[t]), __builtin_amdgcn_alignbyte(d4, d23.y, ksh[t])};
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = mfma_split6(ah, am, al, b[t][0], b[t][1], b[t][2], acc[t]);
+        }
+    };
+    auto step = [&](auto PAR, int ci) {                    // PAR = ci & 1: set PAR held chunk ci (cut already), set PAR ^ 1 holds chunk ci + 1
+        using PN = std::integral_constant<int, decltype(PAR)::value ^ 1>;
+        const int oy = r0 + ci / cpr;
+        const int xq = ci - (ci / cpr) * cpr;
+        const bool stage = oy + 1 < r1;                    // rows 2 oy + 4, 2 oy + 5: the two output row oy + 1 adds
+        if (ci + 2 < nchunks) issue(PAR, ci + 2);
+        if (stage && xq == 0) img_issue(nv, nrow, 2 * oy + 4);
+        const char* cur = abuf0 + decltype(PAR)::value * SPL_ABUF;
+#ifndef CUNET_SPL_NO_MMA       // probe builds (timing only, wrong results)
+        if (half == 0) contract(std::integral_constant<int, 0>{}, ci, cur);
+        else contract(std::integral_constant<int, 1>{}, ci, cur);
+#endif
+        // (the two waves of a SIMD walking a step in opposite order -- one contracts while the other cuts the next chunk -- measured 156 us against
+        // 144: the wave that cuts first waits for loads requested one step earlier)
+        if (ci + 1 < nchunks) commit(PN{}, ci + 1, abuf0 + PN::value * SPL_ABUF);
+        if (stage && xq == cpr - 1) img_commit(nv, nrow);
+        __syncthreads();
+    };
+    for (int ci = 0; ci < nchunks; ci += 2) {
+        step(S0{}, ci);
+        if (ci + 1 < nchunks) step(S1{}, ci + 1);
+    }
+
+    float* out = q.part + (size_t)blockIdx.x * 128 * STEM_K;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = (half * 3 + t) * 32 + li;
+        if (k >= STEM_K || (half == 1 && t == 2)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)n * STEM_K + k] = acc[t][r];
+        }
+    }
+}
+size_t wgrad3_stem_planes_lds_bytes(int IW) { return (size_t)(SPL_NS + 1) * 18 * (IW + 8) + 2 * SPL_ABUF; }
+bool wgrad3_stem_planes_supported(const WgradArgs& a) {
+    if (a.img == nullptr || a.Cout != 128 || a.lddy != 128 || a.Ccat != STEM_K) return false;
+    if (a.W % SPL_P || a.IW % 8 || a.IW != 2 * a.W || a.IH != 2 * a.H || 6 * (a.IW / 4) > WG3_THREADS) return false;
+    return wgrad3_stem_planes_lds_bytes(a.IW) <= 160 * 1024;
+}
+
 // rows: output rows per workgroup; wpi: workgroups per image (wpi * rows >= OH); part: [N * wpi][128][147]
 size_t wgrad3_stem_lds_bytes(int IW, int rows) {
     return (size_t)((((2 * rows + 6) * stem_rp(IW) + 3) & ~3) + STEM_CHUNK * 128) * 4;
@@ -1924,8 +2208,22 @@ hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows
     q.rows_per_split = rows;
     q.c0 = wpi;
     const int N = a.M / (a.H * a.W);
+    if (a.sx != nullptr && (a.sgy == nullptr || a.sstats == nullptr || a.sred == nullptr || a.gamma == nullptr || a.beta == nullptr || (a.H & 1))) return hipErrorInvalidValue;
+    if (a.split && a.split_planes && wgrad3_stem_planes_supported(a)) {      // both operands cut once (planner option stem_wgrad_planes)
+        static bool planes_attr_done = false;
+        if (!planes_attr_done) {
+            const void* pf[2] = {(const void*)&wgrad3_stem_planes_kernel<false>, (const void*)&wgrad3_stem_planes_kernel<true>};
+            for (const void* f : pf) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
+            planes_attr_done = true;
+        }
+        if (a.sx != nullptr) hipLaunchKernelGGL((wgrad3_stem_planes_kernel<true>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_planes_lds_bytes(a.IW), s, q);
+        else hipLaunchKernelGGL((wgrad3_stem_planes_kernel<false>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_planes_lds_bytes(a.IW), s, q);
+        return hipGetLastError();
+    }
     if (a.sx != nullptr) {
-        if (a.sgy == nullptr || a.sstats == nullptr || a.sred == nullptr || a.gamma == nullptr || a.beta == nullptr || (a.H & 1)) return hipErrorInvalidValue;
         if (a.split) hipLaunchKernelGGL((wgrad3_stem_kernel<true, true>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
         else hipLaunchKernelGGL((wgrad3_stem_kernel<true, false>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_lds_bytes(a.IW, rows), s, q);
     } else {

@@ -700,6 +700,53 @@ def test_stem_weight_gradient_with_the_dz_pass_fused(n, h, w):
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize('n,h,w', [(24, 256, 256), (3, 128, 256), (2, 256, 128), (1, 128, 128)])
+def test_stem_weight_gradient_with_both_operands_cut_once_is_bit_identical(n, h, w):
+    """wgrad3_stem_planes_kernel (round 6, planner option stem_wgrad_planes): the image rows in an LDS ring of three bf16 planes de-interleaved by
+    column parity, the dY chunk cut behind the fused BatchNorm / ReLU / pool backward into three planes read by ds_read_b64_tr_b16 -- against
+    wgrad3_stem_kernel<*, true> (fp32 rows and chunk in LDS, every wave cuts what it reads) on the SAME plan state: the same pieces enter the same six
+    products in the same pixel order over the same rows per workgroup, so conv0's weight gradient (autograd wgrad of models/cu_net.py:300) must
+    agree bit for bit -- the fused kernel of a real backward pass (planes) == the unfused planes kernel on the materialised d(loss)/d(conv0 output)
+    == the unfused staging kernel on the same tensor.  The bench batch, rectangular batches (2 / 4 chunks per output row, ragged last workgroup of
+    an image) and one small image."""
+    from oracle import cunet_ref as O
+    cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
+    spec = O.Spec(**cfg)
+    st = O.init_state(spec, seed=111)
+    gen = torch.Generator().manual_seed(112)
+    x = torch.rand(n, 3, h, w, generator=gen) * 2.0 - 0.7
+    target = torch.rand(n, 16, h // 4, w // 4, generator=gen)
+    net = cu_net_amd.create_cu_net(**cfg)
+    net.load_state_dict(st)
+    net = net.cuda().train()
+    plan = net._get_plan(n, h, w, True)
+    d = plan.handle.describe()
+    assert d['nodes'][0]['op'] == 'stem_conv' and d['nodes'][0]['wg3'] > 0
+    o, nmel = {name: (o, nmel) for name, kind, shape, o, nmel in net._entries if kind == 0}['features.conv0.weight']
+    try:
+        plan.debug_set_option('stem_wgrad_planes', 1)
+        plan.stage_target(target.cuda())
+        plan.forward(x.cuda(), True, want_outputs=False)
+        plan.backward(None)
+        torch.cuda.synchronize()
+        fused = net._grad_arena[o:o + nmel].clone()
+        assert float(fused.abs().max()) > 0 and torch.isfinite(fused).all()
+        conv0_out = [t['name'] for t in d['tensors'] if t['id'] == d['nodes'][0]['out']][0]
+        plan.debug_tensor(conv0_out, grad=True)                  # materialises d(loss)/d(conv0 output) from the state the backward left
+        got = {}
+        for planes in (1, 0):
+            plan.debug_set_option('stem_wgrad_planes', planes)
+            plan.debug_run_node_backward(0)                          # the UNFUSED kernels on the materialised tensor (zeroes the arena first)
+            torch.cuda.synchronize()
+            got[planes] = net._grad_arena[o:o + nmel].clone()
+    finally:
+        plan.debug_set_option('stem_wgrad_planes', 0)
+    for name, g in (('unfused planes', got[1]), ('fused planes', fused)):
+        if not torch.equal(g, got[0]):
+            dd = (g - got[0]).abs()
+            raise AssertionError(f'{name}: {int((dd > 0).sum())}/{nmel} elements differ from the staging kernel, max {float(dd.max()):.3e} of {float(got[0].abs().max()):.3e}')
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16_grads'])
 def test_pool_backward_fused_with_the_gathers_around_it(mode):
     """Round 6, planner option fuse_pool_gather (default 1): in front of a down block's adapter pair backward runs gather(pool output) ->
