@@ -85,7 +85,7 @@ struct Node {
     int64_t wg3_part = -1;
 };
 
-struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 0, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 128, wgrad3_stem = 1, conv3x3_ring_min_rows = 512, wgrad_fork_group = 0, wgrad_fork_group_bf16 = 8, fwd_fork_min_w = 0, pair_adapters = 1, heads_on_side = 2, dgrad_nt = 4, wgrad_bf16_dma = 1, fuse_wgrad = 0, dgrad_prefetch = 1, dgrad_rows = -1, f32_split = 1, dgrad3_nt = 1, dgrad3_ring = 768, stem_split = 1, dgrad_rows_v = 2, popcount_pixels = 1, stem_fuse_dz = 1, stem_wgrad_split = 1, fuse_pool_gather = 1, fuse_z_gather = 0, stem_wgrad_caller = 0, wgrad_split_planes = 0, stem_wgrad_planes = 0; };
+struct PlannerOptions { int wgrad3_min_rows = 0, wgrad3_min_chunks = 2, wgrad3_max_splits = 0, wgrad3_min_chunks_bf16 = 4, wgrad3_max_splits_bf16 = 128, wgrad3_stem = 1, conv3x3_ring_min_rows = 512, wgrad_fork_group = 0, wgrad_fork_group_bf16 = 8, fwd_fork_min_w = 0, pair_adapters = 1, heads_on_side = 2, dgrad_nt = 4, wgrad_bf16_dma = 1, fuse_wgrad = 0, dgrad_prefetch = 1, dgrad_rows = -1, f32_split = 1, dgrad3_nt = 1, dgrad3_ring = 768, stem_split = 1, dgrad_rows_v = 2, popcount_pixels = 1, stem_fuse_dz = 1, stem_wgrad_split = 1, fuse_pool_gather = 1, fuse_z_gather = 0, stem_wgrad_caller = 0, wgrad_split_planes = 0, stem_wgrad_planes = 1; };
 PlannerOptions& planner_options();
 
 struct Plan {

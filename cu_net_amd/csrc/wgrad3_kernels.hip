@@ -1897,27 +1897,43 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_kernel(const Wg3Ar
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Round 6 (planner option stem_wgrad_planes, acts with f32_split + stem_wgrad_split): the stem's weight gradient with BOTH operands cut once.
-// wgrad3_stem_kernel<*, EMU> keeps the image rows and the dY chunk as fp32 in LDS and every wave cuts the fragments it reads: an image element
-// ends up cut ~49 times (12 (tap, pixel) pairs x 4 output-channel waves), ~256 VALU instructions per wave and 16-pixel k-step next to 18 MFMAs
-// -- the kernel, the last of a step and alone on the GPU, is VALU-bound at 150 us against 42 us of matrix pipe.  Here
+// Round 6 (planner option stem_wgrad_planes, acts with f32_split + stem_wgrad_split): the stem's weight gradient with BOTH operands cut once and
+// the work of a workgroup split by ROLE.  wgrad3_stem_kernel<*, EMU> keeps the image rows and the dY chunk as fp32 in LDS and every wave cuts the
+// fragments it reads (an image element ends up cut ~49 times: 12 (tap, pixel) pairs x 4 output-channel waves; ~256 VALU instructions per wave and
+// 16-pixel k-step next to 18 MFMAs), and all eight waves walk the same phases in lock-step -- requests, cut, MFMAs, barrier -- so the matrix pipe
+// of a SIMD waits while its two waves cut and the VALU waits while they multiply: 150-160 us, alone on the GPU at the end of every step, against
+// 42 us of matrix pipe.  Here
 //   * the image rows live in a RING of 16 row slots as three bf16 planes, de-interleaved by column parity (a stride-2 tap walks consecutive
 //     elements of one parity line): line (c, kx & 1) holds element idx = ox + (kx >> 1) of the 3 + IW + 3 padded row at byte 2 idx.  A lane's
 //     8 pixels of one plane are 5 dwords (ds_read2_b32 x 2 + ds_read_b32 at byte 2 (x0 + p0) + 4 (kx >> 2)) and four v_alignbyte_b32 by
-//     2 ((kx >> 1) & 1) bytes; line pitch IW + 8 bytes (= 2 mod 4 dwords: the 32 im2col columns of a tile fall into different banks);
-//     two rows are staged per output row (one float4 per thread, cut on its way in), zero rows / borders are zeros in the planes;
-//   * the dY chunk (32 pixels, two buffers: ONE barrier per chunk, the next chunk's cut runs beside the other waves' MFMAs) is cut on its way in,
-//     behind the fused BatchNorm / ReLU / pool backward, into three planes of wgrad4's row layout and read by ds_read_b64_tr_b16 (wg5_frag).
-// Same pieces, same six products, same pixel order and the same rows per workgroup as wgrad3_stem_kernel<*, true>: bit-identical partial tiles.
-constexpr int SPL_NS = 16;                                 // ring slots: 7 rows under contraction + 2 being staged, a power of two
+//     2 ((kx >> 1) & 1) bytes; line pitch IW + 8 bytes (= 2 mod 4 dwords: the 32 im2col columns of a tile fall into different banks: SQ_LDS_BANK_CONFLICT
+//     5 % of the LDS cycles); zero rows / borders are zeros in the planes;
+//   * the dY chunk (32 pixels, two buffers, ONE barrier per chunk) is cut on its way in, behind the fused BatchNorm / ReLU / pool backward, into three
+//     planes of wgrad4's row layout and read by ds_read_b64_tr_b16 (wg5_frag);
+//   * waves 0-3 (one per SIMD) are CONSUMERS: wave w owns output-channel tile w and all five im2col tiles, and does nothing but fragment reads and
+//     MFMAs -- the matrix pipe of its SIMD has one client that keeps it fed back to back; waves 4-7 are PRODUCERS: global loads, the dz arithmetic, the
+//     cuts and the LDS stores of the NEXT chunk and of the image rows of the next output-row pair -- pure VALU / memory work beside the other wave's MFMAs;
+//   * chunks are walked by pooling-window row PAIR (row 2m and 2m + 1 of one 32-column block back to back): conv0's output and the pooled gradient are
+//     requested once per window instead of once per output row (490 -> ~270 MB per launch), two blocks ahead of their cut.
+// Same pieces and the same six products per pair as wgrad3_stem_kernel<*, true>, the same rows per workgroup and partial-tile layout; the order in which
+// a workgroup's pixels enter the fp32 accumulators differs (row pairs): agreement to fp32 summation order, not bit for bit (tests/test_gpu_exact.py).
+constexpr int SPL_NS = 16;                                 // ring slots: 9 rows under contraction + 4 being staged, a power of two
 constexpr int SPL_P = 32;                                  // output pixels per dY chunk
 constexpr int SPL_APITCH = 320;                            // bytes per pixel row of a dY plane (128 bf16 + 64: an odd multiple of 64)
 constexpr int SPL_APLANE = SPL_P * SPL_APITCH;
 constexpr int SPL_ABUF = 3 * SPL_APLANE;
+constexpr int SPL_THREADS = 512;                           // 8 waves, two per SIMD: a consumer and a producer
+constexpr int SPL_CONS = 256;                              // consumer threads (waves 0-3)
+constexpr int SPL_PROD = SPL_THREADS - SPL_CONS;           // producer threads (waves 4-7)
+#ifndef SPL_CONS_PRIO
+#define SPL_CONS_PRIO 2
+#endif
 typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
+struct SplCursor { int m, lo, nr, xb, j; };                // output-row pair, its first row / row count inside the workgroup's range, column block, row index
+
 template <bool FUSE>
-__global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_planes_kernel(const Wg3Args q) {
+__global__ __launch_bounds__(SPL_THREADS, 1) void wgrad3_stem_planes_kernel(const Wg3Args q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float f32x4n __attribute__((ext_vector_type(4)));
     const WgradArgs& p = q.w;
@@ -1938,144 +1954,296 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_planes_kernel(cons
     const int r0 = (blockIdx.x - img * wpi) * rows;
     int r1 = r0 + rows;
     if (r1 > OH) r1 = OH;
+    const int cpr = OW / SPL_P;
+    const int nchunks = r1 > r0 ? (r1 - r0) * cpr : 0;
+    const bool producer = wave >= SPL_CONS / 64;
 
-    for (int i = tid * 16; i < (SPL_NS + 1) * SLOT; i += WG3_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid * 16; i < (SPL_NS + 1) * SLOT; i += SPL_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0u, 0u, 0u, 0u);
 
-    // ---- image rows: a thread stages one float4 of a row PAIR (2 rows x 3 channels x IW / 4 <= 512 items)
+    // ---- the chunk sequence: pairs m = r0 >> 1 ..., of a pair the rows inside [r0, r1), column blocks of 32 pixels; per block the rows back to back
+    auto cur_init = [&](SplCursor& c) {
+        c.m = r0 >> 1; c.lo = r0; c.nr = (r1 < 2 * c.m + 2 ? r1 : 2 * c.m + 2) - c.lo; c.xb = 0; c.j = 0;
+    };
+    auto cur_next = [&](SplCursor& c) -> bool {            // true: the next chunk opens a new block
+        if (++c.j < c.nr) return false;
+        c.j = 0;
+        if (++c.xb == cpr) { c.xb = 0; ++c.m; c.lo = 2 * c.m; c.nr = (r1 < 2 * c.m + 2 ? r1 : 2 * c.m + 2) - c.lo; }
+        return true;
+    };
+
+    // ---- image rows: item i of a row PAIR is one float4 (2 rows x 3 channels x IW / 4 items); pixel ix = 4 sx4 + e sits at element ix + 3 of the
+    // padded row: parity (ix + 3) & 1, idx (ix + 3) >> 1
     const int per_row = 3 * (IW >> 2);
-    const bool stager = tid < 2 * per_row;
-    const int sj = tid / per_row;
-    const int sc = (tid - sj * per_row) / (IW >> 2);
-    const int sx4 = (tid - sj * per_row) - sc * (IW >> 2);
-    // pixel ix = 4 sx4 + e sits at element ix + 3 of the padded row: parity (ix + 3) & 1, idx (ix + 3) >> 1
-    const int so1 = (2 * sc + 1) * LP + 2 * (2 * sx4 + 1);  // e = 0, 2: parity 1, idx 2 sx4 + 1, + 2 (two 2-byte stores)
-    const int so0 = (2 * sc) * LP + 2 * (2 * sx4 + 2);      // e = 1, 3: parity 0, idx 2 sx4 + 2, + 3 (one 4-byte store)
-    auto img_issue = [&](f32x4n& v, int& row, int first) {
-        if (stager) {
-            const int iy = first + sj;
+    struct Item { bool ok; int sj, so0, so1; unsigned g; };
+    auto make_item = [&](int i) {
+        Item it;
+        it.ok = i < 2 * per_row;
+        const int ii = it.ok ? i : 0;
+        it.sj = ii / per_row;
+        const int sc = (ii - it.sj * per_row) / (IW >> 2);
+        const int sx4 = (ii - it.sj * per_row) - sc * (IW >> 2);
+        it.so1 = (2 * sc + 1) * LP + 2 * (2 * sx4 + 1);     // e = 0, 2: parity 1, idx 2 sx4 + 1, + 2 (two 2-byte stores)
+        it.so0 = (2 * sc) * LP + 2 * (2 * sx4 + 2);         // e = 1, 3: parity 0, idx 2 sx4 + 2, + 3 (one 4-byte store)
+        it.g = 4u * (unsigned)((sc * IH + it.sj) * IW + 4 * sx4);      // bytes from the image's row `first` (uniform base + 32-bit lane offset)
+        return it;
+    };
+    const char* img_base = reinterpret_cast<const char*>(p.img + (size_t)img * 3 * IH * IW);
+    auto img_issue = [&](const Item& it, f32x4n& v, int& row, int first) {
+        if (it.ok) {
+            const int iy = first + it.sj;
             row = iy;
             v = f32x4n{0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < IH) v = *reinterpret_cast<const f32x4n*>(p.img + (((size_t)img * 3 + sc) * IH + iy) * IW + 4 * sx4);
+            if (iy >= 0 && iy < IH) v = *reinterpret_cast<const f32x4n*>(img_base + (ptrdiff_t)first * IW * 4 + it.g);
         }
     };
-    auto img_commit = [&](const f32x4n& v, int row) {
-        if (stager) {
+    auto img_commit = [&](const Item& it, const f32x4n& v, int row) {
+        if (it.ok) {
             char* d = smem + ((row + 4) & (SPL_NS - 1)) * SLOT;
             unsigned h0, m0, l0, h1, m1, l1;
             split_bf16x3_pair(f32x2_op{v[1], v[3]}, h0, m0, l0);
             split_bf16x3_pair(f32x2_op{v[0], v[2]}, h1, m1, l1);
-            *reinterpret_cast<unsigned*>(d + so0) = h0;
-            *reinterpret_cast<unsigned*>(d + PL + so0) = m0;
-            *reinterpret_cast<unsigned*>(d + 2 * PL + so0) = l0;
-            *reinterpret_cast<unsigned short*>(d + so1) = (unsigned short)h1;
-            *reinterpret_cast<unsigned short*>(d + so1 + 2) = (unsigned short)(h1 >> 16);
-            *reinterpret_cast<unsigned short*>(d + PL + so1) = (unsigned short)m1;
-            *reinterpret_cast<unsigned short*>(d + PL + so1 + 2) = (unsigned short)(m1 >> 16);
-            *reinterpret_cast<unsigned short*>(d + 2 * PL + so1) = (unsigned short)l1;
-            *reinterpret_cast<unsigned short*>(d + 2 * PL + so1 + 2) = (unsigned short)(l1 >> 16);
+            *reinterpret_cast<unsigned*>(d + it.so0) = h0;
+            *reinterpret_cast<unsigned*>(d + PL + it.so0) = m0;
+            *reinterpret_cast<unsigned*>(d + 2 * PL + it.so0) = l0;
+            *reinterpret_cast<unsigned short*>(d + it.so1) = (unsigned short)h1;
+            *reinterpret_cast<unsigned short*>(d + it.so1 + 2) = (unsigned short)(h1 >> 16);
+            *reinterpret_cast<unsigned short*>(d + PL + it.so1) = (unsigned short)m1;
+            *reinterpret_cast<unsigned short*>(d + PL + it.so1 + 2) = (unsigned short)(m1 >> 16);
+            *reinterpret_cast<unsigned short*>(d + 2 * PL + it.so1) = (unsigned short)l1;
+            *reinterpret_cast<unsigned short*>(d + 2 * PL + it.so1 + 2) = (unsigned short)(l1 >> 16);
         }
     };
-
-    // ---- dY chunks of 32 pixels x 128 channels; FUSE: the tables of this thread's channel piece 4 (tid & 31) (wgrad3_stem_kernel<true>)
-    const int cpr = OW / SPL_P;
-    const int nchunks = (r1 - r0) * cpr;
-    f32x4n tS = {0.f, 0.f, 0.f, 0.f}, tH = tS, tE = tS, tD = tS;
-    if (FUSE) {
-        const double invM = 1.0 / p.scount;
+    // prologue, every thread: rows 4 m0 - 3 ... 4 m0 + 6 (five pairs: what the first output-row pair reads), all requested before the first is cut
+    if (nchunks > 0) {
+        const Item it = make_item(tid);
+        f32x4n iv[5];
+        int ir[5];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * (tid & 31) + e;
-            const double mean = p.sstats[c] / p.scount;
-            double var = p.sstats[128 + c] / p.scount - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
-            const double scale = (double)p.gamma[c] * istd;
-            const double c1 = p.sred[c] * invM, c2 = p.sred[128 + c] * invM;
-            const double D = scale * c2 * istd;
-            tS[e] = (float)scale;
-            tH[e] = (float)((double)p.beta[c] - mean * scale);
-            tD[e] = (float)D;
-            tE[e] = (float)(D * mean - scale * c1);
-        }
+        for (int u = 0; u < 5; ++u) img_issue(it, iv[u], ir[u], 4 * (r0 >> 1) - 3 + 2 * u);
+        __syncthreads();                                   // the zeros are in place
+#pragma unroll
+        for (int u = 0; u < 5; ++u) img_commit(it, iv[u], ir[u]);
+    } else {
+        __syncthreads();
     }
-    constexpr int NDV = FUSE ? 5 : 2;
-    f32x4n dv[2][NDV];                                     // two chunks of raw loads in flight, sets by chunk parity
-    const int pw = tid >> 5, pc = 4 * (tid & 31);          // FUSE: pooling window pw of the chunk (output columns x0 + 2 pw, + 1); else pixels pw, pw + 16
-    auto issue = [&](auto SET, int ci) {
-        constexpr int S = decltype(SET)::value;
-        const int oy = r0 + ci / cpr;
-        const int x0 = SPL_P * (ci - (ci / cpr) * cpr);
-#ifdef CUNET_SPL_NO_LOADS      // probe builds (timing only, wrong results)
-#pragma unroll
-        for (int u = 0; u < NDV; ++u) dv[S][u] = f32x4n{0.25f * (float)(ci + u), 1.f, -0.5f, 0.125f * (float)x0};
-        return;
-#endif
-        if (FUSE) {
-            const size_t w00 = (((size_t)img * OH + (oy & ~1)) * OW + x0 + 2 * pw) * 128 + pc;
-            dv[S][0] = *reinterpret_cast<const f32x4n*>(p.sx + w00);
-            dv[S][1] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + 128);
-            dv[S][2] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + (size_t)OW * 128);
-            dv[S][3] = *reinterpret_cast<const f32x4n*>(p.sx + w00 + (size_t)OW * 128 + 128);
-            dv[S][NDV - 1] = *reinterpret_cast<const f32x4n*>(p.sgy + (((size_t)img * (OH >> 1) + (oy >> 1)) * (OW >> 1) + (x0 >> 1) + pw) * 128 + pc);
-        } else {
-            const float* src = p.dy + (((size_t)img * OH + oy) * OW + x0) * 128;
-            dv[S][0] = *reinterpret_cast<const f32x4n*>(src + (size_t)pw * 128 + pc);
-            dv[S][1] = *reinterpret_cast<const f32x4n*>(src + (size_t)(pw + 16) * 128 + pc);
-        }
-    };
-    auto put = [&](char* buf, int pixel, const f32x4n& o) {
-        u32x2w h, m, l;
-        wg5_cut4(make_float4(o[0], o[1], o[2], o[3]), h, m, l);
-        char* d = buf + pixel * SPL_APITCH + 2 * pc;
-        *reinterpret_cast<u32x2w*>(d) = h;
-        *reinterpret_cast<u32x2w*>(d + SPL_APLANE) = m;
-        *reinterpret_cast<u32x2w*>(d + 2 * SPL_APLANE) = l;
-    };
-    auto commit = [&](auto SET, int ci, char* buf) {
-        constexpr int S = decltype(SET)::value;
-#ifdef CUNET_SPL_NO_COMMIT     // probe builds (timing only, wrong results)
-        return;
-#endif
-        if (FUSE) {
-            const int f_row = (r0 + ci / cpr) & 1;         // parity of the chunk's output row inside its pooling window
-            f32x4n o0, o1;
+
+    if (producer) {
+        // ================= producers: loads, dz arithmetic, cuts, LDS stores -- one chunk ahead of the consumers =================
+        const int tp = tid - SPL_CONS;
+        const int pw = tp >> 5, pc = 4 * (tp & 31);        // FUSE: pooling windows pw, pw + 8 of a block; else pixels pw + 8 i of a row
+        f32x4n tS = {0.f, 0.f, 0.f, 0.f}, tH = tS, tE = tS, tD = tS;
+        if (FUSE) {                                        // tables of this thread's channel piece (wgrad3_stem_kernel<true>, operation for operation)
+            const double invM = 1.0 / p.scount;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int am = 0;                                // first arg-max of the window, as the forward's pool and stem_bwd_kernel take it
-                float best = fmaxf(fmaf(dv[S][0][e], tS[e], tH[e]), 0.f);
-#pragma unroll
-                for (int k = 1; k < 4; ++k) {
-                    const float a = fmaxf(fmaf(dv[S][k][e], tS[e], tH[e]), 0.f);
-                    if (a > best) { best = a; am = k; }
-                }
-                const float g = best > 0.f ? dv[S][NDV - 1][e] : 0.f;
-                const float xa = f_row ? dv[S][2][e] : dv[S][0][e];
-                const float xb = f_row ? dv[S][3][e] : dv[S][1][e];
-                o0[e] = fmaf(-tD[e], xa, fmaf(tS[e], (am == 2 * f_row) ? g : 0.f, tE[e]));
-                o1[e] = fmaf(-tD[e], xb, fmaf(tS[e], (am == 2 * f_row + 1) ? g : 0.f, tE[e]));
+                const int c = pc + e;
+                const double mean = p.sstats[c] / p.scount;
+                double var = p.sstats[128 + c] / p.scount - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+                const double scale = (double)p.gamma[c] * istd;
+                const double c1 = p.sred[c] * invM, c2 = p.sred[128 + c] * invM;
+                const double D = scale * c2 * istd;
+                tS[e] = (float)scale;
+                tH[e] = (float)((double)p.beta[c] - mean * scale);
+                tD[e] = (float)D;
+                tE[e] = (float)(D * mean - scale * c1);
             }
-            put(buf, 2 * pw, o0);
-            put(buf, 2 * pw + 1, o1);
-        } else {
-            put(buf, pw, dv[S][0]);
-            put(buf, pw + 16, dv[S][1]);
         }
-    };
-
-    const int nt = wave & 3;
-    const int half = wave >> 2;
-    f32x16 acc[3];
+        constexpr int NDV = FUSE ? 5 : 4;
+        f32x4n ds[2][2][NDV];                              // [set][window | row of the block][FUSE: 4 x pieces + pooled gradient | pixel pw + 8 i]: two blocks in flight
+        f32x4n tc[2][2];                                   // FUSE: [window][pixel] S * (routed gradient) + E of the window's SECOND row, kept from the first row's pass
+        // lane offsets (bytes, constant over the kernel) from the uniform base of a block: FUSE: window pw + 8 w of conv0's output row 2 m and of the pooled
+        // gradient's row m; else pixel pw of a dY row
+        unsigned offx[2], offg[2];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+        for (int w = 0; w < 2; ++w) {
+            offx[w] = 4u * (unsigned)(2 * (pw + 8 * w) * 128 + pc);
+            offg[w] = 4u * (unsigned)((pw + 8 * w) * 128 + pc);
+        }
+        auto load_block = [&](auto SET, int m, int xb) {
+            constexpr int S = decltype(SET)::value;
+            const int x0 = SPL_P * xb;
+#ifdef CUNET_SPL_NO_LOADS      // probe builds (timing only, wrong results)
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int u = 0; u < NDV; ++u) ds[S][w][u] = f32x4n{0.25f * (float)(m + u), 1.f, -0.5f, 0.125f * (float)x0};
+            return;
+#endif
+            if (FUSE) {
+                const char* r0p = reinterpret_cast<const char*>(p.sx + (((size_t)img * OH + 2 * m) * OW + x0) * 128);
+                const char* r1p = r0p + (size_t)OW * 512;
+                const char* gp = reinterpret_cast<const char*>(p.sgy + (((size_t)img * (OH >> 1) + m) * (OW >> 1) + (x0 >> 1)) * 128);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    ds[S][w][0] = *reinterpret_cast<const f32x4n*>(r0p + offx[w]);
+                    ds[S][w][1] = *reinterpret_cast<const f32x4n*>(r0p + offx[w] + 512);
+                    ds[S][w][2] = *reinterpret_cast<const f32x4n*>(r1p + offx[w]);
+                    ds[S][w][3] = *reinterpret_cast<const f32x4n*>(r1p + offx[w] + 512);
+                    ds[S][w][NDV - 1] = *reinterpret_cast<const f32x4n*>(gp + offg[w]);
+                }
+            } else {
+                const int lo = 2 * m < r0 ? r0 : 2 * m;
+                const int hiq = 2 * m + 2 > r1 ? r1 : 2 * m + 2;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int oy = lo + w < hiq ? lo + w : lo;     // (a block of one row: the same row twice)
+                    const char* src = reinterpret_cast<const char*>(p.dy + (((size_t)img * OH + oy) * OW + x0) * 128);
+#pragma unroll
+                    for (int u = 0; u < NDV; ++u) ds[S][w][u] = *reinterpret_cast<const f32x4n*>(src + offg[0] + 4096u * u);
+                }
+            }
+        };
+        auto put = [&](char* buf, int pixel, const f32x4n& o) {
+            u32x2w h, m, l;
+            wg5_cut4(make_float4(o[0], o[1], o[2], o[3]), h, m, l);
+            char* d = buf + pixel * SPL_APITCH + 2 * pc;
+            *reinterpret_cast<u32x2w*>(d) = h;
+            *reinterpret_cast<u32x2w*>(d + SPL_APLANE) = m;
+            *reinterpret_cast<u32x2w*>(d + 2 * SPL_APLANE) = l;
+        };
+        // the FIRST row of a block inside the workgroup's range (row parity F inside its pooling windows; F = 1: a range that starts on an odd row).
+        // dz = A * (own the max and it is positive ? g : 0) + E - D * x, the arithmetic of stem_bwd_kernel<1> operation for operation; F = 0 also leaves
+        // S * (routed gradient) + E of the windows' second row for commit_second.
+        auto commit_first = [&](auto SET, auto FR, char* buf) {
+            constexpr int S = decltype(SET)::value;
+            constexpr int F = decltype(FR)::value;
+#ifdef CUNET_SPL_NO_COMMIT     // probe builds (timing only, wrong results)
+            return;
+#endif
+            if (FUSE) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    f32x4n o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int am = 0;                        // first arg-max of the window, as the forward's pool and stem_bwd_kernel take it
+                        float best = fmaxf(fmaf(ds[S][w][0][e], tS[e], tH[e]), 0.f);
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) {
+                            const float a = fmaxf(fmaf(ds[S][w][k][e], tS[e], tH[e]), 0.f);
+                            if (a > best) { best = a; am = k; }
+                        }
+                        const float g = best > 0.f ? ds[S][w][NDV - 1][e] : 0.f;
+                        o0[e] = fmaf(-tD[e], ds[S][w][2 * F][e], fmaf(tS[e], (am == 2 * F) ? g : 0.f, tE[e]));
+                        o1[e] = fmaf(-tD[e], ds[S][w][2 * F + 1][e], fmaf(tS[e], (am == 2 * F + 1) ? g : 0.f, tE[e]));
+                        if (F == 0) {
+                            tc[w][0][e] = fmaf(tS[e], (am == 2) ? g : 0.f, tE[e]);
+                            tc[w][1][e] = fmaf(tS[e], (am == 3) ? g : 0.f, tE[e]);
+                        }
+                    }
+                    put(buf, 2 * (pw + 8 * w), o0);
+                    put(buf, 2 * (pw + 8 * w) + 1, o1);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NDV; ++u) put(buf, pw + 8 * u, ds[S][0][u]);
+            }
+        };
+        auto commit_second = [&](auto SET, char* buf) {     // the second row of a block of two
+            constexpr int S = decltype(SET)::value;
+#ifdef CUNET_SPL_NO_COMMIT     // probe builds (timing only, wrong results)
+            return;
+#endif
+            if (FUSE) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    f32x4n o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = fmaf(-tD[e], ds[S][w][2][e], tc[w][0][e]);
+                        o1[e] = fmaf(-tD[e], ds[S][w][3][e], tc[w][1][e]);
+                    }
+                    put(buf, 2 * (pw + 8 * w), o0);
+                    put(buf, 2 * (pw + 8 * w) + 1, o1);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NDV; ++u) put(buf, pw + 8 * u, ds[S][1][u]);
+            }
+        };
+        // the image rows of the NEXT output-row pair: rows 4 m + 7 ... 4 m + 10 beyond what the prologue / the last pair staged (items tp, tp + 256 of
+        // two row pairs), requested at a pair's first step and cut at its last
+        const Item itA = make_item(tp), itB = make_item(tp + SPL_PROD);
+        f32x4n nv[4] = {};
+        int nrow[4] = {0, 0, 0, 0};
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+
+        if (nchunks > 0) {
+            int m = r0 >> 1, xb = 0;                       // the block whose chunks the consumers walk
+            int mL = m, xbL = 0;                           // block cursor of the loads
+            auto blk_next = [&](int& mm, int& xx) { if (++xx == cpr) { xx = 0; ++mm; } };
+            load_block(S0{}, mL, xbL);
+            blk_next(mL, xbL);
+            if (2 * mL < r1) load_block(S1{}, mL, xbL);
+            blk_next(mL, xbL);                             // (mL, xbL) = block 2: the next one to request
+            if (r0 & 1) commit_first(S0{}, S1{}, abuf0);
+            else commit_first(S0{}, S0{}, abuf0);
+            __syncthreads();
+            int wb = 1;                                    // dY buffer the next cut goes to
+            // one block: its first chunk is being contracted when the body starts; SET holds its loads, SET ^ 1 the next block's
+            auto block = [&](auto SET) {
+                using SN = std::integral_constant<int, decltype(SET)::value ^ 1>;
+                const int lo = 2 * m < r0 ? r0 : 2 * m;
+                const int nr = (2 * m + 2 > r1 ? r1 : 2 * m + 2) - lo;
+                const bool stage = 2 * (m + 1) < r1;       // another pair follows: its four new rows 4 m + 7 ... 4 m + 10
+                if (stage && xb == 0) {
+                    img_issue(itA, nv[0], nrow[0], 4 * m + 7);
+                    img_issue(itB, nv[1], nrow[1], 4 * m + 7);
+                    img_issue(itA, nv[2], nrow[2], 4 * m + 9);
+                    img_issue(itB, nv[3], nrow[3], 4 * m + 9);
+                }
+                if (nr == 2) {
+                    commit_second(SET, abuf0 + wb * SPL_ABUF);
+                    wb ^= 1;
+                    __syncthreads();                       // the block's second chunk is being contracted now
+                }
+                int mn = m, xn = xb;
+                blk_next(mn, xn);
+                const bool have_next = 2 * mn < r1;
+                if (2 * mL < r1) load_block(SET, mL, xbL);     // SET has served its block: the block after the next one
+                blk_next(mL, xbL);
+                if (have_next) {
+                    if ((2 * mn < r0 ? r0 : 2 * mn) & 1) commit_first(SN{}, S1{}, abuf0 + wb * SPL_ABUF);
+                    else commit_first(SN{}, S0{}, abuf0 + wb * SPL_ABUF);
+                    wb ^= 1;
+                }
+                if (stage && xb == cpr - 1) {
+                    img_commit(itA, nv[0], nrow[0]);
+                    img_commit(itB, nv[1], nrow[1]);
+                    img_commit(itA, nv[2], nrow[2]);
+                    img_commit(itB, nv[3], nrow[3]);
+                }
+                m = mn; xb = xn;
+                __syncthreads();
+                return have_next;
+            };
+            for (;;) {
+                if (!block(S0{})) break;
+                if (!block(S1{})) break;
+            }
+        }
+        return;
+    }
+
+    // ================= consumers: wave w owns output-channel tile w and the five im2col tiles =================
+    // (the consumer is the pole of its SIMD: its instructions go first, the producer's VALU work takes the slots it leaves)
+    __builtin_amdgcn_s_setprio(SPL_CONS_PRIO);
+    const int nt = wave;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // this lane's im2col column per k-tile: its line inside a plane (+ the dword the five-dword window starts at), its row offset ky and the byte
     // shift of the window; columns >= 147 read the zero slot
-    int kline[3], kky[3], ksh[3];
+    int kline[5], kky[5], ksh[5];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int k = (half * 3 + t) * 32 + li;
-        const bool valid = k < STEM_K && (half == 0 || t < 2);
+    for (int t = 0; t < 5; ++t) {
+        const int k = t * 32 + li;
+        const bool valid = k < STEM_K;
         const int c = k / 49, rem = k - (k / 49) * 49;
         const int ky = rem / 7, kx = rem - (rem / 7) * 7;
         kline[t] = valid ? (2 * c + (kx & 1)) * LP + 4 * (kx >> 2) : 0;
@@ -2085,87 +2253,69 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_planes_kernel(cons
     // transpose-read address of this lane inside a dY plane (wgrad5_split_kernel): pixel 8 hi + ((l & 15) >> 2) (+ 4 for the second read),
     // channel piece 16 ((l >> 4) & 1) + 4 (l & 3) of output-channel tile nt
     const int off_a = (8 * hi + ((lane & 15) >> 2)) * SPL_APITCH + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + nt * 64;
-
-    // ---- prologue: the first two chunks' loads, rows 2 r0 - 3 ... 2 r0 + 4 (four pairs, all requested before the first is cut)
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    if (nchunks > 0) issue(S0{}, 0);
-    if (nchunks > 1) issue(S1{}, 1);
-    {
-        f32x4n iv[4];
-        int ir[4];
+    if (nchunks > 0) {
+        SplCursor cc;
+        cur_init(cc);
+        __syncthreads();                                   // chunk 0 is cut
+        for (int ci = 0; ci < nchunks; ++ci) {
+            const int oy = cc.lo + cc.j;
+            const int x0 = SPL_P * cc.xb;
+            const char* cur = abuf0 + (ci & 1) * SPL_ABUF;
+#ifndef CUNET_SPL_NO_MMA       // probe builds (timing only, wrong results)
+            const int rb = 2 * oy + 1;                     // input row 2 oy - 3 + ky lives in slot (2 oy + 1 + ky) & 15
+            const char* bp[5];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) img_issue(iv[u], ir[u], 2 * r0 - 3 + 2 * u);
-        __syncthreads();                                   // the zeros are in place
-#pragma unroll
-        for (int u = 0; u < 4; ++u) img_commit(iv[u], ir[u]);
-    }
-    if (nchunks > 0) commit(S0{}, 0, abuf0);
-    __syncthreads();
-
-    f32x4n nv = {0.f, 0.f, 0.f, 0.f};                      // the row pair staged for the next output row
-    int nrow = 0;
-    auto contract = [&](auto HF, int ci, const char* cur) {
-        constexpr int CT = StemTiles<decltype(HF)::value>::N;
-        const int oy = r0 + ci / cpr;
-        const int x0 = SPL_P * (ci - (ci / cpr) * cpr);
-        const int rb = 2 * oy + 1;                         // input row 2 oy - 3 + ky lives in slot (2 oy + 1 + ky) & 15
-        const char* bp[CT];
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int sl = kky[t] >= 0 ? ((rb + kky[t]) & (SPL_NS - 1)) : SPL_NS;
-            bp[t] = smem + sl * SLOT + kline[t] + (kky[t] >= 0 ? 2 * (x0 + 8 * hi) : 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < SPL_P / 16; ++ks) {
-            const u32x4 ah = wg5_frag(cur + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
-            const u32x4 am = wg5_frag(cur + SPL_APLANE + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
-            const u32x4 al = wg5_frag(cur + 2 * SPL_APLANE + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
-            u32x4 b[CT][3];
-#pragma unroll
-            for (int t = 0; t < CT; ++t)
+            for (int t = 0; t < 5; ++t) {
+                const int sl = kky[t] >= 0 ? ((rb + kky[t]) & (SPL_NS - 1)) : SPL_NS;
+                bp[t] = smem + sl * SLOT + kline[t] + (kky[t] >= 0 ? 2 * (x0 + 8 * hi) : 0);
+            }
+            // ten stages (k-step, tile) per chunk, software-pipelined by hand: the dwords of stage i + 1 are requested BEFORE stage i's v_alignbyte /
+            // MFMAs (left alone hipcc requests a tile's dwords right in front of its own MFMAs: an LDS round trip exposed per tile)
+            unsigned raw[2][3][5];
+            u32x4 af[2][3];
+            auto rd = [&](int ks, int t, unsigned (&r)[3][5]) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     const char* s = bp[t] + pl * PL + 32 * ks;
                     const u32x2_a4 d01 = *reinterpret_cast<const u32x2_a4*>(s);
                     const u32x2_a4 d23 = *reinterpret_cast<const u32x2_a4*>(s + 8);
-                    const unsigned d4 = *reinterpret_cast<const unsigned*>(s + 16);
-                    b[t][pl] = u32x4{__builtin_amdgcn_alignbyte(d01.y, d01.x, ksh[t]), __builtin_amdgcn_alignbyte(d23.x, d01.y, ksh[t]),
-                                     __builtin_amdgcn_alignbyte(d23.y, d23.x, ksh[t]), __builtin_amdgcn_alignbyte(d4, d23.y, ksh[t])};
+                    r[pl][0] = d01.x; r[pl][1] = d01.y; r[pl][2] = d23.x; r[pl][3] = d23.y;
+                    r[pl][4] = *reinterpret_cast<const unsigned*>(s + 16);
                 }
-            __builtin_amdgcn_sched_barrier(0);
+            };
+            auto rda = [&](int ks, u32x4 (&a)[3]) {
 #pragma unroll
-            for (int t = 0; t < CT; ++t) acc[t] = mfma_split6(ah, am, al, b[t][0], b[t][1], b[t][2], acc[t]);
-        }
-    };
-    auto step = [&](auto PAR, int ci) {                    // PAR = ci & 1: set PAR held chunk ci (cut already), set PAR ^ 1 holds chunk ci + 1
-        using PN = std::integral_constant<int, decltype(PAR)::value ^ 1>;
-        const int oy = r0 + ci / cpr;
-        const int xq = ci - (ci / cpr) * cpr;
-        const bool stage = oy + 1 < r1;                    // rows 2 oy + 4, 2 oy + 5: the two output row oy + 1 adds
-        if (ci + 2 < nchunks) issue(PAR, ci + 2);
-        if (stage && xq == 0) img_issue(nv, nrow, 2 * oy + 4);
-        const char* cur = abuf0 + decltype(PAR)::value * SPL_ABUF;
-#ifndef CUNET_SPL_NO_MMA       // probe builds (timing only, wrong results)
-        if (half == 0) contract(std::integral_constant<int, 0>{}, ci, cur);
-        else contract(std::integral_constant<int, 1>{}, ci, cur);
+                for (int pl = 0; pl < 3; ++pl) a[pl] = wg5_frag(cur + pl * SPL_APLANE + off_a + ks * 16 * SPL_APITCH, 4 * SPL_APITCH);
+            };
+            rda(0, af[0]);
+            rd(0, 0, raw[0]);
+#pragma unroll
+            for (int st = 0; st < 10; ++st) {
+                const int ks = st / 5, t = st - 5 * (st / 5);
+                if (st + 1 < 10) rd((st + 1) / 5, (st + 1) - 5 * ((st + 1) / 5), raw[(st + 1) & 1]);
+                if (st == 3) rda(1, af[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned (&r)[5] = raw[st & 1][pl];
+                    b[pl] = u32x4{__builtin_amdgcn_alignbyte(r[1], r[0], ksh[t]), __builtin_amdgcn_alignbyte(r[2], r[1], ksh[t]),
+                                  __builtin_amdgcn_alignbyte(r[3], r[2], ksh[t]), __builtin_amdgcn_alignbyte(r[4], r[3], ksh[t])};
+                }
+                acc[t] = mfma_split6(af[ks][0], af[ks][1], af[ks][2], b[0], b[1], b[2], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #endif
-        // (the two waves of a SIMD walking a step in opposite order -- one contracts while the other cuts the next chunk -- measured 156 us against
-        // 144: the wave that cuts first waits for loads requested one step earlier)
-        if (ci + 1 < nchunks) commit(PN{}, ci + 1, abuf0 + PN::value * SPL_ABUF);
-        if (stage && xq == cpr - 1) img_commit(nv, nrow);
-        __syncthreads();
-    };
-    for (int ci = 0; ci < nchunks; ci += 2) {
-        step(S0{}, ci);
-        if (ci + 1 < nchunks) step(S1{}, ci + 1);
+            (void)cur_next(cc);
+            __syncthreads();
+        }
     }
 
     float* out = q.part + (size_t)blockIdx.x * 128 * STEM_K;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int k = (half * 3 + t) * 32 + li;
-        if (k >= STEM_K || (half == 1 && t == 2)) continue;
+    for (int t = 0; t < 5; ++t) {
+        const int k = t * 32 + li;
+        if (k >= STEM_K) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -2176,7 +2326,7 @@ __global__ __launch_bounds__(WG3_THREADS, 1) void wgrad3_stem_planes_kernel(cons
 size_t wgrad3_stem_planes_lds_bytes(int IW) { return (size_t)(SPL_NS + 1) * 18 * (IW + 8) + 2 * SPL_ABUF; }
 bool wgrad3_stem_planes_supported(const WgradArgs& a) {
     if (a.img == nullptr || a.Cout != 128 || a.lddy != 128 || a.Ccat != STEM_K) return false;
-    if (a.W % SPL_P || a.IW % 8 || a.IW != 2 * a.W || a.IH != 2 * a.H || 6 * (a.IW / 4) > WG3_THREADS) return false;
+    if (a.W % SPL_P || a.IW % 8 || a.IW != 2 * a.W || a.IH != 2 * a.H || 6 * (a.IW / 4) > SPL_PROD * 2) return false;
     return wgrad3_stem_planes_lds_bytes(a.IW) <= 160 * 1024;
 }
 
@@ -2219,8 +2369,8 @@ hipError_t launch_wgrad3_stem(const WgradArgs& a, float* part, int wpi, int rows
             }
             planes_attr_done = true;
         }
-        if (a.sx != nullptr) hipLaunchKernelGGL((wgrad3_stem_planes_kernel<true>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_planes_lds_bytes(a.IW), s, q);
-        else hipLaunchKernelGGL((wgrad3_stem_planes_kernel<false>), dim3(N * wpi), dim3(WG3_THREADS), wgrad3_stem_planes_lds_bytes(a.IW), s, q);
+        if (a.sx != nullptr) hipLaunchKernelGGL((wgrad3_stem_planes_kernel<true>), dim3(N * wpi), dim3(SPL_THREADS), wgrad3_stem_planes_lds_bytes(a.IW), s, q);
+        else hipLaunchKernelGGL((wgrad3_stem_planes_kernel<false>), dim3(N * wpi), dim3(SPL_THREADS), wgrad3_stem_planes_lds_bytes(a.IW), s, q);
         return hipGetLastError();
     }
     if (a.sx != nullptr) {

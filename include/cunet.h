@@ -324,6 +324,13 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
  *   "wgrad_split_planes" 0 (default; round 6, acts with f32_split): 1 = the fp32 1x1 weight gradient cuts its operands ONCE, on the way into LDS (three
  *                        bf16 planes, fragments by ds_read_b64_tr_b16: wgrad5_split_kernel) for slices of at most 8 channel tiles.  Bit-identical
  *                        partial tiles; 11-16 % less time for those launches alone, +-0.3 % on the CU-Net-2 step, +0.75 % on CU-Net-16
+ *   "stem_wgrad_planes"  1 (default; round 6, acts with f32_split + stem_wgrad_split): the stem's weight gradient cuts BOTH operands once on their way
+ *                        into LDS (image rows as three bf16 planes de-interleaved by column parity in a ring of 16 row slots, the dY chunk as three
+ *                        planes read by ds_read_b64_tr_b16), splits its workgroup into four consumer waves that only request fragments and multiply and
+ *                        four producer waves that only load / compute dz / cut, and walks its chunks by pooling-window row pair (conv0's output is read
+ *                        once instead of twice): wgrad3_stem_planes_kernel, 161 -> 112 us alone at the end of every step, +0.65 % on the CU-Net-2 step.
+ *                        Same pieces and products as wgrad3_stem_kernel<*, true>; the pixels enter the fp32 accumulators in another order (agreement
+ *                        ~3e-7 of the gradient's magnitude, tests/test_gpu_exact.py).  0 = that kernel (also the fallback for IW > 340)
  *   "stem_wgrad_caller"  0 (default; round 6): 1 = the stem's weight gradient and its reduce on the caller's stream behind the stem's BatchNorm
  *                        pass instead of behind the last bucket's work on the side stream.  Measured +0.1 ... 0.2 %
  *   "dgrad_prefetch"     fp32 1x1 data gradient over 128 output channels (every bottleneck / adapter), one channel tile per wave: 2 = two
@@ -351,8 +358,8 @@ int cunet_render_targets(const double* pts, const float* patch, int half, float*
 int cunet_set_planner_option(const char* name, int value);
 /* reads the process-wide value back (tests save / restore the options they change).  0, or CUNET_ERR_INVALID for an unknown name. */
 int cunet_get_planner_option(const char* name, int* value);
-/* debugging aid of the test-suite: changes "wgrad_bf16_dma" or "wgrad_split_planes" -- the options that only pick between bit-identical
- * kernels at launch time -- in the snapshot of a LIVE plan.  Any other name: CUNET_ERR_INVALID (those options shaped the plan's layout). */
+/* debugging aid of the test-suite: changes "wgrad_bf16_dma", "wgrad_split_planes" or "stem_wgrad_planes" -- the options that only pick between
+ * interchangeable kernels (same operands, same partial-tile layout) at launch time -- in the snapshot of a LIVE plan.  Any other name: CUNET_ERR_INVALID (those options shaped the plan's layout). */
 int cunet_debug_set_plan_option(cunet_plan_t* plan, const char* name, int value);
 /* debugging aid: tensors that a training step no longer materialises are written now, from the state the last cunet_backward left in the
  * workspace (today: d(loss)/d(conv0 output) under planner option "stem_fuse_dz").  The Python binding calls it before it reads a gradient

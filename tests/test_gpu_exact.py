@@ -700,15 +700,19 @@ def test_stem_weight_gradient_with_the_dz_pass_fused(n, h, w):
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
-@pytest.mark.parametrize('n,h,w', [(24, 256, 256), (3, 128, 256), (2, 256, 128), (1, 128, 128)])
-def test_stem_weight_gradient_with_both_operands_cut_once_is_bit_identical(n, h, w):
+@pytest.mark.parametrize('n,h,w', [(24, 256, 256), (3, 128, 256), (2, 256, 128), (1, 128, 128), (5, 192, 256)])
+def test_stem_weight_gradient_with_both_operands_cut_once(n, h, w):
     """wgrad3_stem_planes_kernel (round 6, planner option stem_wgrad_planes): the image rows in an LDS ring of three bf16 planes de-interleaved by
-    column parity, the dY chunk cut behind the fused BatchNorm / ReLU / pool backward into three planes read by ds_read_b64_tr_b16 -- against
-    wgrad3_stem_kernel<*, true> (fp32 rows and chunk in LDS, every wave cuts what it reads) on the SAME plan state: the same pieces enter the same six
-    products in the same pixel order over the same rows per workgroup, so conv0's weight gradient (autograd wgrad of models/cu_net.py:300) must
-    agree bit for bit -- the fused kernel of a real backward pass (planes) == the unfused planes kernel on the materialised d(loss)/d(conv0 output)
-    == the unfused staging kernel on the same tensor.  The bench batch, rectangular batches (2 / 4 chunks per output row, ragged last workgroup of
-    an image) and one small image."""
+    column parity, the dY chunk cut behind the fused BatchNorm / ReLU / pool backward into three planes read by ds_read_b64_tr_b16, four consumer waves
+    that only multiply and four producer waves that only load / cut, chunks walked by pooling-window row pair -- against wgrad3_stem_kernel<*, true>
+    (fp32 rows and chunk in LDS, every wave cuts what it reads) on the SAME plan state.  conv0's weight gradient (autograd wgrad of models/cu_net.py:300):
+    (1) bit for bit: the fused planes kernel of a real backward pass == the unfused planes kernel on the materialised d(loss)/d(conv0 output) -- the dz
+    arithmetic inside the producers is stem_bwd_kernel<1>'s, operation for operation;
+    (2) against the staging kernel on the same tensor: the same pieces enter the same six products over the same rows per workgroup, but a workgroup's
+    pixels enter its fp32 accumulators row pair by row pair instead of row by row -- agreement to the summation order: 2e-6 of the gradient's magnitude
+    per element (the sum runs over N x 128 x 128 products; measured ~2e-7).
+    The bench batch, rectangular batches (2 / 4 column blocks per output row; 13-row workgroups start on odd rows: single rows of a pair at either
+    end of a workgroup's range), a small image."""
     from oracle import cunet_ref as O
     cfg = dict(neck_size=4, growth_rate=32, init_chan_num=128, class_num=16, layer_num=2, order=1, loss_num=2)
     spec = O.Spec(**cfg)
@@ -741,10 +745,13 @@ def test_stem_weight_gradient_with_both_operands_cut_once_is_bit_identical(n, h,
             got[planes] = net._grad_arena[o:o + nmel].clone()
     finally:
         plan.debug_set_option('stem_wgrad_planes', 0)
-    for name, g in (('unfused planes', got[1]), ('fused planes', fused)):
-        if not torch.equal(g, got[0]):
-            dd = (g - got[0]).abs()
-            raise AssertionError(f'{name}: {int((dd > 0).sum())}/{nmel} elements differ from the staging kernel, max {float(dd.max()):.3e} of {float(got[0].abs().max()):.3e}')
+    if not torch.equal(fused, got[1]):
+        dd = (fused - got[1]).abs()
+        raise AssertionError(f'fused vs unfused planes kernel: {int((dd > 0).sum())}/{nmel} elements differ, max {float(dd.max()):.3e} of {float(got[1].abs().max()):.3e}')
+    scale = float(got[0].abs().max())
+    err = float((got[1] - got[0]).abs().max())
+    print(f'planes vs staging kernel: max |diff| {err:.3e} of {scale:.3e}')
+    assert err <= 2e-6 * scale, (err, scale)
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16_grads'])

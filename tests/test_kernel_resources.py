@@ -45,6 +45,8 @@ EXPECT = {
         'wgrad3_stem_kernelILb1ELb1E': 256,                # stem weight gradient: dz computed while staging, split contraction (round 5)
         'wgrad5_split_kernelILi5E': 256,                   # round 6 (planner option wgrad_split_planes): operands cut once, planes + transpose reads
         'wgrad5_split_kernelILi8E': 256,
+        'wgrad3_stem_planes_kernelILb1E': 256,             # round 6 (planner option stem_wgrad_planes, default): ring of bf16 planes, consumer / producer waves
+        'wgrad3_stem_planes_kernelILb0E': 256,
     },
     'bf16_kernels.hip': {
         'dgrad_bf16_kernelILi1ELi2ELi4ELb0E': 168,         # bf16 1x1 data gradient, two channel tiles, K = 128 (12 waves)

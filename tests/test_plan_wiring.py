@@ -191,7 +191,7 @@ def test_planner_options_read_back_and_are_restored_between_tests():
     assert set(snap) == set(PLANNER_OPTIONS)
     if not os.environ.get('CUNET_TEST_PLANNER_OPTS'):
         assert (snap['f32_split'], snap['dgrad_rows_v'], snap['popcount_pixels'], snap['stem_fuse_dz'], snap['wgrad_fork_group'], snap['dgrad_rows']) == (1, 2, 1, 1, 0, -1)
-        assert (snap['fuse_pool_gather'], snap['fuse_z_gather'], snap['stem_wgrad_caller'], snap['wgrad_split_planes']) == (1, 0, 0, 0)      # round 6
+        assert (snap['fuse_pool_gather'], snap['fuse_z_gather'], snap['stem_wgrad_caller'], snap['wgrad_split_planes'], snap['stem_wgrad_planes']) == (1, 0, 0, 0, 1)      # round 6
     with pytest.raises(CUNetError):
         get_planner_option('no_such_option')
     for name in PLANNER_OPTIONS:

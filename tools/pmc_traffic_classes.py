@@ -2,7 +2,7 @@
 import re
 
 CLASSES = [      # first match wins: the bf16-MFMA kernels carry bench.py's *_bf16 class names
-    (r'wgrad3_stem_kernel', 'stem_bwd_weight'),
+    (r'wgrad3_stem_kernel|wgrad3_stem_planes_kernel', 'stem_bwd_weight'),
     (r'wgrad3_3x3_bf16_kernel', 'conv3x3_bwd_weight_bf16'),
     (r'wgrad3_bf16_kernel|wgrad4_bf16_kernel', 'conv1x1_bwd_weight_bf16'),
     (r'wgrad3_3x3_kernel', 'conv3x3_bwd_weight'),
