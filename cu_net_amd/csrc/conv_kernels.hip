@@ -1591,6 +1591,9 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_split_kernel(const ConvArgs p
     const int th = wave >> 2;                                     // tiles 2 th, 2 th + 1 of the row (and th + 2 ... for wider rows)
     typedef float f32x4n __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+    unsigned yoff[4];                                             // byte offset of this lane's element in pixel row 8 g + 4 hi of a 32-pixel output tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) yoff[g] = 4u * (unsigned)((8 * g + 4 * hi) * p.ldy + nt * 32 + li);
 
     for (int i = tid; i < 8 * SLOT / 16; i += 512) reinterpret_cast<float4*>(ring)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 256; i += 512) redbuf[i] = 0.0;
@@ -1703,11 +1706,13 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_split_kernel(const ConvArgs p
                 // C layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 hi (pixel)
                 float s1 = 0.f, s2 = 0.f;
                 const size_t m0 = ((size_t)R * OW + txx * 32);
+                // (round 6) a uniform base per pixel row + four kernel-constant 32-bit lane offsets: a store is one instruction (the 64-bit address of
+                // every element took ~7 VALU instructions in front of its store: 103.5 -> 99.6 us, 256 registers + spills -> 236)
+                const char* yb = reinterpret_cast<const char*>(p.y + m0 * p.ldy);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int px = (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const float v = acc[r];
-                    p.y[(m0 + px) * p.ldy + nt * 32 + li] = v;
+                    *reinterpret_cast<float*>(const_cast<char*>(yb) + (size_t)(r & 3) * p.ldy * 4 + yoff[r >> 2]) = v;
                     s1 += v;
                     s2 = fmaf(v, v, s2);
                 }
